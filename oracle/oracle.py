@@ -1,0 +1,160 @@
+"""ctypes binding of the CPU oracle (oracle/plen_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (plen_ml_walk_amd) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS = {}
+
+
+def build(force=False):
+    """Compile the oracle shared objects with gcc (a few seconds)."""
+    targets = ["libplen_oracle_f64.so", "libplen_oracle_f32.so"]
+    if force or not all(os.path.exists(os.path.join(_HERE, t)) for t in targets):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + targets)
+
+
+def _lib(dtype="f64"):
+    if dtype not in _LIBS:
+        path = os.path.join(_HERE, "libplen_oracle_%s.so" % dtype)
+        if not os.path.exists(path):
+            build()
+        lib = C.CDLL(path)
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+        lib.oracle_create.restype = C.c_void_p
+        lib.oracle_create.argtypes = [C.c_int]
+        lib.oracle_destroy.argtypes = [C.c_void_p]
+        lib.oracle_set_params.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        lib.oracle_set_world.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        lib.oracle_get_state.argtypes = [C.c_void_p, dp]
+        lib.oracle_set_state.argtypes = [C.c_void_p, dp]
+        lib.oracle_get_aux.argtypes = [C.c_void_p, ip]
+        lib.oracle_set_targets.argtypes = [C.c_void_p, dp]
+        lib.oracle_substep.argtypes = [C.c_void_p]
+        lib.oracle_contacts.argtypes = [C.c_void_p, ip]
+        lib.oracle_forward_dynamics.argtypes = [C.c_void_p, dp]
+        lib.oracle_minv_times.argtypes = [C.c_void_p, dp, dp]
+        lib.oracle_link_frames.argtypes = [C.c_void_p, dp, dp, dp]
+        lib.oracle_agent_to_env.restype = C.c_double
+        lib.oracle_agent_to_env.argtypes = [C.c_int, C.c_double]
+        lib.oracle_script_reset.argtypes = [C.c_void_p]
+        lib.oracle_script_step.restype = C.c_double
+        lib.oracle_script_step.argtypes = [C.c_void_p, dp] + [C.c_double] * 6 + [C.c_int] * 2 + [C.c_double] * 4 + [ip]
+        lib.oracle_reset.argtypes = [C.c_void_p, dp]
+        lib.oracle_step.restype = C.c_double
+        lib.oracle_step.argtypes = [C.c_void_p, dp, dp, ip]
+        lib.oracle_rollout.restype = C.c_int
+        lib.oracle_rollout.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), dp, dp, C.POINTER(C.c_uint8)]
+        _LIBS[dtype] = lib
+    return _LIBS[dtype]
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class OracleEnv(object):
+    """One PLEN environment on the CPU oracle; mirrors PlenWalkEnv.reset/step (plen_env.py:558,638)."""
+
+    def __init__(self, joint_act=False, dtype="f64"):
+        self.lib = _lib(dtype)
+        self.h = self.lib.oracle_create(int(joint_act))
+
+    def __del__(self):
+        try:
+            self.lib.oracle_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_params(self, mass_scale=1.0, lateral_friction=-1.0):
+        self.lib.oracle_set_params(self.h, float(mass_scale), float(lateral_friction))
+
+    def set_world(self, num_iterations=0, residual_threshold=-1.0):
+        self.lib.oracle_set_world(self.h, int(num_iterations), float(residual_threshold))
+
+    def reset(self):
+        obs = np.zeros(26)
+        self.lib.oracle_reset(self.h, _dp(obs))
+        return obs
+
+    def step(self, action):
+        a = np.ascontiguousarray(action, dtype=np.float64)
+        obs = np.zeros(26)
+        done = C.c_int(0)
+        r = self.lib.oracle_step(self.h, _dp(a), _dp(obs), C.byref(done))
+        return obs, r, bool(done.value), {}
+
+    def rollout(self, actions):
+        """actions float32 [T,18] -> obs [T,26], rew [T], flags uint8 [T] (bit0 terminal, bit1 time limit)."""
+        a = np.ascontiguousarray(actions, dtype=np.float32)
+        T = a.shape[0]
+        obs = np.zeros((T, 26))
+        rew = np.zeros(T)
+        flags = np.zeros(T, dtype=np.uint8)
+        self.lib.oracle_rollout(self.h, T, a.ctypes.data_as(C.POINTER(C.c_float)), _dp(obs), _dp(rew),
+                                flags.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return obs, rew, flags
+
+    # ---- state access -------------------------------------------------------------------
+    def get_state(self):
+        s = np.zeros(49)
+        self.lib.oracle_get_state(self.h, _dp(s))
+        return s
+
+    def set_state(self, s):
+        s = np.ascontiguousarray(s, dtype=np.float64)
+        assert s.shape == (49,)
+        self.lib.oracle_set_state(self.h, _dp(s))
+
+    def get_aux(self):
+        a = (C.c_int * 6)()
+        self.lib.oracle_get_aux(self.h, a)
+        return dict(zip(["gait_period_counter", "double_support_counter", "episode_timestep", "dead", "first_pass", "nhist"], list(a)))
+
+    def set_targets(self, t):
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        self.lib.oracle_set_targets(self.h, _dp(t))
+
+    def substep(self):
+        self.lib.oracle_substep(self.h)
+
+    def contacts(self):
+        a = (C.c_int * 4)()
+        self.lib.oracle_contacts(self.h, a)
+        return dict(right=a[0], left=a[1], ncp=a[2], iterations=a[3])
+
+    def forward_dynamics(self):
+        qdd = np.zeros(24)
+        self.lib.oracle_forward_dynamics(self.h, _dp(qdd))
+        return qdd
+
+    def minv_times(self, f):
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        out = np.zeros(24)
+        self.lib.oracle_minv_times(self.h, _dp(f), _dp(out))
+        return out
+
+    def link_frames(self):
+        R = np.zeros((33, 9)); O = np.zeros((33, 3)); Cc = np.zeros((33, 3))
+        self.lib.oracle_link_frames(self.h, _dp(R), _dp(O), _dp(Cc))
+        return R.reshape(33, 3, 3), O, Cc
+
+    # ---- python-level arithmetic pins -----------------------------------------------------
+    def script_reset(self):
+        self.lib.oracle_script_reset(self.h)
+
+    def script_step(self, q18, z, vx, roll, pitch, yaw, y, rc, lc, lroll, lpitch, rroll, rpitch):
+        q = np.ascontiguousarray(q18, dtype=np.float64)
+        done = C.c_int(0)
+        r = self.lib.oracle_script_step(self.h, _dp(q), z, vx, roll, pitch, yaw, y, int(rc), int(lc),
+                                        lroll, lpitch, rroll, rpitch, C.byref(done))
+        return r, bool(done.value)
+
+
+def agent_to_env(joint, a, dtype="f64"):
+    return _lib(dtype).oracle_agent_to_env(int(joint), float(a))

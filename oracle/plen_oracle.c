@@ -1,0 +1,899 @@
+/*
+ * plen_oracle.c -- CPU ORACLE (test infrastructure, NOT the product path).
+ *
+ * A plain-C restatement of the algorithm the reference's hot path runs:
+ *   plen_bullet/src/plen_bullet/plen_env.py  PlenWalkEnv.step  (:638-692), reset (:558-614),
+ *   agent_to_env (:694-714), move_joints (:716-753), compute_observation (:768-871),
+ *   compute_reward (:873-1070), compute_done (:1072-1093),
+ * including what `p.stepSimulation()` (:667) does inside the third-party `pybullet` module.
+ *
+ * PARITY UNPINNED for the physics: pybullet / Bullet is NOT vendored by the reference, NOT version
+ * pinned (no requirements file) and NOT installed in the build container, and the reference has no
+ * tests or golden vectors for it.  The physics below restates Bullet's published multibody
+ * algorithm (era ~2.89, early 2020) as documented in DESIGN.md section "Oracle":
+ *   btMultiBody::computeAccelerationsArticulatedBodyAlgorithmMultiDof  (Featherstone ABA, explicit
+ *       gyroscopic term, semi-implicit Euler: v += dt*a before the constraint solve),
+ *   btMultiBody::calcAccelerationDeltasMultiDof                         (unit-impulse response),
+ *   btMultiBodyJointMotor / btMultiBodyJointLimitConstraint::createConstraintRows,
+ *   btMultiBodyConstraintSolver::setupMultiBodyContactConstraint / ...TorsionalFriction...,
+ *   btMultiBodyConstraintSolver::solveSingleIteration / resolveSingleConstraintRowGeneric /
+ *       resolveConeFrictionConstraintRows, residual early-out,
+ *   btMultiBody::stepPositionsMultiDof (exponential-map quaternion update),
+ *   pybullet.c getEulerFromQuaternion,
+ * with PyBullet's world defaults (50 iterations, erp2 0.08, linearSlop 1e-5, residual 1e-7, ...).
+ * The Python-level arithmetic (action map, reward, termination, gait bookkeeping) IS pinned: it is
+ * checked against golden vectors captured from the reference itself (tests/golden/, made by
+ * tools/make_golden.py) in tests/test_oracle_golden.py.
+ *
+ * Known, documented deviation: contact generation.  Bullet runs GJK/EPA foot-hull vs ground-box
+ * with a persistent 4-point manifold whose point positions depend on solver history; that is not
+ * reproducible without Bullet itself.  Here each foot has 4 fixed candidate points (corner-most
+ * sole-hull vertices, 1 mm spherical margin) tested against the half-space z<=0; a candidate is a
+ * manifold point while its distance is below the foot's contact-breaking threshold.  Only the two
+ * feet collide with the ground (self-collision is off in the reference).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ *
+ * Build:  make -C oracle     (gcc -O2 -fPIC -shared; -DORACLE_REAL=float for the f32 variant)
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include "plen_model_raw.h"
+
+#ifndef ORACLE_REAL
+#define ORACLE_REAL double
+#endif
+typedef ORACLE_REAL real;
+
+#define NL RAW_NLINKS          /* 32 non-base links                               */
+#define ND RAW_NDOF            /* 18 joint DoF                                    */
+#define NV (6 + ND)            /* generalized velocity: base omega(3), v(3), qd   */
+#define MAXCP 8                /* 2 feet x 4 candidate points                     */
+#define MAXROWS (36 + MAXCP * 6)
+#define HIST 1024
+
+/* ---------------------------------------------------------------- small math helpers */
+static inline void v3set(real *a, real x, real y, real z) { a[0] = x; a[1] = y; a[2] = z; }
+static inline void v3cpy(real *a, const real *b) { a[0] = b[0]; a[1] = b[1]; a[2] = b[2]; }
+static inline real v3dot(const real *a, const real *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void v3cross(real *c, const real *a, const real *b) {
+    real x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    c[0] = x; c[1] = y; c[2] = z;
+}
+static inline void v3sub(real *c, const real *a, const real *b) { c[0] = a[0] - b[0]; c[1] = a[1] - b[1]; c[2] = a[2] - b[2]; }
+static inline void v3add(real *c, const real *a, const real *b) { c[0] = a[0] + b[0]; c[1] = a[1] + b[1]; c[2] = a[2] + b[2]; }
+static inline void v3axpy(real *y, real a, const real *x) { y[0] += a * x[0]; y[1] += a * x[1]; y[2] += a * x[2]; }
+static inline real v3norm(const real *a) { return (real)sqrt((double)v3dot(a, a)); }
+static inline void m3mulv(real *o, const real *M, const real *v) {
+    real x = M[0] * v[0] + M[1] * v[1] + M[2] * v[2];
+    real y = M[3] * v[0] + M[4] * v[1] + M[5] * v[2];
+    real z = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+static inline void m3mul(real *o, const real *A, const real *B) {
+    real t[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
+        t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+    memcpy(o, t, sizeof t);
+}
+/* rotation about a unit axis by angle (Rodrigues) */
+static void axis_angle(real *R, const real *a, real q) {
+    real c = (real)cos((double)q), s = (real)sin((double)q), t = 1 - c;
+    R[0] = c + a[0] * a[0] * t;        R[1] = a[0] * a[1] * t - a[2] * s; R[2] = a[0] * a[2] * t + a[1] * s;
+    R[3] = a[1] * a[0] * t + a[2] * s; R[4] = c + a[1] * a[1] * t;        R[5] = a[1] * a[2] * t - a[0] * s;
+    R[6] = a[2] * a[0] * t - a[1] * s; R[7] = a[2] * a[1] * t + a[0] * s; R[8] = c + a[2] * a[2] * t;
+}
+/* quaternion (x,y,z,w), body->world */
+static void quat_to_mat(real *R, const real *q) {
+    real x = q[0], y = q[1], z = q[2], w = q[3];
+    real d = x * x + y * y + z * z + w * w, s = 2 / d;
+    real xs = x * s, ys = y * s, zs = z * s;
+    real wx = w * xs, wy = w * ys, wz = w * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
+    R[0] = 1 - (yy + zz); R[1] = xy - wz;       R[2] = xz + wy;
+    R[3] = xy + wz;       R[4] = 1 - (xx + zz); R[5] = yz - wx;
+    R[6] = xz - wy;       R[7] = yz + wx;       R[8] = 1 - (xx + yy);
+}
+static void mat_to_quat(real *q, const real *R) {   /* btMatrix3x3::getRotation */
+    real tr = R[0] + R[4] + R[8];
+    if (tr > 0) {
+        real s = (real)sqrt((double)(tr + 1));
+        q[3] = s * (real)0.5; s = (real)0.5 / s;
+        q[0] = (R[7] - R[5]) * s; q[1] = (R[2] - R[6]) * s; q[2] = (R[3] - R[1]) * s;
+    } else {
+        int i = R[0] < R[4] ? (R[4] < R[8] ? 2 : 1) : (R[0] < R[8] ? 2 : 0);
+        int j = (i + 1) % 3, k = (i + 2) % 3;
+        real s = (real)sqrt((double)(R[4 * i] - R[4 * j] - R[4 * k] + 1));
+        q[i] = s * (real)0.5; s = (real)0.5 / s;
+        q[3] = (R[3 * k + j] - R[3 * j + k]) * s;
+        q[j] = (R[3 * j + i] + R[3 * i + j]) * s;
+        q[k] = (R[3 * k + i] + R[3 * i + k]) * s;
+    }
+}
+/* pybullet.c getEulerFromQuaternion (plen_env.py:799, :1017, :1030) */
+static void quat_to_euler(real *rpy, const real *q) {
+    real sqx = q[0] * q[0], sqy = q[1] * q[1], sqz = q[2] * q[2], squ = q[3] * q[3];
+    real sarg = -2 * (q[0] * q[2] - q[3] * q[1]);
+    const real PI = (real)3.14159265358979323846;
+    if (sarg <= (real)-0.99999) {
+        rpy[0] = 0; rpy[1] = (real)-0.5 * PI; rpy[2] = 2 * (real)atan2((double)q[0], (double)-q[1]);
+    } else if (sarg >= (real)0.99999) {
+        rpy[0] = 0; rpy[1] = (real)0.5 * PI; rpy[2] = 2 * (real)atan2((double)-q[0], (double)q[1]);
+    } else {
+        rpy[0] = (real)atan2((double)(2 * (q[1] * q[2] + q[3] * q[0])), (double)(squ - sqx - sqy + sqz));
+        rpy[1] = (real)asin((double)sarg);
+        rpy[2] = (real)atan2((double)(2 * (q[0] * q[1] + q[3] * q[2])), (double)(squ + sqx - sqy - sqz));
+    }
+}
+
+/* 6x6 helpers; spatial vectors are [angular(3); linear(3)] in WORLD axes about a body's COM */
+static void m6mulv(real *o, const real *M, const real *v) {
+    real t[6];
+    for (int i = 0; i < 6; i++) { real s = 0; for (int j = 0; j < 6; j++) s += M[6 * i + j] * v[j]; t[i] = s; }
+    memcpy(o, t, sizeof t);
+}
+static real v6dot(const real *a, const real *b) { real s = 0; for (int i = 0; i < 6; i++) s += a[i] * b[i]; return s; }
+/* shift a wrench given about point c (child) to point p (parent), r = c - p:  n_p = n_c + r x f */
+static void wrench_shift(real *o, const real *w, const real *r) {
+    real t[3]; v3cross(t, r, w + 3);
+    o[0] = w[0] + t[0]; o[1] = w[1] + t[1]; o[2] = w[2] + t[2]; o[3] = w[3]; o[4] = w[4]; o[5] = w[5];
+}
+/* shift an (acceleration-like) motion vector from p to c = p + r:  a_c = a_p + alpha x r */
+static void motion_shift(real *o, const real *m, const real *r) {
+    real t[3]; v3cross(t, m, r);
+    o[0] = m[0]; o[1] = m[1]; o[2] = m[2]; o[3] = m[3] + t[0]; o[4] = m[4] + t[1]; o[5] = m[5] + t[2];
+}
+/* I_p += X^T I X with X the motion shift p->c (r = c - p) */
+static void inertia_shift_add(real *Ip, const real *Ic, const real *r) {
+    /* X = [[1,0],[-[r]x,1]];  X^T = [[1,[r]x],[0,1]] */
+    real X[36] = {0}, T[36], O[36];
+    for (int i = 0; i < 6; i++) X[7 * i] = 1;
+    /* -[r]x in the lower-left block */
+    X[6 * 3 + 1] = r[2];  X[6 * 3 + 2] = -r[1];
+    X[6 * 4 + 0] = -r[2]; X[6 * 4 + 2] = r[0];
+    X[6 * 5 + 0] = r[1];  X[6 * 5 + 1] = -r[0];
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { real s = 0; for (int k = 0; k < 6; k++) s += Ic[6 * i + k] * X[6 * k + j]; T[6 * i + j] = s; }
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { real s = 0; for (int k = 0; k < 6; k++) s += X[6 * k + i] * T[6 * k + j]; O[6 * i + j] = s; }
+    for (int i = 0; i < 36; i++) Ip[i] += O[i];
+}
+/* solve 6x6 SPD system by Cholesky */
+static void solve6(real *x, const real *A, const real *b) {
+    real L[36] = {0};
+    for (int j = 0; j < 6; j++) {
+        real s = A[7 * j];
+        for (int k = 0; k < j; k++) s -= L[6 * j + k] * L[6 * j + k];
+        real d = (real)sqrt((double)s); L[7 * j] = d;
+        for (int i = j + 1; i < 6; i++) {
+            real t = A[6 * i + j];
+            for (int k = 0; k < j; k++) t -= L[6 * i + k] * L[6 * j + k];
+            L[6 * i + j] = t / d;
+        }
+    }
+    real y[6];
+    for (int i = 0; i < 6; i++) { real t = b[i]; for (int k = 0; k < i; k++) t -= L[6 * i + k] * y[k]; y[i] = t / L[7 * i]; }
+    for (int i = 5; i >= 0; i--) { real t = y[i]; for (int k = i + 1; k < 6; k++) t -= L[6 * k + i] * x[k]; x[i] = t / L[7 * i]; }
+}
+
+/* ---------------------------------------------------------------- world parameters */
+typedef struct {
+    real dt;                 /* 1/240: PyBullet default, never changed (plen_env.py:298-305 commented) */
+    real gravity[3];         /* plen_env.py:296 */
+    int num_iterations;      /* PyBullet default 50 */
+    real erp;                /* 0.2  (non-contact rows) */
+    real erp2;               /* 0.08 (contact rows, PyBullet override) */
+    real friction_erp;       /* 0.2 */
+    real global_cfm;         /* 0 */
+    real linear_slop;        /* 1e-5 (PyBullet override) */
+    real residual_threshold; /* 1e-7 (PyBullet override) */
+    real restitution_velocity_threshold; /* 0.2 */
+    real max_coordinate_velocity;        /* btMultiBody m_maxCoordinateVelocity 100 */
+    real lateral_friction;   /* foot 0.8 x plane 0.8 (plen_env.py:309,444) */
+    real spinning_friction;  /* foot 0.1 x plane lateral 0.8 */
+    real rolling_friction;   /* foot 0.1 (0.01 joint_act) x 0.8 (plen_env.py:439-442) */
+    real restitution;        /* 0.5 x 0.5 (plen_env.py:309,481) */
+    real linear_damping;     /* 0 (0.1 joint_act) (plen_env.py:472-480) */
+    real angular_damping;    /* 0 */
+    real motor_kp, motor_kd; /* PyBullet POSITION_CONTROL defaults 0.1 / 1.0 */
+    real motor_max_force;    /* 0.15 (plen_env.py:753) */
+} World;
+
+typedef struct {
+    /* ---- physics state (49 reals) ---- */
+    real base_pos[3], base_quat[4], base_omega[3], base_vel[3], q[ND], qd[ND];
+    real target[ND];
+    /* ---- model (mutable for domain randomisation) ---- */
+    real mass[NL + 1], inertia[NL + 1][3];   /* index 0 = base, i+1 = link i */
+    World w;
+    int joint_act;
+    /* ---- kinematics cache ---- */
+    real Rw[NL + 1][9], Ow[NL + 1][3], Cw[NL + 1][3], Aw[NL + 1][3];
+    real Iw[NL + 1][9];
+    /* ---- ABA cache ---- */
+    real IA[NL + 1][36], U[NL + 1][6], Dinv[NL + 1], S[NL + 1][6];
+    /* ---- contact state of the last collision pass ---- */
+    int ncp; int cp_foot[MAXCP]; real cp_pos[MAXCP][3]; real cp_dist[MAXCP];
+    int right_contact, left_contact;
+    int last_iterations; real last_residual;
+    /* ---- env-level state (plen_env.py attributes) ---- */
+    int gait_period_counter, double_support_counter, episode_timestep, dead, first_pass;
+    real torso_z, torso_y, torso_vx, roll, pitch, yaw;
+    real diffs[6];
+    int nhist; real hist[6][HIST];  /* lhip,rhip,lknee,rknee,lankle,rankle = joints 2,8,3,9,4,10 */
+} Oracle;
+
+static const real ENV_RANGES[ND][2] = {   /* plen_env.py:148-167 */
+    {-1.57, 1.57}, {-0.15, 1.5}, {-0.95, 0.75}, {-0.9, 0.3}, {-0.95, 1.2}, {-0.8, 0.4},
+    {-1.57, 1.57}, {-1.5, 0.15}, {-0.75, 0.95}, {-0.3, 0.9}, {-1.2, 0.95}, {-0.4, 0.8},
+    {-1.57, 1.57}, {-0.15, 1.57}, {-0.2, 0.35}, {-1.57, 1.57}, {-0.15, 1.57}, {-0.2, 0.35}};
+
+static void world_defaults(World *w, int joint_act) {
+    w->dt = (real)(1.0 / 240.0);
+    v3set(w->gravity, 0, 0, (real)-9.81);
+    w->num_iterations = 50;
+    w->erp = (real)0.2; w->erp2 = (real)0.08; w->friction_erp = (real)0.2; w->global_cfm = 0;
+    w->linear_slop = (real)0.00001; w->residual_threshold = (real)1e-7;
+    w->restitution_velocity_threshold = (real)0.2; w->max_coordinate_velocity = 100;
+    w->lateral_friction = (real)(0.8 * 0.8);
+    w->spinning_friction = (real)(0.1 * 0.8);
+    w->rolling_friction = (real)((joint_act ? 0.01 : 0.1) * 0.8);
+    w->restitution = (real)(0.5 * 0.5);
+    w->linear_damping = (real)(joint_act ? 0.1 : 0.0); w->angular_damping = 0;
+    w->motor_kp = (real)0.1; w->motor_kd = 1; w->motor_max_force = (real)0.15;
+}
+
+/* ---------------------------------------------------------------- forward kinematics */
+static void fk(Oracle *o) {
+    quat_to_mat(o->Rw[0], o->base_quat);
+    v3cpy(o->Ow[0], o->base_pos);
+    real c[3] = {(real)RAW_BASE_COM[0], (real)RAW_BASE_COM[1], (real)RAW_BASE_COM[2]}, t[3];
+    m3mulv(t, o->Rw[0], c); v3add(o->Cw[0], o->Ow[0], t);
+    v3set(o->Aw[0], 0, 0, 0);
+    for (int i = 0; i < NL; i++) {
+        int p = RAW_PARENT[i] + 1, b = i + 1;
+        real JR[9], jt[3], ax[3], Rq[9], Rl[9];
+        for (int k = 0; k < 9; k++) JR[k] = (real)RAW_JR[i][k];
+        for (int k = 0; k < 3; k++) { jt[k] = (real)RAW_JT[i][k]; ax[k] = (real)RAW_AXIS[i][k]; }
+        if (RAW_JTYPE[i] == 1) { axis_angle(Rq, ax, o->q[RAW_DOF[i]]); m3mul(Rl, JR, Rq); }
+        else memcpy(Rl, JR, sizeof Rl);
+        m3mul(o->Rw[b], o->Rw[p], Rl);
+        m3mulv(t, o->Rw[p], jt); v3add(o->Ow[b], o->Ow[p], t);
+        real cl[3] = {(real)RAW_COM[i][0], (real)RAW_COM[i][1], (real)RAW_COM[i][2]};
+        m3mulv(t, o->Rw[b], cl); v3add(o->Cw[b], o->Ow[b], t);
+        m3mulv(o->Aw[b], o->Rw[b], ax);
+    }
+    /* world inertia tensors R diag(I) R^T */
+    for (int b = 0; b <= NL; b++) {
+        const real *R = o->Rw[b]; const real *I = o->inertia[b];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
+            o->Iw[b][3 * i + j] = R[3 * i] * I[0] * R[3 * j] + R[3 * i + 1] * I[1] * R[3 * j + 1] + R[3 * i + 2] * I[2] * R[3 * j + 2];
+    }
+}
+
+/* ---------------------------------------------------------------- ABA
+ * World-axes formulation, every body's spatial quantities taken about its own COM, classical
+ * accelerations (see DESIGN.md "Oracle dynamics").  Generalized velocity layout follows btMultiBody:
+ * v[0..2] base angular velocity (world), v[3..5] base COM linear velocity (world), v[6+d] joint rates.
+ * qdd receives the generalized accelerations for zero joint torque (motors act as constraints).
+ */
+static void aba(Oracle *o, real *qdd) {
+    real om[NL + 1][3], vc[NL + 1][3], zeta[NL + 1][6], p[NL + 1][6], acc[NL + 1][6];
+    const World *w = &o->w;
+    v3cpy(om[0], o->base_omega); v3cpy(vc[0], o->base_vel);
+    /* pass 1: velocities, velocity-product accelerations, rigid-body bias wrenches */
+    for (int b = 0; b <= NL; b++) {
+        if (b > 0) {
+            int i = b - 1, pb = RAW_PARENT[i] + 1;
+            real qd = RAW_JTYPE[i] == 1 ? o->qd[RAW_DOF[i]] : 0;
+            real rel[3] = {o->Aw[b][0] * qd, o->Aw[b][1] * qd, o->Aw[b][2] * qd};
+            v3add(om[b], om[pb], rel);
+            real rpo[3], roc[3], t[3], t2[3];
+            v3sub(rpo, o->Ow[b], o->Cw[pb]);        /* parent COM -> joint origin */
+            v3sub(roc, o->Cw[b], o->Ow[b]);         /* joint origin -> child COM  */
+            v3cross(t, om[pb], rpo); v3add(vc[b], vc[pb], t);
+            v3cross(t, om[b], roc);  v3add(vc[b], vc[b], t);
+            /* zeta_ang = om_p x (a qd);  zeta_lin = om_p x (om_p x rpo) + zeta_ang x roc + om_c x (om_c x roc) */
+            v3cross(zeta[b], om[pb], rel);
+            v3cross(t, om[pb], rpo); v3cross(t2, om[pb], t); v3cpy(zeta[b] + 3, t2);
+            v3cross(t, zeta[b], roc); v3add(zeta[b] + 3, zeta[b] + 3, t);
+            v3cross(t, om[b], roc); v3cross(t2, om[b], t); v3add(zeta[b] + 3, zeta[b] + 3, t2);
+            /* joint motion subspace about the child COM: [a; a x roc] */
+            v3cpy(o->S[b], o->Aw[b]); v3cross(o->S[b] + 3, o->Aw[b], roc);
+        }
+        /* articulated inertia starts as the rigid-body inertia; bias = gyroscopic - gravity + damping */
+        real *IA = o->IA[b]; memset(IA, 0, 36 * sizeof(real));
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) IA[6 * i + j] = o->Iw[b][3 * i + j];
+        IA[21] = IA[28] = IA[35] = o->mass[b];
+        real Iom[3], g[3];
+        m3mulv(Iom, o->Iw[b], om[b]); v3cross(g, om[b], Iom);
+        real wn = v3norm(om[b]), vn = v3norm(vc[b]);
+        for (int k = 0; k < 3; k++) {
+            p[b][k] = g[k] + Iom[k] * (w->angular_damping + w->angular_damping * wn);
+            p[b][3 + k] = -o->mass[b] * w->gravity[k] + o->mass[b] * vc[b][k] * (w->linear_damping + w->linear_damping * vn);
+        }
+    }
+    /* pass 2: leaves -> root (links are in DFS pre-order, so reverse index order works) */
+    for (int b = NL; b >= 1; b--) {
+        int i = b - 1, pb = RAW_PARENT[i] + 1;
+        real r[3]; v3sub(r, o->Cw[b], o->Cw[pb]);
+        real Ia[36], pa[6], t6[6];
+        memcpy(Ia, o->IA[b], sizeof Ia);
+        if (RAW_JTYPE[i] == 1) {
+            m6mulv(o->U[b], o->IA[b], o->S[b]);
+            real D = v6dot(o->S[b], o->U[b]);
+            o->Dinv[b] = 1 / D;
+            real u = -v6dot(o->S[b], p[b]);            /* tau = 0 */
+            for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) Ia[6 * a + c] -= o->U[b][a] * o->Dinv[b] * o->U[b][c];
+            m6mulv(t6, Ia, zeta[b]);
+            for (int a = 0; a < 6; a++) pa[a] = p[b][a] + t6[a] + o->U[b][a] * o->Dinv[b] * u;
+        } else {
+            m6mulv(t6, Ia, zeta[b]);
+            for (int a = 0; a < 6; a++) pa[a] = p[b][a] + t6[a];
+        }
+        inertia_shift_add(o->IA[pb], Ia, r);
+        wrench_shift(t6, pa, r);
+        for (int a = 0; a < 6; a++) p[pb][a] += t6[a];
+    }
+    /* base: IA a0 = -p0 */
+    real rhs[6]; for (int a = 0; a < 6; a++) rhs[a] = -p[0][a];
+    solve6(acc[0], o->IA[0], rhs);
+    for (int a = 0; a < 6; a++) qdd[a] = acc[0][a];
+    /* pass 3: root -> leaves */
+    for (int b = 1; b <= NL; b++) {
+        int i = b - 1, pb = RAW_PARENT[i] + 1;
+        real r[3]; v3sub(r, o->Cw[b], o->Cw[pb]);
+        real ap[6]; motion_shift(ap, acc[pb], r);
+        for (int a = 0; a < 6; a++) ap[a] += zeta[b][a];
+        if (RAW_JTYPE[i] == 1) {
+            real u = -v6dot(o->S[b], p[b]);
+            real qa = o->Dinv[b] * (u - v6dot(o->U[b], ap));
+            qdd[6 + RAW_DOF[i]] = qa;
+            for (int a = 0; a < 6; a++) acc[b][a] = ap[a] + o->S[b][a] * qa;
+        } else memcpy(acc[b], ap, sizeof ap);
+    }
+}
+
+/* btMultiBody::calcAccelerationDeltasMultiDof: out = M^-1 force, using the cached ABA quantities */
+static void aba_delta(const Oracle *o, const real *force, real *out) {
+    real p[NL + 1][6], acc[NL + 1][6], u[NL + 1];
+    memset(p, 0, sizeof p);
+    for (int b = NL; b >= 1; b--) {
+        int i = b - 1, pb = RAW_PARENT[i] + 1;
+        real r[3]; v3sub(r, o->Cw[b], o->Cw[pb]);
+        real pa[6], t6[6];
+        if (RAW_JTYPE[i] == 1) {
+            u[b] = force[6 + RAW_DOF[i]] - v6dot(o->S[b], p[b]);
+            for (int a = 0; a < 6; a++) pa[a] = p[b][a] + o->U[b][a] * o->Dinv[b] * u[b];
+        } else memcpy(pa, p[b], sizeof pa);
+        wrench_shift(t6, pa, r);
+        for (int a = 0; a < 6; a++) p[pb][a] += t6[a];
+    }
+    real rhs[6]; for (int a = 0; a < 6; a++) rhs[a] = force[a] - p[0][a];
+    solve6(acc[0], o->IA[0], rhs);
+    for (int a = 0; a < 6; a++) out[a] = acc[0][a];
+    for (int b = 1; b <= NL; b++) {
+        int i = b - 1, pb = RAW_PARENT[i] + 1;
+        real r[3]; v3sub(r, o->Cw[b], o->Cw[pb]);
+        real ap[6]; motion_shift(ap, acc[pb], r);
+        if (RAW_JTYPE[i] == 1) {
+            real qa = o->Dinv[b] * (u[b] - v6dot(o->U[b], ap));
+            out[6 + RAW_DOF[i]] = qa;
+            for (int a = 0; a < 6; a++) acc[b][a] = ap[a] + o->S[b][a] * qa;
+        } else memcpy(acc[b], ap, sizeof ap);
+    }
+}
+
+/* ---------------------------------------------------------------- constraint rows */
+typedef struct {
+    real jac[NV], delta[NV];
+    real jac_diag_inv, rhs, cfm, lo, hi, applied, friction;
+    int friction_index;
+} Row;
+
+/* btMultiBody::fillContactJacobianMultiDof / fillConstraintJacobianMultiDof:
+ * row for direction (n_ang, n_lin) at world point P on link `link` (link index, base = -1) */
+static void fill_jacobian(const Oracle *o, int link, const real *P, const real *n_ang, const real *n_lin, real *jac) {
+    memset(jac, 0, NV * sizeof(real));
+    real r[3], t[3];
+    v3sub(r, P, o->Cw[0]); v3cross(t, r, n_lin);
+    for (int k = 0; k < 3; k++) { jac[k] = t[k] + n_ang[k]; jac[3 + k] = n_lin[k]; }
+    for (int i = link; i >= 0; i = RAW_PARENT[i]) {
+        if (RAW_JTYPE[i] != 1) continue;
+        int b = i + 1;
+        v3sub(r, P, o->Ow[b]); v3cross(t, r, n_lin);
+        jac[6 + RAW_DOF[i]] = v3dot(o->Aw[b], t) + v3dot(o->Aw[b], n_ang);
+    }
+}
+
+static void gen_vel(const Oracle *o, real *v) {
+    v3cpy(v, o->base_omega); v3cpy(v + 3, o->base_vel);
+    for (int d = 0; d < ND; d++) v[6 + d] = o->qd[d];
+}
+
+static real row_finish(const Oracle *o, Row *r, real cfm_in) {
+    aba_delta(o, r->jac, r->delta);
+    real d = 0; for (int k = 0; k < NV; k++) d += r->jac[k] * r->delta[k];
+    d += cfm_in;
+    const real EPS = (sizeof(real) == 8) ? (real)2.220446049250313e-16 : (real)1.1920929e-07f;
+    r->jac_diag_inv = d > EPS ? 1 / d : 0;
+    real v[NV], rel = 0; gen_vel(o, v);
+    for (int k = 0; k < NV; k++) rel += v[k] * r->jac[k];
+    r->applied = 0;
+    return rel;
+}
+
+/* btSequentialImpulseConstraintSolver::restitutionCurve */
+static real restitution_curve(real rel_vel, real restitution, real thr) {
+    if (fabs((double)rel_vel) < thr) return 0;
+    return restitution * -rel_vel;
+}
+
+/* btMultiBodyConstraintSolver::resolveSingleConstraintRowGeneric */
+static real resolve_row(Row *c, real *dv) {
+    real di = c->rhs - c->applied * c->cfm;
+    real dvn = 0; for (int k = 0; k < NV; k++) dvn += c->jac[k] * dv[k];
+    di -= dvn * c->jac_diag_inv;
+    real sum = c->applied + di;
+    if (sum < c->lo) { di = c->lo - c->applied; c->applied = c->lo; }
+    else if (sum > c->hi) { di = c->hi - c->applied; c->applied = c->hi; }
+    else c->applied = sum;
+    for (int k = 0; k < NV; k++) dv[k] += c->delta[k] * di;
+    return di / c->jac_diag_inv;
+}
+
+/* btMultiBodyConstraintSolver::resolveConeFrictionConstraintRows */
+static real resolve_cone(Row *cA, Row *cB, real *dv) {
+    real dB = cB->rhs - cB->applied * cB->cfm, dA = cA->rhs - cA->applied * cA->cfm;
+    real nB = 0, nA = 0;
+    for (int k = 0; k < NV; k++) { nB += cB->jac[k] * dv[k]; nA += cA->jac[k] * dv[k]; }
+    dB -= nB * cB->jac_diag_inv; dA -= nA * cA->jac_diag_inv;
+    real sumB = cB->applied + dB, sumA = cA->applied + dA;
+    if (sumA * sumA + sumB * sumB >= cA->lo * cB->lo) {
+        real angle = (real)atan2((double)sumA, (double)sumB);
+        real ca = (real)fabs((double)(cA->lo * (real)sin((double)angle)));
+        real cb = (real)fabs((double)(cB->lo * (real)cos((double)angle)));
+        if (sumA < -ca) { dA = -ca - cA->applied; cA->applied = -ca; }
+        else if (sumA > ca) { dA = ca - cA->applied; cA->applied = ca; }
+        else cA->applied = sumA;
+        if (sumB < -cb) { dB = -cb - cB->applied; cB->applied = -cb; }
+        else if (sumB > cb) { dB = cb - cB->applied; cB->applied = cb; }
+        else cB->applied = sumB;
+    } else { cA->applied = sumA; cB->applied = sumB; }
+    for (int k = 0; k < NV; k++) dv[k] += cA->delta[k] * dA + cB->delta[k] * dB;
+    return dA / cA->jac_diag_inv + dB / cB->jac_diag_inv;
+}
+
+/* ---------------------------------------------------------------- collision: feet vs ground */
+static void collide(Oracle *o) {
+    o->ncp = 0; o->right_contact = 0; o->left_contact = 0;
+    for (int f = 0; f < 2; f++) {
+        int link = f == 0 ? RAW_RFOOT_LINK : RAW_LFOOT_LINK, b = link + 1;
+        real thr = (real)(f == 0 ? RAW_RFOOT_BREAK : RAW_LFOOT_BREAK);
+        for (int k = 0; k < 4; k++) {
+            const double *pl = f == 0 ? RAW_RFOOT_POINTS[k] : RAW_LFOOT_POINTS[k];
+            real l[3] = {(real)pl[0], (real)pl[1], (real)pl[2]}, wpt[3];
+            m3mulv(wpt, o->Rw[b], l); v3add(wpt, wpt, o->Ow[b]);
+            real dist = wpt[2] - (real)RAW_MARGIN;
+            if (dist <= thr) {
+                int c = o->ncp++;
+                o->cp_foot[c] = f; o->cp_dist[c] = dist;
+                v3set(o->cp_pos[c], wpt[0], wpt[1], dist);   /* position on the robot (sphere-swept vertex) */
+                if (f == 0) o->right_contact = 1; else o->left_contact = 1;
+            }
+        }
+    }
+}
+
+/* ---------------------------------------------------------------- one 1/240 s substep */
+static void substep(Oracle *o) {
+    const World *w = &o->w;
+    const real dt = w->dt;
+    fk(o);
+    collide(o);                                   /* performDiscreteCollisionDetection */
+    /* stepVelocities: v += dt * ABA(q, v) */
+    real qdd[NV], v[NV];
+    aba(o, qdd);
+    gen_vel(o, v);
+    for (int k = 0; k < NV; k++) {
+        v[k] += qdd[k] * dt;
+        if (v[k] > w->max_coordinate_velocity) v[k] = w->max_coordinate_velocity;
+        if (v[k] < -w->max_coordinate_velocity) v[k] = -w->max_coordinate_velocity;
+    }
+    v3cpy(o->base_omega, v); v3cpy(o->base_vel, v + 3);
+    for (int d = 0; d < ND; d++) o->qd[d] = v[6 + d];
+
+    /* ---- row setup ---- */
+    static const real Z3[3] = {0, 0, 0};
+    Row nc[36], nrm[MAXCP], spin[MAXCP], roll[2 * MAXCP], fric[2 * MAXCP];
+    int n_nc = 0, n_n = 0, n_spin = 0, n_roll = 0, n_fric = 0;
+    for (int s = 0; s < 36; s++) {
+        int d = RAW_NC_DOF[s], link = RAW_MOVING[d];
+        if (RAW_NC_KIND[s] == 1) {
+            /* btMultiBodyJointMotor::createConstraintRows (POSITION_CONTROL, kp 0.1, kd 1, target vel 0) */
+            Row *r = &nc[n_nc++];
+            memset(r->jac, 0, sizeof r->jac); r->jac[6 + d] = 1;
+            real rel = row_finish(o, r, 0);
+            real pos_stab = (o->target[d] - o->q[d]) / dt;               /* motor erp = 1 */
+            real desired = w->motor_kp * pos_stab + o->qd[d] + w->motor_kd * (0 - o->qd[d]);
+            real vel_err = desired - rel;
+            r->rhs = vel_err * r->jac_diag_inv; r->cfm = 0;
+            r->hi = w->motor_max_force * dt; r->lo = -r->hi;
+        } else {
+            /* btMultiBodyJointLimitConstraint: a row only while the limit is violated */
+            real lo = (real)RAW_LOWER[link], hi = (real)RAW_UPPER[link];
+            for (int side = 0; side < 2; side++) {
+                real pen = side == 0 ? o->q[d] - lo : hi - o->q[d];
+                if (pen > 0) continue;
+                Row *r = &nc[n_nc++];
+                memset(r->jac, 0, sizeof r->jac); r->jac[6 + d] = side == 0 ? 1 : -1;
+                real rel = row_finish(o, r, 0);
+                /* split impulse is on and unimplemented for multibodies: beyond the -0.04 threshold
+                 * the positional part goes to m_rhsPenetration, which the multibody solver ignores */
+                real pos_err = pen > (real)-0.04 ? -pen * w->erp / dt : 0;
+                r->rhs = pos_err * r->jac_diag_inv + (0 - rel) * r->jac_diag_inv; r->cfm = 0;
+                r->lo = 0; r->hi = 100;           /* btMultiBodyConstraint m_maxAppliedImpulse default */
+            }
+        }
+    }
+    /* convertMultiBodyContact: per manifold point normal, spinning, 2 rolling, 2 lateral rows */
+    const real nrmW[3] = {0, 0, 1};
+    const real dir1[3] = {0, -1, 0}, dir2[3] = {1, 0, 0};          /* btPlaneSpace1((0,0,1)) */
+    for (int c = 0; c < o->ncp; c++) {
+        int link = o->cp_foot[c] == 0 ? RAW_RFOOT_LINK : RAW_LFOOT_LINK;
+        const real *P = o->cp_pos[c];
+        Row *r = &nrm[n_n];
+        fill_jacobian(o, link, P, Z3, nrmW, r->jac);
+        real cfm = w->global_cfm / dt;
+        real rel = row_finish(o, r, cfm);
+        real distance = o->cp_dist[c] + w->linear_slop;
+        real rest = restitution_curve(rel, w->restitution, w->restitution_velocity_threshold);
+        if (rest <= 0) rest = 0;
+        real pos_err = 0, vel_err = rest - rel;
+        if (distance > 0) vel_err -= distance / dt; else pos_err = -distance * w->erp2 / dt;
+        r->rhs = pos_err * r->jac_diag_inv + vel_err * r->jac_diag_inv;
+        r->cfm = cfm * r->jac_diag_inv; r->lo = 0; r->hi = (real)1e10; r->friction = w->lateral_friction;
+        r->friction_index = n_n;
+        if (w->spinning_friction > 0) {
+            Row *t = &spin[n_spin++];
+            fill_jacobian(o, link, P, nrmW, Z3, t->jac);
+            real rv = row_finish(o, t, 0);
+            t->rhs = (0 - rv) * t->jac_diag_inv; t->cfm = 0; t->friction = w->spinning_friction; t->friction_index = n_n;
+            t->lo = -t->friction; t->hi = t->friction;
+        }
+        if (w->rolling_friction > 0) {
+            for (int a = 0; a < 2; a++) {
+                Row *t = &roll[n_roll++];
+                fill_jacobian(o, link, P, a == 0 ? dir1 : dir2, Z3, t->jac);
+                real rv = row_finish(o, t, 0);
+                t->rhs = (0 - rv) * t->jac_diag_inv; t->cfm = 0; t->friction = w->rolling_friction; t->friction_index = n_n;
+                t->lo = -t->friction; t->hi = t->friction;
+            }
+        }
+        for (int a = 0; a < 2; a++) {
+            Row *t = &fric[n_fric++];
+            fill_jacobian(o, link, P, Z3, a == 0 ? dir1 : dir2, t->jac);
+            real rv = row_finish(o, t, 0);         /* frictionCFM = 0; friction positional error = 0 */
+            t->rhs = (0 - rv) * t->jac_diag_inv; t->cfm = 0; t->friction = w->lateral_friction; t->friction_index = n_n;
+            t->lo = -t->friction; t->hi = t->friction;
+        }
+        n_n++;
+    }
+
+    /* ---- solveGroupCacheFriendlyIterations ---- */
+    real dv[NV]; memset(dv, 0, sizeof dv);
+    int it; real residual = 0;
+    for (it = 0; it < w->num_iterations; it++) {
+        residual = 0;
+        for (int j = 0; j < n_nc; j++) {
+            int idx = (it & 1) ? j : n_nc - 1 - j;
+            real r = resolve_row(&nc[idx], dv); if (r * r > residual) residual = r * r;
+        }
+        for (int j = 0; j < n_n; j++) { real r = resolve_row(&nrm[j], dv); if (r * r > residual) residual = r * r; }
+        for (int j = 0; j < n_spin; j++) {
+            real tot = nrm[spin[j].friction_index].applied;
+            if (tot > 0) { spin[j].lo = -spin[j].friction * tot; spin[j].hi = spin[j].friction * tot;
+                real r = resolve_row(&spin[j], dv); if (r * r > residual) residual = r * r; }
+        }
+        for (int j = 0; j < n_roll; j++) {
+            real tot = nrm[roll[j].friction_index].applied;
+            if (tot > 0) { roll[j].lo = -roll[j].friction * tot; roll[j].hi = roll[j].friction * tot;
+                real r = resolve_row(&roll[j], dv); if (r * r > residual) residual = r * r; }
+        }
+        for (int j = 0; j + 1 < n_fric; j += 2) {
+            real tot = nrm[fric[j].friction_index].applied;
+            fric[j].lo = -fric[j].friction * tot; fric[j].hi = fric[j].friction * tot;
+            fric[j + 1].lo = fric[j].lo; fric[j + 1].hi = fric[j].hi;
+            real r = resolve_cone(&fric[j], &fric[j + 1], dv); if (r * r > residual) residual = r * r;
+        }
+        if (residual <= w->residual_threshold || it >= w->num_iterations - 1) { it++; break; }
+    }
+    o->last_iterations = it; o->last_residual = residual;
+    /* processDeltaVeeMultiDof2 */
+    for (int k = 0; k < NV; k++) {
+        v[k] += dv[k];
+        if (v[k] > w->max_coordinate_velocity) v[k] = w->max_coordinate_velocity;
+        if (v[k] < -w->max_coordinate_velocity) v[k] = -w->max_coordinate_velocity;
+    }
+    v3cpy(o->base_omega, v); v3cpy(o->base_vel, v + 3);
+    for (int d = 0; d < ND; d++) o->qd[d] = v[6 + d];
+
+    /* ---- btMultiBody::stepPositionsMultiDof ---- */
+    v3axpy(o->base_pos, dt, o->base_vel);
+    {
+        const real *angvel = o->base_omega;
+        real fAngle = v3norm(angvel), axis[3];
+        const real ANGULAR_MOTION_THRESHOLD = (real)(0.5 * 1.5707963267948966);
+        if (fAngle * dt > ANGULAR_MOTION_THRESHOLD) fAngle = (real)0.5 * (real)1.5707963267948966 / dt;
+        real k;
+        if (fAngle < (real)0.001) k = (real)0.5 * dt - (dt * dt * dt) * (real)0.020833333333 * fAngle * fAngle;
+        else k = (real)sin((double)((real)0.5 * fAngle * dt)) / fAngle;
+        v3set(axis, angvel[0] * k, angvel[1] * k, angvel[2] * k);
+        real dq[4] = {axis[0], axis[1], axis[2], (real)cos((double)(fAngle * dt * (real)0.5))};
+        const real *q0 = o->base_quat; real r[4];
+        /* r = dq * q0 */
+        r[3] = dq[3] * q0[3] - dq[0] * q0[0] - dq[1] * q0[1] - dq[2] * q0[2];
+        r[0] = dq[3] * q0[0] + dq[0] * q0[3] + dq[1] * q0[2] - dq[2] * q0[1];
+        r[1] = dq[3] * q0[1] + dq[1] * q0[3] + dq[2] * q0[0] - dq[0] * q0[2];
+        r[2] = dq[3] * q0[2] + dq[2] * q0[3] + dq[0] * q0[1] - dq[1] * q0[0];
+        real n = (real)sqrt((double)(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]));
+        for (int i = 0; i < 4; i++) o->base_quat[i] = r[i] / n;
+    }
+    for (int d = 0; d < ND; d++) o->q[d] += dt * o->qd[d];
+}
+
+/* ---------------------------------------------------------------- env level (plen_env.py) */
+/* plen_env.py:694-714 */
+static double agent_to_env(const real *range, double agent_val) {
+    double lo = range[0], hi = range[1];
+    double m = (hi - lo) / (1.0 - (-1.0));
+    double b = hi - (m * 1.0);
+    double v = m * agent_val + b;
+    if (v >= hi) v = hi - 0.001; else if (v <= lo) v = lo + 0.001;
+    return v;
+}
+
+/* plen_env.py:768-871 */
+static void compute_observation(Oracle *o, real *obs) {
+    real rpy[3]; quat_to_euler(rpy, o->base_quat);
+    o->torso_z = o->base_pos[2]; o->torso_y = o->base_pos[1]; o->torso_vx = o->base_vel[0];
+    o->roll = rpy[0]; o->pitch = rpy[1]; o->yaw = rpy[2];
+    for (int d = 0; d < ND; d++) obs[d] = o->q[d];
+    obs[18] = o->torso_z; obs[19] = o->torso_vx; obs[20] = o->roll; obs[21] = o->pitch; obs[22] = o->yaw;
+    obs[23] = o->torso_y; obs[24] = (real)o->right_contact; obs[25] = (real)o->left_contact;
+    static const int J[6] = {2, 8, 3, 9, 4, 10};
+    if (o->nhist > 0) { for (int k = 0; k < 6; k++) o->diffs[k] = o->hist[k][o->nhist - 1] - o->q[J[k]]; o->first_pass = 0; }
+    else { o->first_pass = 1; for (int k = 0; k < 6; k++) o->diffs[k] = 0; }
+    if (o->nhist < HIST) { for (int k = 0; k < 6; k++) o->hist[k][o->nhist] = o->q[J[k]]; o->nhist++; }
+}
+
+/* plen_env.py:1072-1093 */
+static int compute_done(Oracle *o) {
+    const double PI3 = 3.14159265358979323846 / 3.0;
+    int done = (o->roll > PI3) || (o->pitch > PI3) || (o->torso_z < (real)0.08) || (o->torso_y > 1);
+    o->dead = done;
+    return done;
+}
+
+static void clear_gait(Oracle *o) {
+    o->nhist = 0; o->gait_period_counter = 0; o->double_support_counter = 0;
+}
+
+/* world orientation of a foot link as roll/pitch (plen_env.py:1016-1018, :1029-1031) */
+static void foot_rp(const Oracle *o, int link, real *r, real *p) {
+    real q[4], rpy[3]; mat_to_quat(q, o->Rw[link + 1]); quat_to_euler(rpy, q); *r = rpy[0]; *p = rpy[1];
+}
+
+/* plen_env.py:873-1070.  foot_roll/pitch are passed in so the function can be pinned against the
+ * reference with arbitrary inputs. */
+static double reward_core(Oracle *o, double lr, double lp, double rr, double rp) {
+    double reward = 0;
+    double vx = o->torso_vx;
+    reward += 0.0;                                          /* alive_reward == 0 */
+    if (vx < 0) reward -= exp(vx * 3.0); else reward += (vx * 3.0) * (vx * 3.0);
+    { double h = fabs(0.160178937611 - (double)o->torso_z) * 40.0; reward -= h * h; }
+    reward -= fabs((double)o->torso_y) * fabs((double)o->torso_y) * 1;
+    reward -= fabs((double)o->roll) * fabs((double)o->roll) * 1.0;
+    reward -= fabs((double)o->pitch) * fabs((double)o->pitch) * 0.5;
+    reward -= fabs((double)o->yaw) * fabs((double)o->yaw) * 1.0;
+    double jar = 0, jap = 0;
+    const int gps = 80;
+    if (o->gait_period_counter >= gps && o->right_contact == 1) {
+        clear_gait(o);
+    } else if (o->gait_period_counter >= 1.5 * gps) {
+        reward -= 2;
+    } else if (o->gait_period_counter > 0) {
+        for (int pr = 0; pr < 3; pr++) {
+            double dot = 0, nl = 0, nr = 0;
+            for (int i = 0; i < o->nhist; i++) {
+                double l = o->hist[2 * pr][i], r = o->hist[2 * pr + 1][i];
+                dot += l * r; nl += l * l; nr += r * r;
+            }
+            jar += dot / (sqrt(nl) * sqrt(nr));
+        }
+        jar *= 1.0 / 3.0;
+        if (!o->first_pass) {
+            for (int k = 0; k < 6; k++) jap -= 1.0 / exp(fabs((double)o->diffs[k]));
+            jap *= 0.5 * (1.0 / 3.0);
+        }
+    }
+    reward += jar; reward += jap;
+    if (o->left_contact == 1) {
+        double x = (o->gait_period_counter * 10 / (double)gps) - 0.5 * 10;
+        reward += 0.5 * (1 - tanh(x * x));
+    }
+    const double gpr = 0.1;
+    if (o->gait_period_counter < gps / 2.0) {
+        if (o->right_contact == 1 && o->left_contact == 0) reward += gpr;
+        else if (o->right_contact == 0) reward -= gpr;
+    } else if (o->gait_period_counter < gps) {
+        if (o->left_contact == 1 && o->right_contact == 0) reward += gpr;
+        else if (o->left_contact == 0) reward -= gpr;
+    }
+    if (o->right_contact == 1 && o->left_contact == 1) {
+        o->double_support_counter += 1;
+        if (o->double_support_counter >= 16) reward -= 2;
+    }
+    if (o->left_contact == 1 && fabs(lr) <= 0.1 && fabs(lp) <= 0.1) reward += 0.1;
+    if (o->right_contact == 1 && fabs(rr) <= 0.1 && fabs(rp) <= 0.1) reward += 0.1;
+    if (o->dead) { reward -= 100.0; o->dead = 0; }
+    return reward;
+}
+
+/* ---------------------------------------------------------------- exported C API */
+#define API __attribute__((visibility("default")))
+
+API int oracle_real_size(void) { return (int)sizeof(real); }
+
+API Oracle *oracle_create(int joint_act) {
+    Oracle *o = (Oracle *)calloc(1, sizeof(Oracle));
+    o->joint_act = joint_act;
+    world_defaults(&o->w, joint_act);
+    o->mass[0] = (real)RAW_BASE_MASS;
+    for (int k = 0; k < 3; k++) o->inertia[0][k] = (real)RAW_BASE_INERTIA[k];
+    for (int i = 0; i < NL; i++) { o->mass[i + 1] = (real)RAW_MASS[i]; for (int k = 0; k < 3; k++) o->inertia[i + 1][k] = (real)RAW_INERTIA[i][k]; }
+    o->base_quat[3] = 1; o->base_pos[2] = (real)0.158;
+    o->first_pass = 1;
+    return o;
+}
+API void oracle_destroy(Oracle *o) { free(o); }
+
+/* domain randomisation hooks: scale every link mass (and inertia with it), override lateral friction */
+API void oracle_set_params(Oracle *o, double mass_scale, double lateral_friction) {
+    o->mass[0] = (real)(RAW_BASE_MASS * mass_scale);
+    for (int k = 0; k < 3; k++) o->inertia[0][k] = (real)(RAW_BASE_INERTIA[k] * mass_scale);
+    for (int i = 0; i < NL; i++) { o->mass[i + 1] = (real)(RAW_MASS[i] * mass_scale); for (int k = 0; k < 3; k++) o->inertia[i + 1][k] = (real)(RAW_INERTIA[i][k] * mass_scale); }
+    if (lateral_friction >= 0) o->w.lateral_friction = (real)lateral_friction;
+}
+API void oracle_set_world(Oracle *o, int num_iterations, double residual_threshold) {
+    if (num_iterations > 0) o->w.num_iterations = num_iterations;
+    if (residual_threshold >= 0) o->w.residual_threshold = (real)residual_threshold;
+}
+
+/* state = pos3 quat4 omega3 vel3 q18 qd18 (49 doubles) */
+API void oracle_get_state(const Oracle *o, double *s) {
+    int k = 0;
+    for (int i = 0; i < 3; i++) s[k++] = o->base_pos[i];
+    for (int i = 0; i < 4; i++) s[k++] = o->base_quat[i];
+    for (int i = 0; i < 3; i++) s[k++] = o->base_omega[i];
+    for (int i = 0; i < 3; i++) s[k++] = o->base_vel[i];
+    for (int i = 0; i < ND; i++) s[k++] = o->q[i];
+    for (int i = 0; i < ND; i++) s[k++] = o->qd[i];
+}
+API void oracle_set_state(Oracle *o, const double *s) {
+    int k = 0;
+    for (int i = 0; i < 3; i++) o->base_pos[i] = (real)s[k++];
+    for (int i = 0; i < 4; i++) o->base_quat[i] = (real)s[k++];
+    for (int i = 0; i < 3; i++) o->base_omega[i] = (real)s[k++];
+    for (int i = 0; i < 3; i++) o->base_vel[i] = (real)s[k++];
+    for (int i = 0; i < ND; i++) o->q[i] = (real)s[k++];
+    for (int i = 0; i < ND; i++) o->qd[i] = (real)s[k++];
+}
+/* aux = gait counter, double-support counter, episode step, dead, first_pass, nhist */
+API void oracle_get_aux(const Oracle *o, int *a) {
+    a[0] = o->gait_period_counter; a[1] = o->double_support_counter; a[2] = o->episode_timestep;
+    a[3] = o->dead; a[4] = o->first_pass; a[5] = o->nhist;
+}
+API void oracle_set_targets(Oracle *o, const double *t) { for (int d = 0; d < ND; d++) o->target[d] = (real)t[d]; }
+API void oracle_substep(Oracle *o) { substep(o); }
+API void oracle_contacts(const Oracle *o, int *flags) { flags[0] = o->right_contact; flags[1] = o->left_contact; flags[2] = o->ncp; flags[3] = o->last_iterations; }
+
+/* low-level hooks for cross-checks in tests */
+API void oracle_forward_dynamics(Oracle *o, double *qdd) {   /* accelerations at the current state, no constraints */
+    real a[NV]; fk(o); aba(o, a); for (int k = 0; k < NV; k++) qdd[k] = a[k];
+}
+API void oracle_minv_times(Oracle *o, const double *force, double *out) {   /* M^-1 f (after forward_dynamics) */
+    real f[NV], r[NV]; for (int k = 0; k < NV; k++) f[k] = (real)force[k];
+    aba_delta(o, f, r); for (int k = 0; k < NV; k++) out[k] = r[k];
+}
+API void oracle_link_frames(Oracle *o, double *R, double *O, double *C) {  /* [33][9], [33][3], [33][3] */
+    fk(o);
+    for (int b = 0; b <= NL; b++) { for (int k = 0; k < 9; k++) R[9 * b + k] = o->Rw[b][k]; for (int k = 0; k < 3; k++) { O[3 * b + k] = o->Ow[b][k]; C[3 * b + k] = o->Cw[b][k]; } }
+}
+
+API double oracle_agent_to_env(int joint, double a) { return agent_to_env(ENV_RANGES[joint], a); }
+
+/* reward/done pin: drive the env-level state machine with externally supplied observations
+ * (joint angles, base pose, contacts, foot roll/pitch) exactly as tools/make_golden.py drives the
+ * reference through stubbed pybullet calls.  Mirrors step() order: obs -> done -> reward -> counter++ */
+API void oracle_script_reset(Oracle *o) {
+    clear_gait(o); o->episode_timestep = 0;   /* dead and first_pass are NOT reset (plen_env.py:576-590) */
+}
+API double oracle_script_step(Oracle *o, const double *q18, double z, double vx, double roll, double pitch, double yaw, double y,
+                              int rc, int lc, double lroll, double lpitch, double rroll, double rpitch, int *done_out) {
+    /* install the scripted readings where compute_observation would read them from the engine */
+    for (int d = 0; d < ND; d++) o->q[d] = (real)q18[d];
+    o->right_contact = rc; o->left_contact = lc;
+    o->torso_z = (real)z; o->torso_vx = (real)vx; o->roll = (real)roll; o->pitch = (real)pitch; o->yaw = (real)yaw; o->torso_y = (real)y;
+    static const int J[6] = {2, 8, 3, 9, 4, 10};
+    if (o->nhist > 0) { for (int k = 0; k < 6; k++) o->diffs[k] = o->hist[k][o->nhist - 1] - o->q[J[k]]; o->first_pass = 0; }
+    else { o->first_pass = 1; for (int k = 0; k < 6; k++) o->diffs[k] = 0; }
+    if (o->nhist < HIST) { for (int k = 0; k < 6; k++) o->hist[k][o->nhist] = o->q[J[k]]; o->nhist++; }
+    int done = compute_done(o);
+    double r = reward_core(o, lroll, lpitch, rroll, rpitch);
+    o->episode_timestep += 1; o->gait_period_counter += 1;
+    *done_out = done;
+    return r;
+}
+
+/* plen_env.py:558-614 */
+API void oracle_reset(Oracle *o, double *obs_out) {
+    v3set(o->base_pos, 0, 0, (real)0.158);
+    o->base_quat[0] = o->base_quat[1] = o->base_quat[2] = 0; o->base_quat[3] = 1;
+    v3set(o->base_omega, 0, 0, 0); v3set(o->base_vel, 0, 0, 0);
+    for (int d = 0; d < ND; d++) { o->q[d] = 0; o->qd[d] = 0; o->target[d] = 0; }
+    for (int i = 0; i < 8; i++) substep(o);                 /* 2 * sim_stepsize */
+    real obs[26]; fk(o); compute_observation(o, obs);
+    o->episode_timestep = 0;
+    clear_gait(o);
+    if (obs_out) for (int k = 0; k < 26; k++) obs_out[k] = obs[k];
+}
+
+/* plen_env.py:638-692.  action is float32-valued (Box dtype) carried in doubles.  Returns reward. */
+API double oracle_step(Oracle *o, const double *action, double *obs_out, int *done_out) {
+    for (int d = 0; d < ND; d++)
+        o->target[d] = (real)(o->joint_act ? action[d] : agent_to_env(ENV_RANGES[d], action[d]));
+    for (int i = 0; i < 4; i++) substep(o);
+    real obs[26]; fk(o); compute_observation(o, obs);
+    int done = compute_done(o);
+    real lr, lp, rr, rp;
+    foot_rp(o, RAW_LFOOT_LINK, &lr, &lp); foot_rp(o, RAW_RFOOT_LINK, &rr, &rp);
+    double reward = reward_core(o, lr, lp, rr, rp);
+    o->episode_timestep += 1; o->gait_period_counter += 1;
+    for (int k = 0; k < 26; k++) obs_out[k] = obs[k];
+    *done_out = done;
+    return reward;
+}
+
+/* gym TimeLimit(500) + the driver's auto-reset (plen_td3.py:108-133), for the CPU baseline and the
+ * rollout parity tests: runs `nsteps` control steps of one env, resetting on done/time-limit.
+ * actions [nsteps][18]; outputs obs [nsteps][26] (post-step, pre-reset), rew, done flags
+ * (bit0 = terminal, bit1 = time-limit). Returns the number of env steps executed. */
+API int oracle_rollout(Oracle *o, int nsteps, const float *actions, double *obs, double *rew, uint8_t *flags) {
+    double a[ND], ob[26];
+    for (int t = 0; t < nsteps; t++) {
+        for (int d = 0; d < ND; d++) a[d] = actions[t * ND + d];
+        int done; double r = oracle_step(o, a, ob, &done);
+        int trunc = o->episode_timestep >= 500;
+        if (obs) memcpy(obs + 26 * t, ob, sizeof ob);
+        if (rew) rew[t] = r;
+        if (flags) flags[t] = (uint8_t)((done ? 1 : 0) | (trunc ? 2 : 0));
+        if (done || trunc) oracle_reset(o, NULL);
+    }
+    return nsteps;
+}
+
+API double oracle_last_residual(const Oracle *o) { return (double)o->last_residual; }
+
+/* single-state pin of compute_done + compute_reward (tests/golden/a78_reward_done.npz): install the
+ * env attributes the reference's test harness set by hand, then run done -> reward. */
+API void oracle_script_inject(Oracle *o, int cnt, int ds, int nh, const double *hist, const double *diffs, int first_pass) {
+    o->gait_period_counter = cnt; o->double_support_counter = ds; o->nhist = nh; o->first_pass = first_pass;
+    for (int k = 0; k < 6; k++) { o->diffs[k] = (real)diffs[k]; for (int i = 0; i < nh; i++) o->hist[k][i] = (real)hist[k * nh + i]; }
+}
+API double oracle_script_reward(Oracle *o, double z, double vx, double roll, double pitch, double yaw, double y, int rc, int lc,
+                                double lroll, double lpitch, double rroll, double rpitch, int *done_out) {
+    o->right_contact = rc; o->left_contact = lc;
+    o->torso_z = (real)z; o->torso_vx = (real)vx; o->roll = (real)roll; o->pitch = (real)pitch; o->yaw = (real)yaw; o->torso_y = (real)y;
+    *done_out = compute_done(o);
+    return reward_core(o, lroll, lpitch, rroll, rpitch);
+}
