@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the vectorised PLEN walking environment on MI355X.
+
+Workload = BASELINE.json configs[1]: 4096 vectorised PLEN envs per GPU, random-action rollout
+(actions U[-1,1] from torch.Generator(device).manual_seed(rank), pre-generated and resident in HBM
+before the timed region).  One "step" = one vector step of all 4096 envs of a rank = 4096 env-steps
+(action map, 4 x 1/240 s physics substeps, observation, termination, reward, auto-reset) in ONE
+kernel launch.  Envs shard one-GPU-per-rank with no data-path collective (weak scaling).
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; N>1 is launched by the driver through
+torch.distributed.run (one rank per GPU, RCCL); rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ENVS_PER_GPU = 4096
+ALGO_BYTES_PER_ENV_STEP = 776          # fp32 state+aux+action in, state+aux+obs+reward+done out
+HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def _cpu_worker(args):
+    """One host core: the C oracle stepping one env through `steps` random-action steps (auto-reset)."""
+    seed, steps = args
+    import numpy as np
+    from oracle.oracle import OracleEnv
+    rng = np.random.default_rng(seed)
+    acts = rng.uniform(-1, 1, (steps, 18)).astype(np.float32)
+    env = OracleEnv()
+    env.reset()
+    t0 = time.time()
+    env.rollout(acts)
+    return time.time() - t0
+
+
+def cpu_baseline(budget_s=12.0):
+    """Oracle ("port" of the reference algorithm, f64, gcc -O2) on every host core, bounded sample."""
+    import multiprocessing as mp
+    from oracle import oracle
+    oracle.build()
+    cores = os.cpu_count() or 1
+    probe = _cpu_worker((0, 300))
+    steps = max(500, int(300 / probe * budget_s))
+    ctx = mp.get_context("spawn")
+    t0 = time.time()
+    with ctx.Pool(cores) as pool:
+        pool.map(_cpu_worker, [(100 + i, steps) for i in range(cores)])
+    wall = time.time() - t0
+    return {"value": cores * steps / wall, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d independent envs x %d random-action steps each on the C oracle (f64, gcc -O2), one env per core; "
+                      "single core: %.0f env-steps/s" % (cores, steps, 300 / probe)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from plen_ml_walk_amd.vec_env import PlenVecEnv
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = a.envs_per_gpu
+    dtype = torch.float32 if a.dtype == "f32" else torch.float64
+    env = PlenVecEnv(n, device=dev, dtype=dtype)
+    env.reset()
+    g = torch.Generator(device=dev).manual_seed(rank)
+    # a ring of pre-generated action batches resident in HBM (64 x 4096 x 18 f32 = 19 MB)
+    ring = 64
+    actions = torch.rand(ring, n, 18, generator=g, device=dev, dtype=torch.float32) * 2 - 1
+    done_count = torch.zeros((), dtype=torch.int64, device=dev)
+
+    for t in range(a.warmup):
+        env.step(actions[t % ring])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    env.timing_begin()
+    t0 = time.perf_counter()
+    for t in range(a.steps):
+        _, _, done, _ = env.step(actions[(a.warmup + t) % ring])
+    kernel_ms, launches = env.timing_end()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    done_count += done.sum()
+    if world > 1:
+        tmax = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(tmax[0]), float(tmax[1])
+
+    if rank == 0:
+        total_env_steps = world * n * a.steps
+        value = total_env_steps / elapsed
+        launch_s = kernel_ms * 1e-3 / max(launches, 1)
+        achieved = n * ALGO_BYTES_PER_ENV_STEP / launch_s / 1e9
+        out = {
+            "metric": "env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: %d vectorised PLEN envs per MI355X, random-action rollout, auto-reset "
+                                   "(done or 500-step limit), 4 x 240 Hz substeps per 60 Hz step" % n,
+                       "envs_per_gpu": n, "total_envs": world * n, "substeps": 4, "solver_iterations": 50,
+                       "parallelism": "env-sharded, %d rank(s), no data-path collective" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "note": "algorithmic %d B/env-step x %d env-steps per launch / %.3f ms per launch (HIP events on the launch "
+                                 "stream). The step is FP32-VALU/latency bound (about 2.5 MFLOP per env-step), see DESIGN.md" %
+                                 (ALGO_BYTES_PER_ENV_STEP, n, launch_s * 1e3)},
+            "kernel_ms_per_launch": launch_s * 1e3,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as ex:     # the GPU number stands on its own
+                out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
+        print(json.dumps(out))
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,134 @@
+/*
+ * plenvec.h -- C ABI of libplenvec.so, the MI355X-native vectorised PLEN walking environment.
+ *
+ * The reference has no C/FFI interface of its own: its hot path is the Python class
+ * PlenWalkEnv (plen_bullet/src/plen_bullet/plen_env.py) calling the third-party `pybullet`
+ * C extension.  Each entry point below therefore cites the reference *Python call site(s)* whose
+ * work it replaces; the Python facades in plen_ml_walk_amd/ (same names/kwargs as the reference)
+ * bind these symbols with ctypes (INTEGRATION.md shows the binding a maintainer would add).
+ *
+ * Conventions
+ *   - all functions return 0 on success, a negative PLENVEC_E_* code on failure;
+ *     plenvec_last_error() returns a human-readable message for the calling thread;
+ *   - every array argument is a caller-owned DEVICE pointer unless its name ends in _host;
+ *   - work is enqueued on the hipStream_t passed in (void* here so the header needs no HIP);
+ *     nothing synchronises with the host except create/destroy and the *_host helpers;
+ *   - a handle is not thread-safe: one stream per handle at a time;
+ *   - real-valued device arrays are float or double according to PlenCfg.dtype.
+ */
+#ifndef PLENVEC_H
+#define PLENVEC_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLENVEC_OK 0
+#define PLENVEC_E_INVAL -1     /* bad argument */
+#define PLENVEC_E_HIP -2       /* HIP runtime error (message has the HIP error string) */
+#define PLENVEC_E_NODEV -3     /* no usable GPU: the library never falls back to the CPU */
+
+#define PLENVEC_OBS 26         /* plen_env.py:807-822 */
+#define PLENVEC_ACT 18         /* plen_env.py:142-144 */
+#define PLENVEC_STATE 49       /* pos3 quat4(x,y,z,w) omega3 vel3 q18 qd18 */
+#define PLENVEC_DTYPE_F32 0
+#define PLENVEC_DTYPE_F64 1
+
+/* done flags written by plenvec_step */
+#define PLENVEC_DONE_TERMINAL 1   /* compute_done() fired (plen_env.py:1072-1093) */
+#define PLENVEC_DONE_TIMELIMIT 2  /* gym TimeLimit: episode step reached max_episode_steps (plen_env.py:15-19) */
+
+typedef struct plenvec plenvec_t;
+
+/* World / env configuration.  Zero-initialise, call plenvec_default_cfg(), then override.
+ * Defaults reproduce plen_env.py:34-556 with PyBullet's own defaults for what the reference leaves
+ * unset (DESIGN.md lists each with its source). */
+typedef struct PlenCfg {
+    int32_t dtype;               /* PLENVEC_DTYPE_F32 (default) or _F64 */
+    int32_t joint_act;           /* PlenWalkEnv(joint_act=...) plen_env.py:34,439-442,472-475,652-654 */
+    int32_t max_episode_steps;   /* 500, register() plen_env.py:15-19 */
+    int32_t substeps;            /* 4 = sim_stepsize, plen_env.py:40-42 */
+    int32_t reset_substeps;      /* 8 = 2*sim_stepsize, plen_env.py:569-570 */
+    int32_t num_iterations;      /* 50 */
+    int32_t auto_reset;          /* 1: an env whose episode ended restarts inside the same step call */
+    int32_t reserved0;
+    double dt;                   /* 1/240 */
+    double gravity_z;            /* -9.81, plen_env.py:296 */
+    double erp, erp2;            /* 0.2, 0.08 */
+    double linear_slop;          /* 1e-5 */
+    double residual_threshold;   /* 1e-7 */
+    double restitution_velocity_threshold; /* 0.2 */
+    double max_coordinate_velocity;        /* 100 */
+    double lateral_friction;     /* 0.8*0.8, plen_env.py:309,444 */
+    double spinning_friction;    /* 0.1*0.8, plen_env.py:445 */
+    double rolling_friction;     /* 0.1*0.8 (0.01*0.8 if joint_act), plen_env.py:439-442 */
+    double restitution;          /* 0.5*0.5, plen_env.py:309,481 */
+    double linear_damping;       /* 0 (0.1 if joint_act), plen_env.py:472-480 */
+    double motor_kp, motor_kd;   /* 0.1, 1.0 (PyBullet POSITION_CONTROL defaults) */
+    double motor_max_force;      /* 0.15, plen_env.py:753 */
+    double spawn_z;              /* 0.158, plen_env.py:312 */
+} PlenCfg;
+
+/* Fills *cfg with the reference configuration for the given joint_act mode. */
+int plenvec_default_cfg(PlenCfg *cfg, int joint_act);
+
+/* Replaces: PlenWalkEnv.__init__ (plen_env.py:34-556: connect, loadURDF, changeDynamics...) for
+ * `num_envs` independent environments on HIP device `device`.  The PLEN model tables are compiled
+ * in (generated from the reference's plen.urdf + foot STLs by tools/extract_model.py).
+ * All envs start in the post-reset state (see plenvec_reset).  Host-synchronous. */
+int plenvec_create(const PlenCfg *cfg, int num_envs, int device, plenvec_t **out);
+int plenvec_destroy(plenvec_t *h);
+int plenvec_num_envs(const plenvec_t *h);
+int plenvec_dtype(const plenvec_t *h);
+
+/* Replaces: PlenWalkEnv.reset (plen_env.py:558-614): base pose/joints zeroed, zero motor targets,
+ * 8 settle substeps, observation, gait/episode counters cleared.
+ * mask: uint8[num_envs] device pointer, nonzero = reset that env; NULL = all envs.
+ * obs: real[num_envs][26] device pointer or NULL; rows of envs that were not reset are left untouched. */
+int plenvec_reset(plenvec_t *h, const uint8_t *mask, void *obs, void *stream);
+
+/* Replaces: PlenWalkEnv.step (plen_env.py:638-692) = agent_to_env (:694-714) + move_joints
+ * (:716-753) + 4 x p.stepSimulation() (:665-667) + compute_observation (:768-871) + compute_done
+ * (:1072-1093) + compute_reward (:873-1070) + counters (:674-678), plus gym's TimeLimit wrapper and
+ * the driver's reset-on-done (plen_td3.py:108-133) when cfg.auto_reset is set.
+ *   action   float[num_envs][18]   agent actions in [-1,1] (always float32, the Box dtype)
+ *   next_obs real[num_envs][26]    observation after the step (terminal observation if the episode ended)
+ *   reward   real[num_envs]
+ *   done     uint8[num_envs]       PLENVEC_DONE_* bits
+ *   cur_obs  real[num_envs][26]    observation to act on next: == next_obs unless the env was
+ *                                  auto-reset, then the reset observation.  May be NULL. */
+int plenvec_step(plenvec_t *h, const float *action, void *next_obs, void *reward, uint8_t *done, void *cur_obs, void *stream);
+
+/* State injection / extraction for parity tests (no reference equivalent; PyBullet's
+ * resetBasePositionAndOrientation/resetJointState/getJointStates family).
+ * state: real[num_envs][49].  set_state also clears the gait bookkeeping like reset() does. */
+int plenvec_get_state(plenvec_t *h, void *state, void *stream);
+int plenvec_set_state(plenvec_t *h, const void *state, void *stream);
+/* aux: int32[num_envs][8] = gait counter, double-support counter, episode step, history length,
+ * right contact, left contact, solver iterations of the last substep, reserved */
+int plenvec_get_aux(plenvec_t *h, int32_t *aux, void *stream);
+
+/* Test hook: run `nsub` raw physics substeps (p.stepSimulation(), plen_env.py:667) with the given
+ * motor targets (real[num_envs][18], radians, i.e. AFTER agent_to_env), no observation/reward
+ * bookkeeping.  dump: optional real[num_envs][PLENVEC_DUMP] of solver intermediates of the LAST substep. */
+#define PLENVEC_DUMP 4096
+int plenvec_debug_substeps(plenvec_t *h, const void *targets, int nsub, void *dump, void *stream);
+
+/* Domain randomisation (BASELINE.json configs[4]; not in the reference): per-env scale of every
+ * link mass (inertia scales with it) and per-env foot/ground lateral friction coefficient.
+ * real[num_envs] each; NULL leaves that parameter unchanged.  Takes effect at the next reset. */
+int plenvec_set_params(plenvec_t *h, const void *mass_scale, const void *lateral_friction, void *stream);
+
+/* Kernel timing hook for bench.py: HIP-event time of the step kernel launches on the stream the
+ * kernel was launched on.  begin() records, end() records + synchronises and returns the elapsed
+ * milliseconds and the number of step kernels launched in between. */
+int plenvec_timing_begin(plenvec_t *h, void *stream);
+int plenvec_timing_end(plenvec_t *h, void *stream, double *elapsed_ms, int64_t *launches);
+
+const char *plenvec_last_error(void);
+const char *plenvec_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,77 @@
+"""ctypes binding of libplenvec.so (include/plenvec.h).  No torch types cross this boundary: only
+raw device pointers, sizes and a stream handle.  The library is built in-tree by
+__graft_entry__.build() / plen_ml_walk_amd.build.build_extension(); importing fails loudly if
+the shared object is missing -- there is no Python or CPU fallback for the env step."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libplenvec.so")
+
+OBS, ACT, STATE, DUMP = 26, 18, 49, 4096
+DTYPE_F32, DTYPE_F64 = 0, 1
+DONE_TERMINAL, DONE_TIMELIMIT = 1, 2
+
+
+class PlenCfg(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("joint_act", C.c_int32), ("max_episode_steps", C.c_int32), ("substeps", C.c_int32),
+                ("reset_substeps", C.c_int32), ("num_iterations", C.c_int32), ("auto_reset", C.c_int32), ("reserved0", C.c_int32),
+                ("dt", C.c_double), ("gravity_z", C.c_double), ("erp", C.c_double), ("erp2", C.c_double),
+                ("linear_slop", C.c_double), ("residual_threshold", C.c_double), ("restitution_velocity_threshold", C.c_double),
+                ("max_coordinate_velocity", C.c_double), ("lateral_friction", C.c_double), ("spinning_friction", C.c_double),
+                ("rolling_friction", C.c_double), ("restitution", C.c_double), ("linear_damping", C.c_double),
+                ("motor_kp", C.c_double), ("motor_kd", C.c_double), ("motor_max_force", C.c_double), ("spawn_z", C.c_double)]
+
+
+EXPORTS = ["plenvec_default_cfg", "plenvec_create", "plenvec_destroy", "plenvec_num_envs", "plenvec_dtype", "plenvec_reset",
+           "plenvec_step", "plenvec_get_state", "plenvec_set_state", "plenvec_get_aux", "plenvec_debug_substeps",
+           "plenvec_set_params", "plenvec_timing_begin", "plenvec_timing_end", "plenvec_last_error", "plenvec_version"]
+
+_lib = None
+
+
+class PlenvecError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the HIP library; raises if it has not been built (never falls back to anything)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PlenvecError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+                           "There is no CPU fallback for the environment step." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i32 = C.c_void_p, C.c_int
+    lib.plenvec_default_cfg.argtypes = [C.POINTER(PlenCfg), i32]
+    lib.plenvec_create.argtypes = [C.POINTER(PlenCfg), i32, i32, C.POINTER(vp)]
+    lib.plenvec_destroy.argtypes = [vp]
+    lib.plenvec_num_envs.argtypes = [vp]
+    lib.plenvec_dtype.argtypes = [vp]
+    lib.plenvec_reset.argtypes = [vp, vp, vp, vp]
+    lib.plenvec_step.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.plenvec_get_state.argtypes = [vp, vp, vp]
+    lib.plenvec_set_state.argtypes = [vp, vp, vp]
+    lib.plenvec_get_aux.argtypes = [vp, vp, vp]
+    lib.plenvec_debug_substeps.argtypes = [vp, vp, i32, vp, vp]
+    lib.plenvec_set_params.argtypes = [vp, vp, vp, vp]
+    lib.plenvec_timing_begin.argtypes = [vp, vp]
+    lib.plenvec_timing_end.argtypes = [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.plenvec_last_error.restype = C.c_char_p
+    lib.plenvec_version.restype = C.c_char_p
+    for name in EXPORTS:
+        getattr(lib, name)          # every symbol include/plenvec.h declares must be exported
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        raise PlenvecError("libplenvec error %d: %s" % (code, load().plenvec_last_error().decode()))
+
+
+def default_cfg(joint_act=False):
+    cfg = PlenCfg()
+    check(load().plenvec_default_cfg(C.byref(cfg), int(bool(joint_act))))
+    return cfg

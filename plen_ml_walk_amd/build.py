@@ -1,0 +1,28 @@
+"""In-tree build of libplenvec.so with hipcc for gfx950 (MI355X).  hipcc cross-compiles without a GPU."""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SRC = os.path.join(CSRC, "plenvec.hip")
+OUT = os.path.join(CSRC, "libplenvec.so")
+DEPS = [SRC, os.path.join(CSRC, "plen_model_gen.h"), os.path.join(os.path.dirname(_HERE), "include", "plenvec.h")]
+
+
+def hipcc_path():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (ROCm 7.x expected under /opt/rocm)")
+
+
+def build_extension(force=False, verbose=False):
+    """Compile plenvec.hip -> csrc/libplenvec.so (gfx950 only).  Returns the output path."""
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
+        return OUT
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", OUT, SRC]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    subprocess.check_call(cmd, cwd=CSRC)
+    return OUT

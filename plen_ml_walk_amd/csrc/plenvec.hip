@@ -1,0 +1,1258 @@
+// plenvec.hip -- MI355X (gfx950) vectorised PLEN walking environment: HIP kernels + C ABI.
+//
+// Replaces the hot path of the reference, PlenWalkEnv.step (plen_bullet/src/plen_bullet/plen_env.py:638-692)
+// including the four p.stepSimulation() calls (:665-667) that run inside the third-party pybullet
+// module, for N independent environments per launch.  See DESIGN.md for the derivation; in short:
+//
+//   * ONE WAVEFRONT (64 lanes) PER ENVIRONMENT, one launch per vector step, state resident in
+//     LDS/VGPRs across the 4 substeps.  At BASELINE.json's 4096 envs/GPU this gives 4096 waves =
+//     4 per SIMD on 256 CUs; "one env per lane" would give 64 waves = 6% of the chip.
+//   * lanes play three roles: body b (19 composite bodies), generalized DoF k (24), solver port p (48);
+//   * dynamics: world-axes composite-rigid-body mass matrix M (24x24) + classical recursive
+//     Newton-Euler bias, Cholesky M = L L^T held one row per lane;
+//   * constraints: Bullet's multibody PGS rows (18 position motors, joint limits, per contact point
+//     normal + spinning + 2 rolling + 2 cone-coupled lateral friction rows), solved in "port space":
+//     rows that share a Jacobian share a port, A = J M^-1 J^T (48x48) is held one row per lane in
+//     VGPRs, a row update is  lane-local delta -> v_readlane -> one FMA per lane.  Row order,
+//     alternating sweep direction, limits, residual early-out follow btMultiBodyConstraintSolver.
+//   * integration: btMultiBody::stepPositionsMultiDof (exponential-map quaternion).
+//
+// No MFMA: there is no dense contraction worth a matrix core here (24..48-wide, latency bound).
+// The library never falls back to the CPU; the oracle under oracle/ is never linked or called.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+#include <string>
+#include <vector>
+#include <utility>
+#include <type_traits>
+#include "../../include/plenvec.h"
+#include "plen_model_gen.h"
+
+#define NB 19
+#define ND 18
+#define NV 24
+#define NPORT 48
+#define REC 64          // reals per env state record
+#define AUXN 8          // int32 per env aux record
+
+// ------------------------------------------------------------------------------------------------
+// state record (real[64]):  0-2 pos | 3-6 quat xyzw | 7-9 omega | 10-12 vel | 13-30 q | 31-48 qd |
+//                           49-54 previous gait joint angles (joints 2,8,3,9,4,10; plen_env.py:825-849) |
+//                           55-63 running sums per L/R pair: dot, |L|^2, |R|^2 (plen_env.py:929-945)
+// aux record (int32[8]):    gait counter | double-support counter | episode step | history length |
+//                           right contact | left contact | solver iterations | reserved
+// ------------------------------------------------------------------------------------------------
+
+// device-side parameter block, converted to the kernel's real type on the host
+template <typename real>
+struct DevParams {
+    real dt, inv_dt, gz, erp, erp2, slop, res_thr, rest_thr, vmax;
+    real mu_lat, mu_spin, mu_roll, restitution, lin_damp, kp, kd, max_imp, spawn_z;
+    real margin, brk[2];
+    real pts[2][4][3];
+    real mdl[NB][28];   // JR9 | JT3 | axis3 | com3 | inertia xx yy zz xy xz yz | mass | pad3
+    int num_iterations, max_episode_steps, joint_act, pad;
+};
+
+__device__ __constant__ int c_parent[NB] = {-1, 0, 1, 2, 3, 4, 5, 0, 7, 8, 9, 10, 11, 0, 13, 14, 0, 16, 17};
+__device__ __constant__ int c_depth[NB] = {0, 1, 2, 3, 4, 5, 6, 1, 2, 3, 4, 5, 6, 1, 2, 3, 1, 2, 3};
+__device__ __constant__ int c_child[NB] = {-1, 2, 3, 4, 5, 6, -1, 8, 9, 10, 11, 12, -1, 14, 15, -1, 17, 18, -1};
+// ancestors-or-self bit masks over DoF indices (bit r set: DoF r supports DoF k), base DoFs support everything
+__device__ __constant__ unsigned c_anc[NV] = {
+    0x3f, 0x3f, 0x3f, 0x3f, 0x3f, 0x3f,
+    0x3f | (1u << 6), 0x3f | (3u << 6), 0x3f | (7u << 6), 0x3f | (15u << 6), 0x3f | (31u << 6), 0x3f | (63u << 6),
+    0x3f | (1u << 12), 0x3f | (3u << 12), 0x3f | (7u << 12), 0x3f | (15u << 12), 0x3f | (31u << 12), 0x3f | (63u << 12),
+    0x3f | (1u << 18), 0x3f | (3u << 18), 0x3f | (7u << 18),
+    0x3f | (1u << 21), 0x3f | (3u << 21), 0x3f | (7u << 21)};
+// plen_env.py:148-167
+__device__ __constant__ double c_range_lo[ND] = {-1.57, -0.15, -0.95, -0.9, -0.95, -0.8, -1.57, -1.5, -0.75, -0.3, -1.2, -0.4, -1.57, -0.15, -0.2, -1.57, -0.15, -0.2};
+__device__ __constant__ double c_range_hi[ND] = {1.57, 1.5, 0.75, 0.3, 1.2, 0.4, 1.57, 0.15, 0.95, 0.9, 0.95, 0.8, 1.57, 1.57, 0.35, 1.57, 1.57, 0.35};
+
+// solver visiting order of the motor rows (Bullet quickSort scramble, tools/extract_model.py); the
+// 18 limit constraints follow in the same DoF order.
+#define NC_ORDER_LIST 6, 5, 8, 7, 4, 1, 0, 3, 2, 15, 14, 17, 16, 13, 10, 9, 12, 11
+
+// ---------------------------------------------------------------- math wrappers
+__device__ inline float sqrt_(float x) { return sqrtf(x); }
+__device__ inline double sqrt_(double x) { return sqrt(x); }
+__device__ inline float sin_(float x) { return sinf(x); }
+__device__ inline double sin_(double x) { return sin(x); }
+__device__ inline float cos_(float x) { return cosf(x); }
+__device__ inline double cos_(double x) { return cos(x); }
+__device__ inline float atan2_(float y, float x) { return atan2f(y, x); }
+__device__ inline double atan2_(double y, double x) { return atan2(y, x); }
+__device__ inline float asin_(float x) { return asinf(x); }
+__device__ inline double asin_(double x) { return asin(x); }
+__device__ inline float exp_(float x) { return expf(x); }
+__device__ inline double exp_(double x) { return exp(x); }
+__device__ inline float tanh_(float x) { return tanhf(x); }
+__device__ inline double tanh_(double x) { return tanh(x); }
+__device__ inline float abs_(float x) { return fabsf(x); }
+__device__ inline double abs_(double x) { return fabs(x); }
+__device__ inline float max_(float a, float b) { return fmaxf(a, b); }
+__device__ inline double max_(double a, double b) { return fmax(a, b); }
+__device__ inline float min_(float a, float b) { return fminf(a, b); }
+__device__ inline double min_(double a, double b) { return fmin(a, b); }
+
+// wave-uniform broadcast of lane `l` (l must be wave-uniform)
+__device__ inline float bcast(float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); }
+__device__ inline double bcast(double x, int l) {
+    long long b = __builtin_bit_cast(long long, x);
+    int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ inline int bcast(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+
+// all 64 lanes of the single-wave workgroup see each other's LDS writes after this
+#define WSYNC() __syncthreads()
+
+template <typename real>
+__device__ inline real wave_max(real x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = max_(x, __shfl_xor(x, o));
+    return x;
+}
+
+// compile-time loop: f(std::integral_constant<int, i>) for i in [0, N)
+template <int... Is, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+static constexpr int NC_ORDER[ND] = {NC_ORDER_LIST};
+__host__ __device__ constexpr int port_normal(int c) { return 18 + 15 * (c / 4) + 3 + 3 * (c % 4); }
+
+__device__ __forceinline__ unsigned absbits(float x) { return __builtin_bit_cast(unsigned, x) & 0x7fffffffu; }
+__device__ __forceinline__ unsigned absbits(double x) { return __builtin_bit_cast(unsigned, (float)x) & 0x7fffffffu; }
+
+// One projected-Gauss-Seidel row at compile-time port PP (the row's data lives in lane PP):
+//   u' = clamp(u + (rv - r), lo, hi);  delta = u' - u;  lane PP keeps u';  every lane: r += At[.][PP] * delta
+// res_i accumulates max |delta| (Bullet's residual) as IEEE bits on the scalar unit.
+// f32 fast path: hand-scheduled, 7 vector issues + 5 scalar; the commit to lane PP is done by
+// narrowing EXEC to that lane instead of keeping 48 lane masks alive.
+template <bool FAST, int PP, typename real>
+__device__ __forceinline__ void pgs_row(real &r, real &u, const real rv, const real lo, const real hi, const real acol, const int lane, unsigned &res_i) {
+    if constexpr (FAST && sizeof(real) == 4) {
+        float t, d;
+        int sd;
+        unsigned long long sv;
+        constexpr unsigned mlo = PP < 32 ? (1u << PP) : 0u, mhi = PP >= 32 ? (1u << (PP - 32)) : 0u;
+        asm volatile(
+            "v_sub_f32 %[t], %[rv], %[r]\n\t"
+            "v_add_f32 %[t], %[u], %[t]\n\t"
+            "v_med3_f32 %[t], %[t], %[lo], %[hi]\n\t"
+            "v_sub_f32 %[d], %[t], %[u]\n\t"
+            "s_mov_b64 %[sv], exec\n\t"
+            "s_mov_b32 exec_lo, %[mlo]\n\t"
+            "s_mov_b32 exec_hi, %[mhi]\n\t"
+            "v_readlane_b32 %[sd], %[d], %[pp]\n\t"
+            "v_mov_b32 %[u], %[t]\n\t"
+            "s_mov_b64 exec, %[sv]\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f32 %[r], %[sd], %[a]\n\t"
+            : [t] "=&v"(t), [d] "=&v"(d), [sd] "=&s"(sd), [sv] "=&s"(sv), [u] "+v"(u), [r] "+v"(r)
+            : [rv] "v"(rv), [lo] "v"(lo), [hi] "v"(hi), [a] "v"(acol), [mlo] "i"(mlo), [mhi] "i"(mhi), [pp] "i"(PP));
+        res_i = max(res_i, (unsigned)sd & 0x7fffffffu);
+    } else {
+        const real t = u + (rv - r);
+        const real nu = min_(max_(t, lo), hi);
+        const real d = nu - u;
+        if (lane == PP) u = nu;
+        const real db = bcast(d, PP);
+        res_i = max(res_i, absbits(db));
+        r += acol * db;
+    }
+}
+
+// limit rows have Jacobian sgn * e_d on the joint's port (rare: only while a joint limit is violated)
+template <int PP, typename real>
+__device__ __forceinline__ void pgs_row_signed(real &r, real &u, const real rv, const real lo, const real hi, const real acol, const real sgn, const int lane, unsigned &res_i) {
+    const real t = u + (rv - sgn * r);
+    const real nu = min_(max_(t, lo), hi);
+    const real d = nu - u;
+    if (lane == PP) u = nu;
+    const real db = bcast(d, PP);
+    res_i = max(res_i, absbits(db));
+    r += acol * (bcast(sgn, PP) * db);
+}
+
+// cone-coupled lateral friction pair of contact point with normal port PN (rows at PN+1, PN+2),
+// btMultiBodyConstraintSolver::resolveConeFrictionConstraintRows, evaluated in lambda space
+template <bool FAST, int PN, typename real>
+__device__ __forceinline__ void pgs_cone(real &r, real &u0, const real rv, const real jdi, const real diag, const real fcl, const real aA, const real aB,
+                                         const int lane, unsigned &res_i) {
+    constexpr int PA = PN + 1, PB = PN + 2;
+    const real un = bcast(u0, PN);
+    const real sl = (u0 + (rv - r)) * jdi;          // candidate lambda of this lane's row
+    const real ll = u0 * jdi;                       // current lambda
+    const real lim = fcl * un;                      // mu * lambda_n (valid in lanes PA, PB)
+    const real sA = bcast(sl, PA), sB = bcast(sl, PB);
+    const real lA = bcast(ll, PA), lB = bcast(ll, PB);
+    const real lm = bcast(lim, PA);
+    real nA = sA, nB = sB;
+    const real len2 = sA * sA + sB * sB;
+    if (len2 >= lm * lm) {
+        // |lim*sin(atan2(sA,sB))| = lim*|sA|/hypot ; each row is clamped to its own bound
+        real inv;
+        if constexpr (sizeof(real) == 4) inv = len2 > 0 ? __builtin_amdgcn_rsqf(len2) : 0.0f;   // 1 ulp, f32 path only
+        else inv = len2 > 0 ? (real)1 / sqrt_(len2) : (real)0;
+        const real cA = abs_(lm * (sA * inv)), cB = len2 > 0 ? abs_(lm * (sB * inv)) : abs_(lm);
+        nA = min_(max_(sA, -cA), cA);
+        nB = min_(max_(sB, -cB), cB);
+    }
+    const real dgA = bcast(diag, PA), dgB = bcast(diag, PB);
+    const real dA = (nA - lA) * dgA, dB = (nB - lB) * dgB;     // deltaVel of each row
+    if (lane == PA) u0 = nA * dgA;
+    if (lane == PB) u0 = nB * dgB;
+    res_i = max(res_i, absbits(dA + dB));
+    r += aA * dA + aB * dB;
+}
+
+template <typename real> __device__ inline void cross3(real *c, const real *a, const real *b) {
+    real x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    c[0] = x; c[1] = y; c[2] = z;
+}
+template <typename real> __device__ inline real dot3(const real *a, const real *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+template <typename real> __device__ inline void matvec3(real *o, const real *M, const real *v) {
+    real x = M[0] * v[0] + M[1] * v[1] + M[2] * v[2], y = M[3] * v[0] + M[4] * v[1] + M[5] * v[2], z = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+
+// ---------------------------------------------------------------- LDS layout (one wave = one env)
+template <typename real>
+struct Smem {
+    real st[REC];
+    real tgt[NV];
+    real RO[NB][12];    // world rotation (9, row major) + frame origin (3)
+    real CA[NB][8];     // COM world (3) | pad | joint axis world (3) | pad
+    real kin[NB][12];   // omega | velocity-product alpha | v_origin | velocity-product a_origin
+    real I[NB][16];     // m, m*c (3), Io (xx yy zz xy xz yz) about the base origin; then F(3), N(3): subtree sums
+    real S[NV][8];      // motion subspace about the base origin: [angular; linear]
+    real M[NV][NV + 1]; // mass matrix, later its Cholesky factor L (lower)
+    real tau[NV];
+    real v[NV];         // generalized velocity after the unconstrained update
+    real col[NV];       // broadcast buffer
+    real Y[NPORT][NV + 1];  // J (then L^-1 J^T) per port
+    real lamP[NPORT];
+    real misc[16];
+};
+
+// ---------------------------------------------------------------- forward kinematics + velocity recursion
+// lane b < 19 owns body b.  Fills RO, CA, kin.  with_vel=false: orientation/position only.
+template <typename real>
+__device__ __forceinline__ void kinematics(Smem<real> &s, const DevParams<real> &P, int lane, bool with_vel) {
+    const int b = lane < NB ? lane : 0;
+    const real *m = P.mdl[b];
+    real R[9], O[3], w[3] = {0, 0, 0}, al[3] = {0, 0, 0}, vo[3] = {0, 0, 0}, ao[3] = {0, 0, 0};
+    real L[9];
+    real qd = 0;
+    if (lane < NB) {
+        if (b == 0) {
+            real x = s.st[3], y = s.st[4], z = s.st[5], ww = s.st[6];
+            real d = x * x + y * y + z * z + ww * ww, sc = (real)2 / d;
+            real xs = x * sc, ys = y * sc, zs = z * sc;
+            real wx = ww * xs, wy = ww * ys, wz = ww * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
+            R[0] = 1 - (yy + zz); R[1] = xy - wz; R[2] = xz + wy;
+            R[3] = xy + wz; R[4] = 1 - (xx + zz); R[5] = yz - wx;
+            R[6] = xz - wy; R[7] = yz + wx; R[8] = 1 - (xx + yy);
+            O[0] = s.st[0]; O[1] = s.st[1]; O[2] = s.st[2];
+            w[0] = s.st[7]; w[1] = s.st[8]; w[2] = s.st[9];
+            vo[0] = s.st[10]; vo[1] = s.st[11]; vo[2] = s.st[12];
+#pragma unroll
+            for (int i = 0; i < 9; i++) s.RO[0][i] = R[i];
+#pragma unroll
+            for (int i = 0; i < 3; i++) { s.RO[0][9 + i] = O[i]; s.kin[0][i] = w[i]; s.kin[0][3 + i] = 0; s.kin[0][6 + i] = vo[i]; s.kin[0][9 + i] = 0; }
+        } else {
+            // local rotation  L = JR * Rot(axis, q)   (Rodrigues)
+            real q = s.st[13 + b - 1];
+            qd = s.st[31 + b - 1];
+            real a0 = m[12], a1 = m[13], a2 = m[14];
+            real c = cos_(q), sn = sin_(q), t = 1 - c;
+            real Rq[9] = {c + a0 * a0 * t, a0 * a1 * t - a2 * sn, a0 * a2 * t + a1 * sn,
+                          a1 * a0 * t + a2 * sn, c + a1 * a1 * t, a1 * a2 * t - a0 * sn,
+                          a2 * a0 * t - a1 * sn, a2 * a1 * t + a0 * sn, c + a2 * a2 * t};
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) L[3 * i + j] = m[3 * i] * Rq[j] + m[3 * i + 1] * Rq[3 + j] + m[3 * i + 2] * Rq[6 + j];
+        }
+    }
+    const int depth = lane < NB ? c_depth[b] : -1;
+    const int par = lane < NB && b > 0 ? c_parent[b] : 0;
+    for (int level = 1; level <= 6; level++) {
+        WSYNC();
+        if (depth == level) {
+            real Rp[9], Op[3];
+#pragma unroll
+            for (int i = 0; i < 9; i++) Rp[i] = s.RO[par][i];
+#pragma unroll
+            for (int i = 0; i < 3; i++) Op[i] = s.RO[par][9 + i];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) R[3 * i + j] = Rp[3 * i] * L[j] + Rp[3 * i + 1] * L[3 + j] + Rp[3 * i + 2] * L[6 + j];
+            real d[3];
+            matvec3(d, Rp, &m[9]);
+#pragma unroll
+            for (int i = 0; i < 3; i++) O[i] = Op[i] + d[i];
+#pragma unroll
+            for (int i = 0; i < 9; i++) s.RO[b][i] = R[i];
+#pragma unroll
+            for (int i = 0; i < 3; i++) s.RO[b][9 + i] = O[i];
+            if (with_vel) {
+                real wp[3], alp[3], vop[3], aop[3], ax[3], rel[3], t1[3], t2[3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) { wp[i] = s.kin[par][i]; alp[i] = s.kin[par][3 + i]; vop[i] = s.kin[par][6 + i]; aop[i] = s.kin[par][9 + i]; }
+                matvec3(ax, R, &m[12]);
+#pragma unroll
+                for (int i = 0; i < 3; i++) { rel[i] = ax[i] * qd; w[i] = wp[i] + rel[i]; }
+                cross3(t1, wp, rel);
+#pragma unroll
+                for (int i = 0; i < 3; i++) al[i] = alp[i] + t1[i];
+                cross3(t1, wp, d);
+#pragma unroll
+                for (int i = 0; i < 3; i++) vo[i] = vop[i] + t1[i];
+                cross3(t2, wp, t1);           // wp x (wp x d)
+                cross3(t1, alp, d);
+#pragma unroll
+                for (int i = 0; i < 3; i++) ao[i] = aop[i] + t1[i] + t2[i];
+#pragma unroll
+                for (int i = 0; i < 3; i++) { s.kin[b][i] = w[i]; s.kin[b][3 + i] = al[i]; s.kin[b][6 + i] = vo[i]; s.kin[b][9 + i] = ao[i]; }
+            }
+        }
+    }
+    WSYNC();
+    if (lane < NB) {
+        real e[3], ax[3];
+        matvec3(e, R, &m[15]);
+        matvec3(ax, R, &m[12]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) { s.CA[b][i] = O[i] + e[i]; s.CA[b][4 + i] = ax[i]; }
+    }
+}
+
+// ---------------------------------------------------------------- per-body inertia + bias wrench, subtree sums
+template <typename real>
+__device__ __forceinline__ void body_dynamics(Smem<real> &s, const DevParams<real> &P, int lane, real mass_scale) {
+    if (lane < NB) {
+        const int b = lane;
+        const real *m = P.mdl[b];
+        real R[9], w[3], al[3], vo[3], ao[3], O[3], c[3];
+#pragma unroll
+        for (int i = 0; i < 9; i++) R[i] = s.RO[b][i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) { O[i] = s.RO[b][9 + i]; c[i] = s.CA[b][i]; w[i] = s.kin[b][i]; al[i] = s.kin[b][3 + i]; vo[i] = s.kin[b][6 + i]; ao[i] = s.kin[b][9 + i]; }
+        // world inertia  Iw = R I R^T  (I symmetric: xx yy zz xy xz yz)
+        real Il[9] = {m[18], m[21], m[22], m[21], m[19], m[23], m[22], m[23], m[20]};
+        real T[9], Iw[9];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) T[3 * i + j] = R[3 * i] * Il[j] + R[3 * i + 1] * Il[3 + j] + R[3 * i + 2] * Il[6 + j];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) Iw[3 * i + j] = (T[3 * i] * R[3 * j] + T[3 * i + 1] * R[3 * j + 1] + T[3 * i + 2] * R[3 * j + 2]) * mass_scale;
+        const real ms = m[24] * mass_scale;
+        real e[3] = {c[0] - O[0], c[1] - O[1], c[2] - O[2]}, t1[3], t2[3], vc[3], ac[3];
+        cross3(t1, w, e);
+#pragma unroll
+        for (int i = 0; i < 3; i++) vc[i] = vo[i] + t1[i];
+        cross3(t2, w, t1);
+        cross3(t1, al, e);
+#pragma unroll
+        for (int i = 0; i < 3; i++) ac[i] = ao[i] + t1[i] + t2[i];
+        const real vn = sqrt_(dot3(vc, vc));
+        real f[3], n[3], Iwv[3];
+        const real g[3] = {0, 0, P.gz};
+#pragma unroll
+        for (int i = 0; i < 3; i++) f[i] = ms * (ac[i] - g[i]) + ms * vc[i] * (P.lin_damp + P.lin_damp * vn);
+        matvec3(Iwv, Iw, w);
+        cross3(t1, w, Iwv);
+        matvec3(n, Iw, al);
+#pragma unroll
+        for (int i = 0; i < 3; i++) n[i] += t1[i];
+        real cO[3] = {c[0] - s.st[0], c[1] - s.st[1], c[2] - s.st[2]};
+        cross3(t1, cO, f);
+        const real cc = dot3(cO, cO);
+        s.I[b][0] = ms;
+        s.I[b][1] = ms * cO[0]; s.I[b][2] = ms * cO[1]; s.I[b][3] = ms * cO[2];
+        s.I[b][4] = Iw[0] + ms * (cc - cO[0] * cO[0]);
+        s.I[b][5] = Iw[4] + ms * (cc - cO[1] * cO[1]);
+        s.I[b][6] = Iw[8] + ms * (cc - cO[2] * cO[2]);
+        s.I[b][7] = Iw[1] - ms * cO[0] * cO[1];
+        s.I[b][8] = Iw[2] - ms * cO[0] * cO[2];
+        s.I[b][9] = Iw[5] - ms * cO[1] * cO[2];
+#pragma unroll
+        for (int i = 0; i < 3; i++) { s.I[b][10 + i] = f[i]; s.I[b][13 + i] = n[i] + t1[i]; }
+    }
+    // subtree sums, deepest parents first; a chain body has one child, the base has four
+    const int depth = lane < NB ? c_depth[lane] : -1;
+    const int child = lane < NB ? c_child[lane] : -1;
+    for (int level = 5; level >= 1; level--) {
+        WSYNC();
+        if (depth == level && child >= 0) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) s.I[lane][i] += s.I[child][i];
+        }
+    }
+    WSYNC();
+    if (lane < 16) s.I[0][lane] += s.I[1][lane] + s.I[7][lane] + s.I[13][lane] + s.I[16][lane];
+    WSYNC();
+}
+
+// ---------------------------------------------------------------- env-level helpers
+template <typename real>
+__device__ __forceinline__ void euler_from_quat(const real *q, real *rpy) {   // pybullet.c getEulerFromQuaternion
+    real sqx = q[0] * q[0], sqy = q[1] * q[1], sqz = q[2] * q[2], squ = q[3] * q[3];
+    real sarg = -2 * (q[0] * q[2] - q[3] * q[1]);
+    const real PI = (real)3.14159265358979323846;
+    if (sarg <= (real)-0.99999) { rpy[0] = 0; rpy[1] = (real)-0.5 * PI; rpy[2] = 2 * atan2_(q[0], -q[1]); }
+    else if (sarg >= (real)0.99999) { rpy[0] = 0; rpy[1] = (real)0.5 * PI; rpy[2] = 2 * atan2_(-q[0], q[1]); }
+    else {
+        rpy[0] = atan2_(2 * (q[1] * q[2] + q[3] * q[0]), squ - sqx - sqy + sqz);
+        rpy[1] = asin_(sarg);
+        rpy[2] = atan2_(2 * (q[0] * q[1] + q[3] * q[2]), squ + sqx - sqy - sqz);
+    }
+}
+
+// ---------------------------------------------------------------- one 1/240 s physics substep
+// Contact flags of this substep's collision pass are returned in rc/lc, solver iterations in iters.
+template <bool FAST, typename real>
+__device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P, const int lane, const real mass_scale, const real mu_lat,
+                               int &rc, int &lc, int &iters, real *dump) {
+    // ---------------- A. kinematics, inertias, bias ----------------
+    kinematics(s, P, lane, true);
+    body_dynamics(s, P, lane, mass_scale);
+    const real O0[3] = {s.st[0], s.st[1], s.st[2]};
+
+    // ---------------- B. motion subspaces, mass matrix, bias force ----------------
+    const int k = lane < NV ? lane : 0;
+    const int kb = k < 6 ? 0 : k - 5;           // body whose composite inertia column k uses
+    real Sk[6] = {0, 0, 0, 0, 0, 0};
+    if (lane < NV) {
+        if (k < 6) Sk[k] = 1;
+        else {
+            real a[3] = {s.CA[kb][4], s.CA[kb][5], s.CA[kb][6]}, r[3] = {s.RO[kb][9] - O0[0], s.RO[kb][10] - O0[1], s.RO[kb][11] - O0[2]};
+            Sk[0] = a[0]; Sk[1] = a[1]; Sk[2] = a[2];
+            cross3(&Sk[3], r, a);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) s.S[k][i] = Sk[i];
+    }
+    WSYNC();
+    if (lane < NV) {
+        const real *I = s.I[kb];
+        const real cm = I[0], mc[3] = {I[1], I[2], I[3]};
+        const real Io[9] = {I[4], I[7], I[8], I[7], I[5], I[9], I[8], I[9], I[6]};
+        real n[3], f[3], t1[3];
+        matvec3(n, Io, &Sk[0]);
+        cross3(t1, mc, &Sk[3]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) n[i] += t1[i];
+        cross3(t1, &Sk[0], mc);
+#pragma unroll
+        for (int i = 0; i < 3; i++) f[i] = cm * Sk[3 + i] + t1[i];
+        const unsigned anc = c_anc[k];
+#pragma unroll
+        for (int r = 0; r < NV; r++) {
+            real val = s.S[r][0] * n[0] + s.S[r][1] * n[1] + s.S[r][2] * n[2] + s.S[r][3] * f[0] + s.S[r][4] * f[1] + s.S[r][5] * f[2];
+            if (r <= k) {
+                if (!((anc >> r) & 1u)) val = 0;
+                s.M[r][k] = val;
+                s.M[k][r] = val;
+            }
+        }
+        // generalized bias force (motors are constraints, so no joint torque here)
+        real tau;
+        if (k < 3) tau = -s.I[0][13 + k];
+        else if (k < 6) tau = -s.I[0][10 + k - 3];
+        else {
+            real r[3] = {s.RO[kb][9] - O0[0], s.RO[kb][10] - O0[1], s.RO[kb][11] - O0[2]};
+            real F[3] = {s.I[kb][10], s.I[kb][11], s.I[kb][12]}, N[3] = {s.I[kb][13], s.I[kb][14], s.I[kb][15]};
+            cross3(t1, r, F);
+            tau = -(Sk[0] * (N[0] - t1[0]) + Sk[1] * (N[1] - t1[1]) + Sk[2] * (N[2] - t1[2]));
+        }
+        s.tau[k] = tau;
+    }
+    WSYNC();
+    if (dump && lane < NV) {
+#pragma unroll
+        for (int r = 0; r < NV; r++) dump[r * NV + lane] = s.M[r][lane];
+        dump[576 + lane] = s.tau[lane];
+    }
+
+    // ---------------- C. Cholesky  M = L L^T, row `lane` in registers ----------------
+    real Lr[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) Lr[j] = lane < NV ? s.M[k][j] : (real)0;
+    real inv_diag = 0;      // 1 / L[lane][lane]
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const real djj = bcast(Lr[j], j);
+        const real d = sqrt_(djj), rd = (real)1 / d;
+        real lij = Lr[j] * rd;
+        if (lane == j) { lij = d; inv_diag = rd; }
+        if (lane < j) lij = 0;
+        Lr[j] = lij;
+        if (lane < NV) s.col[lane] = lij;
+        WSYNC();
+#pragma unroll
+        for (int c = j + 1; c < NV; c++) Lr[c] -= lij * s.col[c];
+        WSYNC();
+    }
+    if (lane < NV) {
+#pragma unroll
+        for (int j = 0; j < NV; j++) s.M[k][j] = Lr[j];
+    }
+    // ---------------- D. unconstrained velocity update  v* = clamp(v + dt M^-1 tau) ----------------
+    real vstar;
+    {
+        real bi = lane < NV ? s.tau[k] : (real)0, y = 0;
+#pragma unroll
+        for (int j = 0; j < NV; j++) {        // L y = tau
+            const real t = bi * inv_diag;
+            const real yj = bcast(t, j);
+            if (lane == j) y = t;
+            if (lane > j) bi -= Lr[j] * yj;
+        }
+        WSYNC();
+        // L^T x = y : lane i needs column i of L
+        real x = 0;
+#pragma unroll
+        for (int j = NV - 1; j >= 0; j--) {
+            const real t = y * inv_diag;
+            const real xj = bcast(t, j);
+            if (lane == j) x = t;
+            if (lane < j) y -= s.M[j][k] * xj;
+        }
+        const real vk = lane < 3 ? s.st[7 + k] : (lane < 6 ? s.st[10 + k - 3] : (lane < NV ? s.st[31 + k - 6] : (real)0));
+        vstar = vk + P.dt * x;
+        vstar = min_(max_(vstar, -P.vmax), P.vmax);
+        if (lane < NV) s.v[k] = vstar;
+    }
+    WSYNC();
+    if (dump && lane < NV) {
+#pragma unroll
+        for (int r = 0; r < NV; r++) dump[640 + r * NV + lane] = s.M[r][lane];
+        dump[600 + lane] = s.v[lane];
+    }
+
+    // ---------------- E. collision (feet vs ground) and port Jacobians ----------------
+    // port p: 0..17 joint d | 18+15f+{0,1,2} foot f torsional (n, dir1, dir2) | 18+15f+3+3k+{0,1,2} point k linear
+    const int p = lane < NPORT ? lane : 0;
+    const bool is_joint = lane < ND;
+    const int pf = (p - 18) / 15;                 // foot (valid for p >= 18)
+    const int pl = (p - 18) - 15 * pf;            // 0..14 within foot
+    const bool is_tors = lane >= ND && lane < NPORT && pl < 3;
+    const bool is_lin = lane >= ND && lane < NPORT && pl >= 3;
+    const int pk = is_lin ? (pl - 3) / 3 : 0;     // contact point
+    const int pax = is_lin ? (pl - 3) % 3 : pl;   // 0 normal, 1 dir1 (0,-1,0), 2 dir2 (1,0,0)
+    const int fb = pf == 0 ? GEN_RFOOT_BODY : GEN_LFOOT_BODY;
+    real dist = 0;
+    real Pw[3] = {0, 0, 0};
+    if (lane >= ND && lane < NPORT) {
+#pragma unroll
+        for (int j = 0; j < NV; j++) s.Y[p][j] = 0;
+        real ax[3] = {pax == 2 ? (real)1 : (real)0, pax == 1 ? (real)-1 : (real)0, pax == 0 ? (real)1 : (real)0};
+        if (is_lin) {
+            const real *pt = P.pts[pf][pk];
+            real wp[3];
+            matvec3(wp, s.RO[fb], pt);
+            dist = wp[2] + s.RO[fb][11] - P.margin;
+            Pw[0] = wp[0] + s.RO[fb][9]; Pw[1] = wp[1] + s.RO[fb][10]; Pw[2] = dist;   // sphere-swept vertex: point on the robot
+            real r[3] = {Pw[0] - O0[0], Pw[1] - O0[1], Pw[2] - O0[2]}, t1[3];
+            cross3(t1, r, ax);
+#pragma unroll
+            for (int i = 0; i < 3; i++) { s.Y[p][i] = t1[i]; s.Y[p][3 + i] = ax[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; i++) s.Y[p][i] = ax[i];
+        }
+        for (int i = 0; i < 6; i++) {           // the six leg joints that move this foot
+            const int b = fb - 5 + i;
+            real a[3] = {s.CA[b][4], s.CA[b][5], s.CA[b][6]};
+            real val;
+            if (is_lin) {
+                real r[3] = {Pw[0] - s.RO[b][9], Pw[1] - s.RO[b][10], Pw[2] - s.RO[b][11]}, t1[3];
+                cross3(t1, r, ax);
+                val = dot3(a, t1);
+            } else val = dot3(a, ax);
+            s.Y[p][5 + b] = val;
+        }
+    }
+    const bool cp_active = is_lin && dist <= P.brk[pf];
+    const unsigned long long act_ballot = __ballot(cp_active && pax == 0);
+    // active-point mask in manifold order (right foot points 0..3, left foot 4..7)
+    unsigned act = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) act |= (unsigned)((act_ballot >> (18 + 15 * (c / 4) + 3 + 3 * (c % 4))) & 1ull) << c;
+    rc = (act & 0x0fu) != 0; lc = (act & 0xf0u) != 0;
+    WSYNC();
+    // own Jacobian row into registers, b = J v*, then Y = L^-1 J^T by forward substitution
+    real Jr[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) Jr[j] = is_joint ? (j == 6 + p ? (real)1 : (real)0) : s.Y[p][j];
+    real bvel = 0;
+#pragma unroll
+    for (int j = 0; j < NV; j++) bvel += Jr[j] * s.v[j];
+    // inverse diagonal of L for every row, via LDS
+    if (lane < NV) s.col[lane] = inv_diag;
+    WSYNC();
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        real acc = Jr[i];
+#pragma unroll
+        for (int j = 0; j < i; j++) acc -= s.M[i][j] * Jr[j];
+        Jr[i] = acc * s.col[i];
+    }
+    if (lane < NPORT) {
+#pragma unroll
+        for (int j = 0; j < NV; j++) s.Y[p][j] = Jr[j];
+    }
+    WSYNC();
+    // ---------------- F. port Delassus matrix, one row per lane in registers ----------------
+    // A[p][q] = Y_p . Y_q, accumulated over the 24 generalized coordinates (outer loop kept rolled so
+    // that only the 48 accumulators are live)
+    real Ar[NPORT];
+#pragma unroll
+    for (int q = 0; q < NPORT; q++) Ar[q] = 0;
+#pragma unroll 1
+    for (int j = 0; j < NV; j++) {
+        const real yj = s.Y[p][j];
+#pragma unroll
+        for (int q = 0; q < NPORT; q++) Ar[q] += yj * s.Y[q][j];
+    }
+    real diag = 0;
+#pragma unroll
+    for (int q = 0; q < NPORT; q++) if (lane == q) diag = Ar[q];
+    const real EPS = sizeof(real) == 8 ? (real)2.220446049250313e-16 : (real)1.1920929e-07;
+    const real jdi = diag > EPS ? (real)1 / diag : (real)0;
+    if (dump) {
+        if (lane < NPORT) {
+#pragma unroll
+            for (int q = 0; q < NPORT; q++) dump[1216 + lane * NPORT + q] = Ar[q];
+            dump[3520 + lane] = bvel;
+            dump[3568 + lane] = dist;
+        }
+    }
+    // The solver below works with velocity-scaled impulses u = lambda * diag (so a row's impulse
+    // change IS Bullet's "deltaVel" residual) and the column-scaled matrix At[q][p] = A[q][p] / diag_p.
+    WSYNC();
+    if (lane < NPORT) s.lamP[p] = jdi;
+    WSYNC();
+#pragma unroll
+    for (int q = 0; q < NPORT; q++) Ar[q] *= s.lamP[q];
+
+    // ---------------- G. rows ----------------
+    // joint lanes: motor row (+ a limit row when violated); contact lanes: one row per port, except the
+    // torsional ports which carry one row per active contact point of their foot (same Jacobian).
+    // rv = velocity-level right-hand side (Bullet's m_rhs / jacDiagABInv)
+    real rv = 0, u0 = 0, u1 = 0, u2 = 0, u3 = 0;   // u0..3: torsional per point; u0: everything else
+    real rv_lim = 0, u_lim = 0, sgn_lim = 1;
+    bool lim_active = false;
+    const real dis = jdi > 0 ? (real)1 : (real)0;  // a row whose diagonal vanished is disabled (m_jacDiagABInv = 0)
+    if (is_joint) {
+        const real q = s.st[13 + p], tgt = s.tgt[p];
+        rv = (P.kp * ((tgt - q) * P.inv_dt) + bvel + P.kd * (0 - bvel) - bvel) * dis;
+        const real lo = (real)GEN_LOWER_LIMIT, hi = (real)GEN_UPPER_LIMIT;
+        const real pen_lo = q - lo, pen_hi = hi - q;
+        if (pen_lo <= 0) {
+            lim_active = true; sgn_lim = 1;
+            const real pos_err = pen_lo > (real)-0.04 ? -pen_lo * P.erp * P.inv_dt : (real)0;
+            rv_lim = (pos_err - bvel) * dis;
+        } else if (pen_hi <= 0) {
+            lim_active = true; sgn_lim = -1;
+            const real pos_err = pen_hi > (real)-0.04 ? -pen_hi * P.erp * P.inv_dt : (real)0;
+            rv_lim = (pos_err + bvel) * dis;
+        }
+    } else if (is_lin && pax == 0) {
+        const real distance = dist + P.slop;
+        real rest = abs_(bvel) < P.rest_thr ? (real)0 : P.restitution * -bvel;
+        rest = max_(rest, (real)0);
+        real pos_err = 0, vel_err = rest - bvel;
+        if (distance > 0) vel_err -= distance * P.inv_dt; else pos_err = -distance * P.erp2 * P.inv_dt;
+        rv = (pos_err + vel_err) * dis;
+    } else if (lane < NPORT) {
+        rv = (0 - bvel) * dis;
+    }
+    const unsigned long long lim_ballot = __ballot(lim_active);
+    const unsigned lim_mask = (unsigned)(lim_ballot & 0x3ffffull);
+    // bounds in u units: lambda in [lo, hi]  <=>  u in [lo*diag, hi*diag]
+    const real motor_hi = P.max_imp * diag;
+    const real lim_hi = (real)100 * diag;
+    const real nrm_hi = (real)1e10 * diag;
+    // friction bound of a row = mu * lambda_n = (mu * diag_row * jdi_n) * u_n ; jdi of every port is in lamP
+    real fc0 = 0, fc1 = 0, fc2 = 0, fc3 = 0;
+    if (is_tors) {
+        const real mu = (pl == 0 ? P.mu_spin : P.mu_roll) * diag;
+        const int pn0 = 18 + 15 * pf + 3;
+        fc0 = mu * s.lamP[pn0]; fc1 = mu * s.lamP[pn0 + 3]; fc2 = mu * s.lamP[pn0 + 6]; fc3 = mu * s.lamP[pn0 + 9];
+    }
+    // lateral friction is cone-coupled in lambda space: keep mu_lat * jdi_n for the point's normal port
+    const real fcl = (is_lin && pax != 0) ? mu_lat * s.lamP[p - pax] : (real)0;
+
+    real r = 0;                    // J_port * deltaV, this lane's port
+    unsigned res_i = 0;            // wave-uniform running max |deltaVel| of this iteration (IEEE bits, non-negative)
+    const unsigned thr_i = __builtin_bit_cast(unsigned, (float)sqrt((double)P.res_thr));
+
+    int it = 0;
+    for (it = 0; it < P.num_iterations; it++) {
+        res_i = 0;
+        // -- non-contact rows: sorted order (motors, then limits) on odd iterations, reversed on even ones --
+        if (it & 1) {
+            static_for<ND>([&](auto ic) { constexpr int PP = NC_ORDER[decltype(ic)::value]; pgs_row<FAST, PP>(r, u0, rv, -motor_hi, motor_hi, Ar[PP], lane, res_i); });
+            if (lim_mask) {
+                static_for<ND>([&](auto ic) {
+                    constexpr int PP = NC_ORDER[decltype(ic)::value];
+                    if (lim_mask & (1u << PP)) pgs_row_signed<PP>(r, u_lim, rv_lim, (real)0, lim_hi, Ar[PP], sgn_lim, lane, res_i);
+                });
+            }
+        } else {
+            if (lim_mask) {
+                static_for<ND>([&](auto ic) {
+                    constexpr int PP = NC_ORDER[ND - 1 - decltype(ic)::value];
+                    if (lim_mask & (1u << PP)) pgs_row_signed<PP>(r, u_lim, rv_lim, (real)0, lim_hi, Ar[PP], sgn_lim, lane, res_i);
+                });
+            }
+            static_for<ND>([&](auto ic) { constexpr int PP = NC_ORDER[ND - 1 - decltype(ic)::value]; pgs_row<FAST, PP>(r, u0, rv, -motor_hi, motor_hi, Ar[PP], lane, res_i); });
+        }
+        // -- normal rows (manifold order: right foot points, then left foot points) --
+        static_for<8>([&](auto ic) {
+            constexpr int c = decltype(ic)::value, PP = port_normal(c);
+            if (act & (1u << c)) pgs_row<FAST, PP>(r, u0, rv, (real)0, nrm_hi, Ar[PP], lane, res_i);
+        });
+        // -- spinning rows (one per active point, all on the foot's normal-axis torsional port) --
+        if (P.mu_spin > 0) {
+            static_for<8>([&](auto ic) {
+                constexpr int c = decltype(ic)::value, PN = port_normal(c), PP = 18 + 15 * (c / 4);
+                if (act & (1u << c)) {
+                    const real un = bcast(u0, PN);
+                    if (un > 0) {
+                        real &uu = (c % 4) == 0 ? u0 : (c % 4) == 1 ? u1 : (c % 4) == 2 ? u2 : u3;
+                        const real lim = ((c % 4) == 0 ? fc0 : (c % 4) == 1 ? fc1 : (c % 4) == 2 ? fc2 : fc3) * un;
+                        pgs_row<FAST, PP>(r, uu, rv, -lim, lim, Ar[PP], lane, res_i);
+                    }
+                }
+            });
+        }
+        // -- rolling rows (two per active point) --
+        if (P.mu_roll > 0) {
+            static_for<8>([&](auto ic) {
+                constexpr int c = decltype(ic)::value, PN = port_normal(c), PP = 18 + 15 * (c / 4);
+                if (act & (1u << c)) {
+                    const real un = bcast(u0, PN);
+                    if (un > 0) {
+                        real &uu = (c % 4) == 0 ? u0 : (c % 4) == 1 ? u1 : (c % 4) == 2 ? u2 : u3;
+                        const real lim = ((c % 4) == 0 ? fc0 : (c % 4) == 1 ? fc1 : (c % 4) == 2 ? fc2 : fc3) * un;
+                        pgs_row<FAST, PP + 1>(r, uu, rv, -lim, lim, Ar[PP + 1], lane, res_i);
+                        pgs_row<FAST, PP + 2>(r, uu, rv, -lim, lim, Ar[PP + 2], lane, res_i);
+                    }
+                }
+            });
+        }
+        // -- lateral friction, cone-coupled pairs --
+        static_for<8>([&](auto ic) {
+            constexpr int c = decltype(ic)::value, PN = port_normal(c);
+            if (act & (1u << c)) pgs_cone<FAST, PN>(r, u0, rv, jdi, diag, fcl, Ar[PN + 1], Ar[PN + 2], lane, res_i);
+        });
+        if (res_i <= thr_i || it >= P.num_iterations - 1) { it++; break; }
+    }
+    iters = it;
+    const real lam0 = u0 * jdi, lam1 = u1 * jdi, lam2 = u2 * jdi, lam3 = u3 * jdi, lam_lim = u_lim * jdi;
+
+    // ---------------- H. apply impulses:  dv = L^-T (Y Lambda),  v = clamp(v* + dv) ----------------
+    {
+        real lamP = lam0 + lam1 + lam2 + lam3 + sgn_lim * lam_lim;
+        if (lane < NPORT) s.lamP[p] = lamP;
+        WSYNC();
+        real z = 0;
+        if (lane < NV) {
+#pragma unroll
+            for (int q = 0; q < NPORT; q++) z += s.Y[q][k] * s.lamP[q];
+        }
+        real x = 0;
+#pragma unroll
+        for (int j = NV - 1; j >= 0; j--) {
+            const real t = z * inv_diag;
+            const real xj = bcast(t, j);
+            if (lane == j) x = t;
+            if (lane < j) z -= s.M[j][k] * xj;
+        }
+        real vn = vstar + x;
+        vn = min_(max_(vn, -P.vmax), P.vmax);
+        WSYNC();
+        if (lane < NV) s.v[k] = vn;
+        if (dump && lane < NPORT) dump[3616 + lane] = lamP;
+        if (dump && lane == 0) dump[3700] = (real)it;
+    }
+    WSYNC();
+    // ---------------- I. integrate positions (btMultiBody::stepPositionsMultiDof) ----------------
+    {
+        const real w0 = s.v[0], w1 = s.v[1], w2 = s.v[2];
+        real fa = sqrt_(w0 * w0 + w1 * w1 + w2 * w2);
+        const real HALF_PI = (real)1.5707963267948966;
+        if (fa * P.dt > (real)0.5 * HALF_PI) fa = (real)0.5 * HALF_PI / P.dt;
+        real kk;
+        if (fa < (real)0.001) kk = (real)0.5 * P.dt - (P.dt * P.dt * P.dt) * (real)0.020833333333 * fa * fa;
+        else kk = sin_((real)0.5 * fa * P.dt) / fa;
+        const real dq[4] = {w0 * kk, w1 * kk, w2 * kk, cos_(fa * P.dt * (real)0.5)};
+        const real q0[4] = {s.st[3], s.st[4], s.st[5], s.st[6]};
+        real rq[4];
+        rq[3] = dq[3] * q0[3] - dq[0] * q0[0] - dq[1] * q0[1] - dq[2] * q0[2];
+        rq[0] = dq[3] * q0[0] + dq[0] * q0[3] + dq[1] * q0[2] - dq[2] * q0[1];
+        rq[1] = dq[3] * q0[1] + dq[1] * q0[3] + dq[2] * q0[0] - dq[0] * q0[2];
+        rq[2] = dq[3] * q0[2] + dq[2] * q0[3] + dq[0] * q0[1] - dq[1] * q0[0];
+        const real nrm = sqrt_(rq[0] * rq[0] + rq[1] * rq[1] + rq[2] * rq[2] + rq[3] * rq[3]);
+        WSYNC();
+        if (lane < 3) { s.st[lane] += P.dt * s.v[3 + lane]; s.st[7 + lane] = s.v[lane]; s.st[10 + lane] = s.v[3 + lane]; }
+        if (lane < 4) s.st[3 + lane] = rq[lane] / nrm;
+        if (lane >= 6 && lane < NV) { s.st[13 + lane - 6] += P.dt * s.v[lane]; s.st[31 + lane - 6] = s.v[lane]; }
+    }
+    WSYNC();
+}
+
+// ================================================================================================
+// kernels
+// ================================================================================================
+enum { MODE_STEP = 0, MODE_RESET_BUILD = 1, MODE_DEBUG = 2 };
+
+template <typename real>
+struct StepArgs {
+    const DevParams<real> *P;
+    real *state; int *aux;                       // [N][64], [N][8]
+    real *reset_state; int *reset_aux; real *reset_obs;   // reset cache [N][64], [N][8], [N][26]
+    const float *action;                         // [N][18]   MODE_STEP
+    const real *targets;                         // [N][18]   MODE_DEBUG
+    real *next_obs; real *reward; uint8_t *done; real *cur_obs;
+    const real *mass_scale; const real *mu_lat;  // per-env domain randomisation or null
+    real *dump;                                  // [N][PLENVEC_DUMP] or null
+    int n, mode, nsub, auto_reset;
+};
+
+// plen_env.py:694-714, evaluated in double so the +-0.001 clamps fire exactly where the reference's do
+__device__ inline double agent_to_env(int j, double a) {
+    const double lo = c_range_lo[j], hi = c_range_hi[j];
+    const double m = (hi - lo) / (1.0 - (-1.0));
+    const double b = hi - (m * 1.0);
+    double v = m * a + b;
+    if (v >= hi) v = hi - 0.001; else if (v <= lo) v = lo + 0.001;
+    return v;
+}
+
+template <typename real, bool FAST>
+__global__ __launch_bounds__(64, sizeof(real) == 8 ? 2 : 4) void plen_env_kernel(StepArgs<real> a) {
+    __shared__ Smem<real> s;
+    const int env = blockIdx.x;
+    const int lane = threadIdx.x;
+    const DevParams<real> &P = *a.P;
+    const real mass_scale = a.mass_scale ? a.mass_scale[env] : (real)1;
+    const real mu_lat = a.mu_lat ? a.mu_lat[env] : P.mu_lat;
+    real *dump = a.dump ? a.dump + (size_t)env * PLENVEC_DUMP : nullptr;
+
+    // ---- load the env record (one coalesced 64-real read) ----
+    int gait_cnt, ds_cnt, ep_step, nhist;
+    if (a.mode == MODE_RESET_BUILD) {
+        real v = 0;
+        if (lane == 2) v = P.spawn_z;
+        if (lane == 6) v = 1;
+        s.st[lane] = v;
+        gait_cnt = ds_cnt = ep_step = nhist = 0;
+    } else {
+        s.st[lane] = a.state[(size_t)env * REC + lane];
+        const int *ax = a.aux + (size_t)env * AUXN;
+        gait_cnt = ax[0]; ds_cnt = ax[1]; ep_step = ax[2]; nhist = ax[3];
+    }
+    // ---- motor targets ----
+    if (lane < NV) {
+        real t = 0;
+        if (lane < ND) {
+            if (a.mode == MODE_STEP) {
+                const double act = (double)a.action[(size_t)env * ND + lane];
+                t = (real)(P.joint_act ? act : agent_to_env(lane, act));
+            } else if (a.mode == MODE_DEBUG) t = a.targets[(size_t)env * ND + lane];
+        }
+        s.tgt[lane] = t;
+    }
+    WSYNC();
+
+    int rc = 0, lc = 0, iters = 0;
+    for (int sub = 0; sub < a.nsub; sub++)
+        substep<FAST>(s, P, lane, mass_scale, mu_lat, rc, lc, iters, (sub == a.nsub - 1) ? dump : nullptr);
+
+    if (a.mode == MODE_DEBUG) {
+        a.state[(size_t)env * REC + lane] = s.st[lane];
+        if (lane == 0) { int *ax = a.aux + (size_t)env * AUXN; ax[4] = rc; ax[5] = lc; ax[6] = iters; }
+        return;
+    }
+
+    // ================= env level: compute_observation / compute_done / compute_reward =================
+    kinematics(s, P, lane, false);            // link frames at the post-step configuration (getLinkState)
+    real quat[4] = {s.st[3], s.st[4], s.st[5], s.st[6]}, rpy[3];
+    euler_from_quat(quat, rpy);
+    const real torso_z = s.st[2], torso_y = s.st[1], torso_vx = s.st[10];
+    // observation (plen_env.py:807-822)
+    real ob = 0;
+    if (lane < ND) ob = s.st[13 + lane];
+    else if (lane == 18) ob = torso_z;
+    else if (lane == 19) ob = torso_vx;
+    else if (lane == 20) ob = rpy[0];
+    else if (lane == 21) ob = rpy[1];
+    else if (lane == 22) ob = rpy[2];
+    else if (lane == 23) ob = torso_y;
+    else if (lane == 24) ob = (real)rc;
+    else if (lane == 25) ob = (real)lc;
+
+    // gait bookkeeping (plen_env.py:825-866), O(1) form: previous angles + running sums
+    const int GJ[6] = {2, 8, 3, 9, 4, 10};
+    real cur[6], diffs[6], last[6], sums[9];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { cur[i] = s.st[13 + GJ[i]]; last[i] = s.st[49 + i]; }
+#pragma unroll
+    for (int i = 0; i < 9; i++) sums[i] = s.st[55 + i];
+    const bool first_pass = nhist == 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) diffs[i] = first_pass ? (real)0 : last[i] - cur[i];
+#pragma unroll
+    for (int pr = 0; pr < 3; pr++) {
+        const real l = cur[2 * pr], r = cur[2 * pr + 1];
+        sums[3 * pr] += l * r; sums[3 * pr + 1] += l * l; sums[3 * pr + 2] += r * r;
+    }
+    nhist += 1;
+
+    real reward = 0;
+    int done_flag = 0;
+    if (a.mode == MODE_STEP) {
+        // compute_done (plen_env.py:1072-1093): one-sided on roll/pitch/y
+        const real PI3 = (real)(3.14159265358979323846 / 3.0);
+        const bool dead = (rpy[0] > PI3) || (rpy[1] > PI3) || (torso_z < (real)0.08) || (torso_y > (real)1);
+        // compute_reward (plen_env.py:873-1070)
+        if (torso_vx < 0) reward -= exp_(torso_vx * (real)3); else reward += (torso_vx * (real)3) * (torso_vx * (real)3);
+        { const real h = abs_((real)0.160178937611 - torso_z) * (real)40; reward -= h * h; }
+        reward -= torso_y * torso_y;
+        reward -= rpy[0] * rpy[0];
+        reward -= rpy[1] * rpy[1] * (real)0.5;
+        reward -= rpy[2] * rpy[2];
+        real jar = 0, jap = 0;
+        if (gait_cnt >= 80 && rc == 1) {
+            nhist = 0; gait_cnt = 0; ds_cnt = 0;
+#pragma unroll
+            for (int i = 0; i < 9; i++) sums[i] = 0;
+        } else if (gait_cnt >= 120) {
+            reward -= 2;
+        } else if (gait_cnt > 0) {
+#pragma unroll
+            for (int pr = 0; pr < 3; pr++) jar += sums[3 * pr] / (sqrt_(sums[3 * pr + 1]) * sqrt_(sums[3 * pr + 2]));
+            jar *= (real)(1.0 / 3.0);
+            if (!first_pass) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) jap -= (real)1 / exp_(abs_(diffs[i]));
+                jap *= (real)(0.5 * (1.0 / 3.0));
+            }
+        }
+        reward += jar; reward += jap;
+        if (lc == 1) {
+            const real x = ((real)gait_cnt * (real)10 / (real)80) - (real)5;
+            reward += (real)0.5 * (1 - tanh_(x * x));
+        }
+        if (gait_cnt < 40) {
+            if (rc == 1 && lc == 0) reward += (real)0.1; else if (rc == 0) reward -= (real)0.1;
+        } else if (gait_cnt < 80) {
+            if (lc == 1 && rc == 0) reward += (real)0.1; else if (lc == 0) reward -= (real)0.1;
+        }
+        if (rc == 1 && lc == 1) { ds_cnt += 1; if (ds_cnt >= 16) reward -= 2; }
+        // flat-foot bonus (plen_env.py:1011-1038): roll/pitch of the foot link frames
+        {
+            const real *Rl = s.RO[GEN_LFOOT_BODY], *Rr = s.RO[GEN_RFOOT_BODY];
+            const real lroll = atan2_(Rl[7], Rl[8]), lpitch = asin_(min_(max_(-Rl[6], (real)-1), (real)1));
+            const real rroll = atan2_(Rr[7], Rr[8]), rpitch = asin_(min_(max_(-Rr[6], (real)-1), (real)1));
+            if (lc == 1 && abs_(lroll) <= (real)0.1 && abs_(lpitch) <= (real)0.1) reward += (real)0.1;
+            if (rc == 1 && abs_(rroll) <= (real)0.1 && abs_(rpitch) <= (real)0.1) reward += (real)0.1;
+        }
+        if (dead) reward -= 100;
+        ep_step += 1; gait_cnt += 1;
+        const bool trunc = ep_step >= P.max_episode_steps;
+        done_flag = (dead ? PLENVEC_DONE_TERMINAL : 0) | (trunc ? PLENVEC_DONE_TIMELIMIT : 0);
+        if (lane < PLENVEC_OBS) a.next_obs[(size_t)env * PLENVEC_OBS + lane] = ob;
+        if (lane == 0) { a.reward[env] = reward; a.done[env] = (uint8_t)done_flag; }
+    } else {
+        // reset(): the observation is taken, then the gait bookkeeping is cleared (plen_env.py:574-590)
+        nhist = 0; gait_cnt = 0; ds_cnt = 0; ep_step = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) sums[i] = 0;
+    }
+    WSYNC();
+    // write the gait slots back into the record
+    if (lane < 6) s.st[49 + lane] = cur[lane];
+    if (lane < 9) s.st[55 + lane] = sums[lane];
+    WSYNC();
+
+    if (a.mode == MODE_RESET_BUILD) {
+        a.state[(size_t)env * REC + lane] = s.st[lane];
+        a.reset_state[(size_t)env * REC + lane] = s.st[lane];
+        if (lane < PLENVEC_OBS) a.reset_obs[(size_t)env * PLENVEC_OBS + lane] = ob;
+        if (lane < AUXN) {
+            const int v = lane == 4 ? rc : (lane == 5 ? lc : (lane == 6 ? iters : 0));
+            a.aux[(size_t)env * AUXN + lane] = v; a.reset_aux[(size_t)env * AUXN + lane] = v;
+        }
+        return;
+    }
+    // ---- MODE_STEP: store, auto-reset when the episode ended (TimeLimit + plen_td3.py:122-133) ----
+    const bool ended = done_flag != 0 && a.auto_reset;
+    if (ended) {
+        a.state[(size_t)env * REC + lane] = a.reset_state[(size_t)env * REC + lane];
+        if (lane < AUXN) a.aux[(size_t)env * AUXN + lane] = a.reset_aux[(size_t)env * AUXN + lane];
+        if (a.cur_obs && lane < PLENVEC_OBS) a.cur_obs[(size_t)env * PLENVEC_OBS + lane] = a.reset_obs[(size_t)env * PLENVEC_OBS + lane];
+    } else {
+        a.state[(size_t)env * REC + lane] = s.st[lane];
+        if (lane < AUXN) {
+            const int v = lane == 0 ? gait_cnt : lane == 1 ? ds_cnt : lane == 2 ? ep_step : lane == 3 ? nhist : lane == 4 ? rc : lane == 5 ? lc : lane == 6 ? iters : 0;
+            a.aux[(size_t)env * AUXN + lane] = v;
+        }
+        if (a.cur_obs && lane < PLENVEC_OBS) a.cur_obs[(size_t)env * PLENVEC_OBS + lane] = ob;
+    }
+}
+
+// masked copy of the reset cache into the live state (plenvec_reset)
+template <typename real>
+__global__ void plen_reset_copy_kernel(int n, const uint8_t *mask, const real *rs, const int *ra, const real *ro, real *st, int *ax, real *obs) {
+    const int env = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    const int lane = threadIdx.x & 63;
+    if (env >= n) return;
+    if (mask && !mask[env]) return;
+    st[(size_t)env * REC + lane] = rs[(size_t)env * REC + lane];
+    if (lane < AUXN) ax[(size_t)env * AUXN + lane] = ra[(size_t)env * AUXN + lane];
+    if (obs && lane < PLENVEC_OBS) obs[(size_t)env * PLENVEC_OBS + lane] = ro[(size_t)env * PLENVEC_OBS + lane];
+}
+
+// [N][49] <-> record conversion for the state injection API
+template <typename real>
+__global__ void plen_state_io_kernel(int n, real *rec, int *ax, real *ext, int set) {
+    const int env = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    const int lane = threadIdx.x & 63;
+    if (env >= n) return;
+    if (set) {
+        rec[(size_t)env * REC + lane] = lane < PLENVEC_STATE ? ext[(size_t)env * PLENVEC_STATE + lane] : (real)0;
+        if (lane < AUXN) ax[(size_t)env * AUXN + lane] = 0;
+    } else if (lane < PLENVEC_STATE) ext[(size_t)env * PLENVEC_STATE + lane] = rec[(size_t)env * REC + lane];
+}
+
+// ================================================================================================
+// host side: C ABI
+// ================================================================================================
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(PLENVEC_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct plenvec {
+    PlenCfg cfg;
+    int n, device, dtype;
+    size_t rsz;
+    void *P, *state, *reset_state, *reset_obs, *mass_scale, *mu_lat;
+    int *aux, *reset_aux;
+    bool reset_dirty, use_ms, use_mu, fast;
+    hipEvent_t ev0, ev1;
+    int64_t launches, launches_mark;
+};
+
+template <typename real>
+static void fill_params(const PlenCfg &c, DevParams<real> &p) {
+    memset(&p, 0, sizeof p);
+    p.dt = (real)c.dt; p.inv_dt = (real)(1.0 / c.dt); p.gz = (real)c.gravity_z; p.erp = (real)c.erp; p.erp2 = (real)c.erp2;
+    p.slop = (real)c.linear_slop; p.res_thr = (real)c.residual_threshold; p.rest_thr = (real)c.restitution_velocity_threshold;
+    p.vmax = (real)c.max_coordinate_velocity; p.mu_lat = (real)c.lateral_friction; p.mu_spin = (real)c.spinning_friction;
+    p.mu_roll = (real)c.rolling_friction; p.restitution = (real)c.restitution; p.lin_damp = (real)c.linear_damping;
+    p.kp = (real)c.motor_kp; p.kd = (real)c.motor_kd; p.max_imp = (real)(c.motor_max_force * c.dt); p.spawn_z = (real)c.spawn_z;
+    p.margin = (real)GEN_MARGIN; p.brk[0] = (real)GEN_RFOOT_BREAK; p.brk[1] = (real)GEN_LFOOT_BREAK;
+    for (int k = 0; k < 4; k++) for (int i = 0; i < 3; i++) { p.pts[0][k][i] = (real)GEN_RFOOT_POINTS[k][i]; p.pts[1][k][i] = (real)GEN_LFOOT_POINTS[k][i]; }
+    for (int b = 0; b < NB; b++) {
+        for (int i = 0; i < 9; i++) p.mdl[b][i] = (real)GEN_JR[b][i];
+        for (int i = 0; i < 3; i++) { p.mdl[b][9 + i] = (real)GEN_JT[b][i]; p.mdl[b][12 + i] = (real)GEN_AXIS[b][i]; p.mdl[b][15 + i] = (real)GEN_COM[b][i]; }
+        for (int i = 0; i < 6; i++) p.mdl[b][18 + i] = (real)GEN_INERTIA[b][i];
+        p.mdl[b][24] = (real)GEN_MASS[b];
+    }
+    p.num_iterations = c.num_iterations; p.max_episode_steps = c.max_episode_steps; p.joint_act = c.joint_act;
+}
+
+template <typename real>
+static int launch_env(plenvec *h, int mode, int nsub, const float *action, const void *targets, void *next_obs, void *reward,
+                      uint8_t *done, void *cur_obs, void *dump, hipStream_t st) {
+    StepArgs<real> a;
+    a.P = (const DevParams<real> *)h->P;
+    a.state = (real *)h->state; a.aux = h->aux;
+    a.reset_state = (real *)h->reset_state; a.reset_aux = h->reset_aux; a.reset_obs = (real *)h->reset_obs;
+    a.action = action; a.targets = (const real *)targets;
+    a.next_obs = (real *)next_obs; a.reward = (real *)reward; a.done = done; a.cur_obs = (real *)cur_obs;
+    a.mass_scale = h->use_ms ? (const real *)h->mass_scale : nullptr;
+    a.mu_lat = h->use_mu ? (const real *)h->mu_lat : nullptr;
+    a.dump = (real *)dump;
+    a.n = h->n; a.mode = mode; a.nsub = nsub; a.auto_reset = h->cfg.auto_reset;
+    if (h->fast) hipLaunchKernelGGL((plen_env_kernel<real, true>), dim3(h->n), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((plen_env_kernel<real, false>), dim3(h->n), dim3(64), 0, st, a);
+    HIPCHK(hipGetLastError());
+    h->launches++;
+    return PLENVEC_OK;
+}
+
+static int launch_env_any(plenvec *h, int mode, int nsub, const float *action, const void *targets, void *next_obs, void *reward,
+                          uint8_t *done, void *cur_obs, void *dump, hipStream_t st) {
+    return h->dtype == PLENVEC_DTYPE_F64 ? launch_env<double>(h, mode, nsub, action, targets, next_obs, reward, done, cur_obs, dump, st)
+                                         : launch_env<float>(h, mode, nsub, action, targets, next_obs, reward, done, cur_obs, dump, st);
+}
+
+static int rebuild_reset_cache(plenvec *h, hipStream_t st) {
+    int rcode = launch_env_any(h, MODE_RESET_BUILD, h->cfg.reset_substeps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, st);
+    if (rcode == PLENVEC_OK) h->reset_dirty = false;
+    return rcode;
+}
+
+static int state_io(plenvec *h, void *ext, int set, hipStream_t st) {
+    if (!ext) return fail(PLENVEC_E_INVAL, "state must be a device pointer");
+    const int per = 4, blocks = (h->n + per - 1) / per;
+    if (h->dtype == PLENVEC_DTYPE_F64) hipLaunchKernelGGL(plen_state_io_kernel<double>, dim3(blocks), dim3(64 * per), 0, st, h->n, (double *)h->state, h->aux, (double *)ext, set);
+    else hipLaunchKernelGGL(plen_state_io_kernel<float>, dim3(blocks), dim3(64 * per), 0, st, h->n, (float *)h->state, h->aux, (float *)ext, set);
+    HIPCHK(hipGetLastError());
+    return PLENVEC_OK;
+}
+extern "C" {
+
+const char *plenvec_last_error(void) { return g_err.c_str(); }
+const char *plenvec_version(void) { return "plenvec 0.1 (gfx950, wave-per-env)"; }
+
+int plenvec_default_cfg(PlenCfg *c, int joint_act) {
+    if (!c) return fail(PLENVEC_E_INVAL, "cfg is NULL");
+    memset(c, 0, sizeof *c);
+    c->dtype = PLENVEC_DTYPE_F32; c->joint_act = joint_act ? 1 : 0; c->max_episode_steps = 500;
+    c->substeps = 4; c->reset_substeps = 8; c->num_iterations = 50; c->auto_reset = 1;
+    c->dt = 1.0 / 240.0; c->gravity_z = -9.81; c->erp = 0.2; c->erp2 = 0.08; c->linear_slop = 0.00001;
+    c->residual_threshold = 1e-7; c->restitution_velocity_threshold = 0.2; c->max_coordinate_velocity = 100.0;
+    c->lateral_friction = 0.8 * 0.8; c->spinning_friction = 0.1 * 0.8; c->rolling_friction = (joint_act ? 0.01 : 0.1) * 0.8;
+    c->restitution = 0.5 * 0.5; c->linear_damping = joint_act ? 0.1 : 0.0;
+    c->motor_kp = 0.1; c->motor_kd = 1.0; c->motor_max_force = 0.15; c->spawn_z = 0.158;
+    return PLENVEC_OK;
+}
+
+int plenvec_create(const PlenCfg *cfg, int num_envs, int device, plenvec_t **out) {
+    if (!out) return fail(PLENVEC_E_INVAL, "out is NULL");
+    *out = nullptr;
+    if (num_envs <= 0) return fail(PLENVEC_E_INVAL, "num_envs must be positive");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(PLENVEC_E_NODEV, "no HIP device visible: libplenvec has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(PLENVEC_E_INVAL, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    plenvec *h = new plenvec();
+    if (cfg) h->cfg = *cfg; else plenvec_default_cfg(&h->cfg, 0);
+    if (h->cfg.dtype != PLENVEC_DTYPE_F32 && h->cfg.dtype != PLENVEC_DTYPE_F64) { delete h; return fail(PLENVEC_E_INVAL, "bad dtype"); }
+    if (h->cfg.substeps <= 0 || h->cfg.reset_substeps < 0 || h->cfg.num_iterations <= 0) { delete h; return fail(PLENVEC_E_INVAL, "bad substeps/iterations"); }
+    h->n = num_envs; h->device = device; h->dtype = h->cfg.dtype;
+    h->rsz = h->dtype == PLENVEC_DTYPE_F64 ? 8 : 4;
+    const size_t N = (size_t)num_envs;
+    HIPCHK(hipMalloc(&h->state, N * REC * h->rsz));
+    HIPCHK(hipMalloc(&h->reset_state, N * REC * h->rsz));
+    HIPCHK(hipMalloc(&h->reset_obs, N * PLENVEC_OBS * h->rsz));
+    HIPCHK(hipMalloc(&h->mass_scale, N * h->rsz));
+    HIPCHK(hipMalloc(&h->mu_lat, N * h->rsz));
+    HIPCHK(hipMalloc((void **)&h->aux, N * AUXN * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&h->reset_aux, N * AUXN * sizeof(int)));
+    if (h->dtype == PLENVEC_DTYPE_F64) {
+        DevParams<double> p; fill_params(h->cfg, p);
+        HIPCHK(hipMalloc(&h->P, sizeof p)); HIPCHK(hipMemcpy(h->P, &p, sizeof p, hipMemcpyHostToDevice));
+    } else {
+        DevParams<float> p; fill_params(h->cfg, p);
+        HIPCHK(hipMalloc(&h->P, sizeof p)); HIPCHK(hipMemcpy(h->P, &p, sizeof p, hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
+    h->use_ms = h->use_mu = false; h->launches = 0; h->launches_mark = 0;
+    h->fast = getenv("PLENVEC_NO_ASM") == nullptr;
+    int rcode = rebuild_reset_cache(h, 0);
+    if (rcode != PLENVEC_OK) { plenvec_destroy(h); return rcode; }
+    HIPCHK(hipStreamSynchronize(0));
+    *out = h;
+    return PLENVEC_OK;
+}
+
+int plenvec_destroy(plenvec_t *h) {
+    if (!h) return PLENVEC_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    void *bufs[] = {h->state, h->reset_state, h->reset_obs, h->mass_scale, h->mu_lat, h->aux, h->reset_aux, h->P};
+    for (void *b : bufs) if (b) (void)hipFree(b);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    delete h;
+    return PLENVEC_OK;
+}
+
+int plenvec_num_envs(const plenvec_t *h) { return h ? h->n : PLENVEC_E_INVAL; }
+int plenvec_dtype(const plenvec_t *h) { return h ? h->dtype : PLENVEC_E_INVAL; }
+
+int plenvec_reset(plenvec_t *h, const uint8_t *mask, void *obs, void *stream) {
+    if (!h) return fail(PLENVEC_E_INVAL, "handle is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    if (h->reset_dirty) {
+        // parameters changed: the settle has to be re-simulated; this also puts EVERY env in its reset state
+        int rcode = rebuild_reset_cache(h, st);
+        if (rcode != PLENVEC_OK) return rcode;
+    }
+    const int per = 4, blocks = (h->n + per - 1) / per;
+    if (h->dtype == PLENVEC_DTYPE_F64)
+        hipLaunchKernelGGL(plen_reset_copy_kernel<double>, dim3(blocks), dim3(64 * per), 0, st, h->n, mask, (const double *)h->reset_state, h->reset_aux, (const double *)h->reset_obs, (double *)h->state, h->aux, (double *)obs);
+    else
+        hipLaunchKernelGGL(plen_reset_copy_kernel<float>, dim3(blocks), dim3(64 * per), 0, st, h->n, mask, (const float *)h->reset_state, h->reset_aux, (const float *)h->reset_obs, (float *)h->state, h->aux, (float *)obs);
+    HIPCHK(hipGetLastError());
+    return PLENVEC_OK;
+}
+
+int plenvec_step(plenvec_t *h, const float *action, void *next_obs, void *reward, uint8_t *done, void *cur_obs, void *stream) {
+    if (!h) return fail(PLENVEC_E_INVAL, "handle is NULL");
+    if (!action || !next_obs || !reward || !done) return fail(PLENVEC_E_INVAL, "action/next_obs/reward/done must be device pointers");
+    return launch_env_any(h, MODE_STEP, h->cfg.substeps, action, nullptr, next_obs, reward, done, cur_obs, nullptr, (hipStream_t)stream);
+}
+
+int plenvec_debug_substeps(plenvec_t *h, const void *targets, int nsub, void *dump, void *stream) {
+    if (!h) return fail(PLENVEC_E_INVAL, "handle is NULL");
+    if (!targets || nsub <= 0) return fail(PLENVEC_E_INVAL, "targets must be a device pointer and nsub positive");
+    return launch_env_any(h, MODE_DEBUG, nsub, nullptr, targets, nullptr, nullptr, nullptr, nullptr, dump, (hipStream_t)stream);
+}
+
+int plenvec_get_state(plenvec_t *h, void *state, void *stream) { if (!h) return fail(PLENVEC_E_INVAL, "handle is NULL"); return state_io(h, state, 0, (hipStream_t)stream); }
+int plenvec_set_state(plenvec_t *h, const void *state, void *stream) { if (!h) return fail(PLENVEC_E_INVAL, "handle is NULL"); return state_io(h, (void *)state, 1, (hipStream_t)stream); }
+
+int plenvec_get_aux(plenvec_t *h, int32_t *aux, void *stream) {
+    if (!h || !aux) return fail(PLENVEC_E_INVAL, "handle/aux is NULL");
+    HIPCHK(hipMemcpyAsync(aux, h->aux, (size_t)h->n * AUXN * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return PLENVEC_OK;
+}
+
+int plenvec_set_params(plenvec_t *h, const void *mass_scale, const void *lateral_friction, void *stream) {
+    if (!h) return fail(PLENVEC_E_INVAL, "handle is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    if (mass_scale) { HIPCHK(hipMemcpyAsync(h->mass_scale, mass_scale, (size_t)h->n * h->rsz, hipMemcpyDeviceToDevice, st)); h->use_ms = true; }
+    if (lateral_friction) { HIPCHK(hipMemcpyAsync(h->mu_lat, lateral_friction, (size_t)h->n * h->rsz, hipMemcpyDeviceToDevice, st)); h->use_mu = true; }
+    h->reset_dirty = true;
+    return PLENVEC_OK;
+}
+
+int plenvec_timing_begin(plenvec_t *h, void *stream) {
+    if (!h) return fail(PLENVEC_E_INVAL, "handle is NULL");
+    h->launches_mark = h->launches;
+    HIPCHK(hipEventRecord(h->ev0, (hipStream_t)stream));
+    return PLENVEC_OK;
+}
+int plenvec_timing_end(plenvec_t *h, void *stream, double *elapsed_ms, int64_t *launches) {
+    if (!h) return fail(PLENVEC_E_INVAL, "handle is NULL");
+    HIPCHK(hipEventRecord(h->ev1, (hipStream_t)stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    if (elapsed_ms) *elapsed_ms = ms;
+    if (launches) *launches = h->launches - h->launches_mark;
+    return PLENVEC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,121 @@
+"""PlenVecEnv: N PLEN walking environments stepped by one HIP launch on one MI355X.
+
+Torch is plumbing here (device memory + the current stream); the step itself is libplenvec.so.
+The single-env, reference-shaped facade is plen_ml_walk_amd.plen_env.PlenWalkEnv."""
+import ctypes as C
+import torch
+from . import _lib as L
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class PlenVecEnv(object):
+    """Vector form of PlenWalkEnv (plen_bullet/src/plen_bullet/plen_env.py:22): `reset()` and
+    `step(action)` act on all `num_envs` environments; tensors stay on the GPU.
+
+    step(action[N,18] float32) -> (next_obs[N,26], reward[N], done[N] bool, info)
+      next_obs is the post-step observation (the terminal one if the episode ended);
+      info["obs"] is the observation to act on next (reset observation for envs that ended, because
+      the env auto-resets like the reference driver does, plen_td3.py:122-133);
+      info["terminal"] marks compute_done() terminations with the time limit masked out, i.e. the
+      `done_bool` the reference stores in the replay buffer (plen_td3.py:109-110);
+      info["time_limit"] marks gym TimeLimit truncations (plen_env.py:15-19)."""
+
+    def __init__(self, num_envs, device=None, dtype=torch.float32, joint_act=False, auto_reset=True, cfg_overrides=None):
+        if not torch.cuda.is_available():
+            raise L.PlenvecError("PlenVecEnv needs a ROCm GPU (MI355X); there is no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.type != "cuda":
+            raise L.PlenvecError("PlenVecEnv device must be a cuda (HIP) device")
+        self.lib = L.load()
+        self.num_envs = int(num_envs)
+        self.dtype = dtype
+        cfg = L.default_cfg(joint_act)
+        cfg.dtype = L.DTYPE_F64 if dtype == torch.float64 else L.DTYPE_F32
+        cfg.auto_reset = int(bool(auto_reset))
+        for k, v in (cfg_overrides or {}).items():
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        self.max_episode_steps = cfg.max_episode_steps
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        h = C.c_void_p()
+        with torch.cuda.device(idx):
+            L.check(self.lib.plenvec_create(C.byref(cfg), self.num_envs, idx, C.byref(h)))
+        self.h = h
+        n, dev = self.num_envs, self.device
+        self._next_obs = torch.empty(n, L.OBS, dtype=dtype, device=dev)
+        self._cur_obs = torch.empty(n, L.OBS, dtype=dtype, device=dev)
+        self._reward = torch.empty(n, dtype=dtype, device=dev)
+        self._done = torch.empty(n, dtype=torch.uint8, device=dev)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.plenvec_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- gym-like surface ---------------------------------------------------------------
+    def reset(self, mask=None):
+        m = None
+        if mask is not None:
+            m = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        L.check(self.lib.plenvec_reset(self.h, _ptr(m), _ptr(self._cur_obs), self._stream()))
+        return self._cur_obs
+
+    def step(self, action, out=None):
+        a = action
+        if a.dtype != torch.float32 or not a.is_contiguous() or a.device != self.device:
+            a = a.to(device=self.device, dtype=torch.float32).contiguous()
+        assert a.shape == (self.num_envs, L.ACT)
+        L.check(self.lib.plenvec_step(self.h, _ptr(a), _ptr(self._next_obs), _ptr(self._reward), _ptr(self._done),
+                                      _ptr(self._cur_obs), self._stream()))
+        flags = self._done
+        info = {"obs": self._cur_obs, "terminal": (flags & L.DONE_TERMINAL).bool() & ~(flags & L.DONE_TIMELIMIT).bool(),
+                "time_limit": (flags & L.DONE_TIMELIMIT).bool(), "flags": flags}
+        return self._next_obs, self._reward, flags != 0, info
+
+    # ---- state access (parity tests) ------------------------------------------------------
+    def get_state(self):
+        s = torch.empty(self.num_envs, L.STATE, dtype=self.dtype, device=self.device)
+        L.check(self.lib.plenvec_get_state(self.h, _ptr(s), self._stream()))
+        return s
+
+    def set_state(self, state):
+        s = state.to(device=self.device, dtype=self.dtype).contiguous()
+        assert s.shape == (self.num_envs, L.STATE)
+        L.check(self.lib.plenvec_set_state(self.h, _ptr(s), self._stream()))
+
+    def get_aux(self):
+        a = torch.empty(self.num_envs, 8, dtype=torch.int32, device=self.device)
+        L.check(self.lib.plenvec_get_aux(self.h, _ptr(a), self._stream()))
+        return a
+
+    def debug_substeps(self, targets, nsub=1, dump=False):
+        t = targets.to(device=self.device, dtype=self.dtype).contiguous()
+        assert t.shape == (self.num_envs, L.ACT)
+        d = torch.zeros(self.num_envs, L.DUMP, dtype=self.dtype, device=self.device) if dump else None
+        L.check(self.lib.plenvec_debug_substeps(self.h, _ptr(t), int(nsub), _ptr(d), self._stream()))
+        return d
+
+    def set_params(self, mass_scale=None, lateral_friction=None):
+        ms = mass_scale.to(device=self.device, dtype=self.dtype).contiguous() if mass_scale is not None else None
+        mu = lateral_friction.to(device=self.device, dtype=self.dtype).contiguous() if lateral_friction is not None else None
+        L.check(self.lib.plenvec_set_params(self.h, _ptr(ms), _ptr(mu), self._stream()))
+
+    def timing_begin(self):
+        L.check(self.lib.plenvec_timing_begin(self.h, self._stream()))
+
+    def timing_end(self):
+        ms, n = C.c_double(0), C.c_int64(0)
+        L.check(self.lib.plenvec_timing_end(self.h, self._stream(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value

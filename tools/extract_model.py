@@ -383,6 +383,9 @@ def write_merged_header(m, path):
             f.write("static const double GEN_%s_POINTS[4][3] = {\n%s};\n" % (tag, carr([x for v in ft["points"] for x in v], nested=3)))
             f.write("static const double GEN_%s_BREAK = %r;\n" % (tag, ft["break_threshold"]))
         f.write("static const double GEN_MARGIN = %r;\n" % m["margin"])
+        lows = set(l["lower"] for l in m["links"] if l["jtype"] == 1); ups = set(l["upper"] for l in m["links"] if l["jtype"] == 1)
+        assert len(lows) == 1 and len(ups) == 1, "the HIP path assumes one common joint limit"
+        f.write("#define GEN_LOWER_LIMIT %r\n#define GEN_UPPER_LIMIT %r\n" % (lows.pop(), ups.pop()))
         f.write("static const int GEN_NC_KIND[36] = {%s};\n" % ", ".join("0" if o["kind"] == "limit" else "1" for o in m["noncontact_order"]))
         f.write("static const int GEN_NC_DOF[36] = {%s};\n" % ", ".join(str(o["dof"]) for o in m["noncontact_order"]))
         f.write("#endif\n")
