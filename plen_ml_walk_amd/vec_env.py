@@ -11,11 +11,30 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+class StepInfo(dict):
+    """Lazy view of the step flags (keeps tiny elementwise kernels out of the rollout loop):
+    "obs" observation to act on next, "flags" raw PLENVEC_DONE_* bits, "terminal" / "time_limit" masks."""
+
+    def __init__(self, flags, cur_obs):
+        dict.__init__(self, obs=cur_obs, flags=flags)
+
+    def __missing__(self, key):
+        f = dict.__getitem__(self, "flags")
+        if key == "time_limit":
+            v = (f & L.DONE_TIMELIMIT) != 0
+        elif key == "terminal":          # compute_done() fired and the time limit did not: plen_td3.py:109-110 done_bool
+            v = ((f & L.DONE_TERMINAL) != 0) & ((f & L.DONE_TIMELIMIT) == 0)
+        else:
+            raise KeyError(key)
+        self[key] = v
+        return v
+
+
 class PlenVecEnv(object):
     """Vector form of PlenWalkEnv (plen_bullet/src/plen_bullet/plen_env.py:22): `reset()` and
     `step(action)` act on all `num_envs` environments; tensors stay on the GPU.
 
-    step(action[N,18] float32) -> (next_obs[N,26], reward[N], done[N] bool, info)
+    step(action[N,18] float32) -> (next_obs[N,26], reward[N], done[N] uint8 (nonzero = episode ended), info)
       next_obs is the post-step observation (the terminal one if the episode ended);
       info["obs"] is the observation to act on next (reset observation for envs that ended, because
       the env auto-resets like the reference driver does, plen_td3.py:122-133);
@@ -80,9 +99,7 @@ class PlenVecEnv(object):
         L.check(self.lib.plenvec_step(self.h, _ptr(a), _ptr(self._next_obs), _ptr(self._reward), _ptr(self._done),
                                       _ptr(self._cur_obs), self._stream()))
         flags = self._done
-        info = {"obs": self._cur_obs, "terminal": (flags & L.DONE_TERMINAL).bool() & ~(flags & L.DONE_TIMELIMIT).bool(),
-                "time_limit": (flags & L.DONE_TIMELIMIT).bool(), "flags": flags}
-        return self._next_obs, self._reward, flags != 0, info
+        return self._next_obs, self._reward, flags, StepInfo(flags, self._cur_obs)
 
     # ---- state access (parity tests) ------------------------------------------------------
     def get_state(self):
