@@ -31,6 +31,9 @@ def _lib(dtype="f64"):
         lib.oracle_destroy.argtypes = [C.c_void_p]
         lib.oracle_set_params.argtypes = [C.c_void_p, C.c_double, C.c_double]
         lib.oracle_set_world.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        lib.oracle_set_friction.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+        lib.oracle_last_residual.restype = C.c_double
+        lib.oracle_last_residual.argtypes = [C.c_void_p]
         lib.oracle_get_state.argtypes = [C.c_void_p, dp]
         lib.oracle_set_state.argtypes = [C.c_void_p, dp]
         lib.oracle_get_aux.argtypes = [C.c_void_p, ip]
@@ -76,6 +79,9 @@ class OracleEnv(object):
 
     def set_world(self, num_iterations=0, residual_threshold=-1.0):
         self.lib.oracle_set_world(self.h, int(num_iterations), float(residual_threshold))
+
+    def set_friction(self, lateral=-1.0, spinning=-1.0, rolling=-1.0):
+        self.lib.oracle_set_friction(self.h, float(lateral), float(spinning), float(rolling))
 
     def reset(self):
         obs = np.zeros(26)

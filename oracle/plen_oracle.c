@@ -897,3 +897,11 @@ API double oracle_script_reward(Oracle *o, double z, double vx, double roll, dou
     *done_out = compute_done(o);
     return reward_core(o, lroll, lpitch, rroll, rpitch);
 }
+
+/* contact-parameter overrides for the well-conditioned parity configurations used by the tests
+ * (negative = keep).  Coefficients are the COMBINED ones the solver uses. */
+API void oracle_set_friction(Oracle *o, double lateral, double spinning, double rolling) {
+    if (lateral >= 0) o->w.lateral_friction = (real)lateral;
+    if (spinning >= 0) o->w.spinning_friction = (real)spinning;
+    if (rolling >= 0) o->w.rolling_friction = (real)rolling;
+}

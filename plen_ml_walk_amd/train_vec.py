@@ -1,0 +1,134 @@
+#!/usr/bin/env python
+"""Vectorised TD3 training: N PLEN envs per GPU stepped by one HIP launch, actor/critic/replay on the
+same device, one process per GPU, gradients all-reduced over RCCL (BASELINE.json configs[2], [3]).
+
+What the reference's loop (plen_bullet/src/plen_td3.py:83-157) becomes with N envs per step:
+  * warm-up: uniform random actions until the rank-local buffer holds >= start_timesteps transitions
+    (reference: 1e4 single steps; at N=4096 that is 3 vector steps);
+  * acting: actor(state) + N(0, expl_noise) clipped to [-1, 1]  (plen_td3.py:101-104), batched on device;
+  * storing: (state, action, next_state, reward, done_bool) with done_bool = terminal AND NOT time-limit
+    (plen_td3.py:109-110); next_state is the terminal observation, the next `state` is the reset
+    observation of envs that ended (auto-reset inside the step kernel);
+  * learning: `updates_per_step` TD3Agent.train() calls of `batch_size` per vector step.  The reference
+    does 1 update of 100 per single env step (update-to-data 1 : 1); that ratio cannot be kept at
+    millions of env-steps/s, so the default here is 1 update of batch 4096 per vector step of 4096 envs
+    (same samples-per-env-step, 1/4096 of the optimiser steps) -- state the choice when reporting.
+  * ranks: envs and replay are rank-local; the flat critic / actor gradient buckets are averaged over
+    ranks every update (TD3Agent), parameters start from rank 0's initialisation.
+"""
+import argparse
+import json
+import os
+import time
+
+import torch
+
+
+def setup_distributed():
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            dist.init_process_group(backend, device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+        else:
+            dist.init_process_group(backend)
+    return int(os.environ.get("RANK", "0")), world
+
+
+class VecTD3Trainer(object):
+    def __init__(self, env, agent, replay, start_timesteps=10000, expl_noise=0.1, batch_size=4096, updates_per_step=1, seed=0):
+        self.env, self.agent, self.replay = env, agent, replay
+        self.start_timesteps = start_timesteps
+        self.expl_noise = expl_noise
+        self.batch_size = batch_size
+        self.updates_per_step = updates_per_step
+        dev = agent.device
+        self.gen = torch.Generator(device=dev)
+        self.gen.manual_seed(seed)
+        self.state = env.reset().to(torch.float32).clone()
+        self.env_steps = 0
+        self.grad_steps = 0
+        n = self.state.shape[0]
+        self.ep_return = torch.zeros(n, device=dev)
+        self.finished_returns = []
+
+    def step(self):
+        env, agent = self.env, self.agent
+        n = self.state.shape[0]
+        if self.replay.size < self.start_timesteps:
+            action = torch.rand(n, 18, device=agent.device, generator=self.gen) * 2 - 1
+        else:
+            action = agent.select_action_batch(self.state)
+            action = (action + torch.randn(action.shape, device=agent.device, generator=self.gen) * (agent.max_action * self.expl_noise)).clamp(-agent.max_action, agent.max_action)
+        next_obs, reward, done, info = env.step(action)
+        self.replay.add_batch(self.state, action, next_obs, reward, info["terminal"].to(torch.float32))
+        self.ep_return += reward.to(torch.float32)
+        ended = done != 0
+        if len(self.finished_returns) < 64:                      # cheap running log, bounded
+            self.finished_returns.append((self.ep_return * ended).sum() / ended.sum().clamp(min=1))
+        self.ep_return = self.ep_return * (~ended)
+        self.state = info["obs"].to(torch.float32).clone()
+        self.env_steps += n
+        if self.replay.size >= self.start_timesteps:
+            for _ in range(self.updates_per_step):
+                agent.train(self.replay, self.batch_size)
+                self.grad_steps += 1
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--steps", type=int, default=200, help="vector steps to run")
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--updates-per-step", type=int, default=1)
+    ap.add_argument("--start-timesteps", type=int, default=10000)
+    ap.add_argument("--replay", type=int, default=1000000)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--save", default=None, help="checkpoint prefix (reference 4-file layout)")
+    a = ap.parse_args(argv)
+    from .vec_env import PlenVecEnv
+    from .td3 import ReplayBuffer, TD3Agent
+    import torch.distributed as dist
+    rank, world = setup_distributed()
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    torch.manual_seed(a.seed)                                     # identical init on every rank (then broadcast anyway)
+    env = PlenVecEnv(a.envs, device=dev)
+    agent = TD3Agent(26, 18, 1.0, device=dev)
+    replay = ReplayBuffer(a.replay, device=dev)
+    replay.seed(a.seed + rank)
+    tr = VecTD3Trainer(env, agent, replay, a.start_timesteps, 0.1, a.batch, a.updates_per_step, seed=1000 + rank)
+    for _ in range(a.warmup):
+        tr.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    e0, g0, t0 = tr.env_steps, tr.grad_steps, time.perf_counter()
+    for _ in range(a.steps):
+        tr.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+    if rank == 0:
+        print(json.dumps({"metric": "td3_env_steps_per_sec", "value": world * (tr.env_steps - e0) / dt, "unit": "env-steps/s",
+                          "grad_steps_per_sec": (tr.grad_steps - g0) / dt, "n_gpus": world, "envs_per_gpu": a.envs, "batch": a.batch,
+                          "updates_per_step": a.updates_per_step, "steps": a.steps, "ms_per_step": dt / a.steps * 1e3,
+                          "critic_loss": float(agent.last_critic_loss) if agent.last_critic_loss is not None else None}))
+        if a.save:
+            agent.save(a.save)
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

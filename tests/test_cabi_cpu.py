@@ -1,0 +1,62 @@
+"""The C-ABI shared object: loads on a CPU-only box, exports exactly what include/plenvec.h declares,
+refuses to run without a GPU (no CPU fallback), and its config struct matches the ctypes mirror."""
+import ctypes as C
+import os
+import re
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from plen_ml_walk_amd.build import build_extension
+    from plen_ml_walk_amd import _lib
+    build_extension()
+    return _lib.load()
+
+
+def test_header_symbols_are_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "plenvec.h")).read()
+    names = sorted(set(re.findall(r"\b(plenvec_[a-z_]+)\s*\(", hdr)))
+    assert len(names) >= 16
+    from plen_ml_walk_amd import _lib
+    assert sorted(_lib.EXPORTS) == names
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_default_cfg_matches_reference_constants(lib):
+    from plen_ml_walk_amd import _lib
+    c = _lib.default_cfg(False)
+    assert (c.max_episode_steps, c.substeps, c.reset_substeps, c.num_iterations) == (500, 4, 8, 50)       # plen_env.py:15-19,40-42,569
+    assert c.dt == 1.0 / 240.0 and c.gravity_z == -9.81 and c.motor_max_force == 0.15 and c.spawn_z == 0.158   # :41,:296,:753,:312
+    assert abs(c.lateral_friction - 0.64) < 1e-15 and abs(c.rolling_friction - 0.08) < 1e-15 and c.linear_damping == 0.0
+    j = _lib.default_cfg(True)
+    assert abs(j.rolling_friction - 0.008) < 1e-15 and j.linear_damping == 0.1 and j.joint_act == 1      # :439-442,:472-475
+    assert C.sizeof(_lib.PlenCfg) == 8 * 4 + 17 * 8
+
+
+def test_error_paths_without_gpu(lib):
+    from plen_ml_walk_amd import _lib
+    h = C.c_void_p()
+    cfg = _lib.default_cfg(False)
+    assert lib.plenvec_create(C.byref(cfg), 0, 0, C.byref(h)) == -1            # PLENVEC_E_INVAL
+    assert b"num_envs" in lib.plenvec_last_error()
+    assert lib.plenvec_step(None, None, None, None, None, None, None) == -1
+    if not torch.cuda.is_available():
+        rc = lib.plenvec_create(C.byref(cfg), 4, 0, C.byref(h))
+        assert rc == -3 and b"no CPU fallback" in lib.plenvec_last_error()      # PLENVEC_E_NODEV: fails loudly
+        from plen_ml_walk_amd.vec_env import PlenVecEnv
+        with pytest.raises(_lib.PlenvecError):
+            PlenVecEnv(4)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "plen_ml_walk_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "plen_oracle" not in txt, f

@@ -1,0 +1,56 @@
+"""The generated model tables against the facts the reference pins."""
+import json
+import os
+import numpy as np
+import np_model as nm
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+M = json.load(open(os.path.join(ROOT, "plen_ml_walk_amd/model/plen_model.json")))
+
+
+def test_link_order_reproduces_moving_joints():
+    assert M["moving_joints"] == [5, 6, 7, 9, 10, 11, 13, 14, 15, 17, 18, 19, 20, 21, 24, 26, 27, 30]    # plen_env.py:318-320
+    names = [l["joint"] for l in M["links"]]
+    want = ['rb_servo_r_hip', 'r_hip_r_thigh', 'r_thigh_r_knee', 'r_knee_r_shin', 'r_shin_r_ankle', 'r_ankle_r_foot',
+            'lb_servo_l_hip', 'l_hip_l_thigh', 'l_thigh_l_knee', 'l_knee_l_shin', 'l_shin_l_ankle', 'l_ankle_l_foot',
+            'torso_r_shoulder', 'r_shoulder_rs_servo', 're_servo_r_elbow', 'torso_l_shoulder', 'l_shoulder_ls_servo', 'le_servo_l_elbow']
+    assert [names[i] for i in M["moving_joints"]] == want                                                # plen_env.py:718-743
+    assert M["feet"][0]["link"] == 11 and M["feet"][1]["link"] == 19                                     # plen_env.py:774,784
+
+
+def test_total_mass_and_merge():
+    assert abs(M["total_mass"] - 0.495834) < 1e-9          # "0.495Kg", plen_ros plen_walk.py:350
+    assert abs(sum(b["mass"] for b in M["bodies"]) - M["total_mass"]) < 1e-12
+    assert len(M["bodies"]) == 19 and len(M["links"]) == 32
+    # composite inertias are symmetric positive definite
+    for b in M["bodies"]:
+        xx, yy, zz, xy, xz, yz = b["inertia"]
+        assert np.all(np.linalg.eigvalsh(np.array([[xx, xy, xz], [xy, yy, yz], [xz, yz, zz]])) > 0)
+
+
+def test_sole_heights_at_spawn():
+    # at spawn the right sole is 2.63 mm above, the left 2.85 mm below z=0
+    assert abs(M["feet"][0]["sole_z_at_spawn"] - 0.00263) < 2e-5
+    assert abs(M["feet"][1]["sole_z_at_spawn"] + 0.00285) < 2e-5
+    for f in M["feet"]:
+        assert f["n_hull"] == 209 and f["n_sole"] == 32 and len(f["points"]) == 4
+
+
+def test_noncontact_order_is_a_permutation():
+    ids = sorted((o["kind"], o["dof"]) for o in M["noncontact_order"])
+    assert ids == sorted([("limit", d) for d in range(18)] + [("motor", d) for d in range(18)])
+
+
+def test_merged_zero_pose_matches_raw_tree():
+    """FK of the 19 merged bodies lands every moving link frame where the raw 33-link tree puts it."""
+    from oracle.oracle import OracleEnv
+    e = OracleEnv()
+    s = np.zeros(49); s[2] = 0.158; s[6] = 1.0
+    rng = np.random.default_rng(0)
+    s[13:31] = rng.uniform(-1, 1, 18)
+    e.set_state(s)
+    R, O, C = e.link_frames()
+    Rm, Om, Cm, Am = nm.fk(s[0:3], s[3:7], s[13:31])
+    for b in range(1, 19):
+        link = M["moving_joints"][b - 1] + 1
+        assert np.allclose(R[link], Rm[b], atol=1e-14) and np.allclose(O[link], Om[b], atol=1e-14)
