@@ -181,8 +181,9 @@ def test_reference_config_one_step_distribution():
             assert np.median(ratio) <= 5 and np.quantile(ratio, 0.9) <= 60
             assert flags_bad <= 6
         r = rew.cpu().numpy().astype(np.float64)
-        ok = err <= 1e-6
-        assert np.abs(r - rref)[ok].max() <= (1e-9 if dtype == torch.float64 else 1e-3)
+        # reward = smooth function of the observation (slope up to ~20 per unit) + discrete terms
+        ok = err <= (1e-9 if dtype == torch.float64 else 1e-5)
+        assert np.abs(r - rref)[ok].max() <= (1e-6 if dtype == torch.float64 else 2e-3)
         env.close()
 
 
@@ -194,7 +195,7 @@ def test_terminal_and_time_limit_semantics():
     env = _env(n, torch.float64, cfg_overrides={"max_episode_steps": 3})
     reset_obs = env.reset().clone()
     s = env.get_state()
-    s[1, 2] = 0.05                      # env 1 starts below the 0.08 height threshold -> dead on the first step
+    s[1, 1] = 1.5                       # env 1 starts beyond the y > 1 threshold -> dead on the first step
     env.set_state(s)
     z = torch.zeros(n, 18)
     flags, rewards, cur = [], [], []
