@@ -38,6 +38,7 @@
 #define NPORT 48
 #define REC 64          // reals per env state record
 #define AUXN 8          // int32 per env aux record
+#define YTS 52          // row stride of the transposed Y buffer (48 ports + pad: conflict-free b128 row reads)
 
 // ------------------------------------------------------------------------------------------------
 // state record (real[64]):  0-2 pos | 3-6 quat xyzw | 7-9 omega | 10-12 vel | 13-30 q | 31-48 qd |
@@ -91,6 +92,17 @@ __device__ inline float exp_(float x) { return expf(x); }
 __device__ inline double exp_(double x) { return exp(x); }
 __device__ inline float tanh_(float x) { return tanhf(x); }
 __device__ inline double tanh_(double x) { return tanh(x); }
+// a product that must NOT be contracted into a following add (keeps the asm and compiler paths bit-identical)
+__device__ inline float mul_rn_(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ inline double mul_rn_(double a, double b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ inline float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ inline double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ inline float abs_(float x) { return fabsf(x); }
 __device__ inline double abs_(double x) { return fabs(x); }
 __device__ inline float max_(float a, float b) { return fmaxf(a, b); }
@@ -129,87 +141,141 @@ __host__ __device__ constexpr int port_normal(int c) { return 18 + 15 * (c / 4) 
 __device__ __forceinline__ unsigned absbits(float x) { return __builtin_bit_cast(unsigned, x) & 0x7fffffffu; }
 __device__ __forceinline__ unsigned absbits(double x) { return __builtin_bit_cast(unsigned, (float)x) & 0x7fffffffu; }
 
-// One projected-Gauss-Seidel row at compile-time port PP (the row's data lives in lane PP):
-//   u' = clamp(u + (rv - r), lo, hi);  delta = u' - u;  lane PP keeps u';  every lane: r += At[.][PP] * delta
-// res_i accumulates max |delta| (Bullet's residual) as IEEE bits on the scalar unit.
-// f32 fast path: hand-scheduled, 7 vector issues + 5 scalar; the commit to lane PP is done by
-// narrowing EXEC to that lane instead of keeping 48 lane masks alive.
+// ------------------------------------------------------------------------------------------------
+// Projected Gauss-Seidel rows in port space.  Per lane (= port) the solver keeps
+//     e   = (J_port * deltaV) - rv      rv = the row's velocity-level right-hand side (Bullet's m_rhs / jacDiagABInv)
+// and per row the velocity-scaled impulse u = lambda * diag, stored RELATIVE to its bounds where the
+// bounds are fixed (blo = lo - u, bhi = hi - u), so that one row update is
+//     d = clamp(-e, blo, bhi);   lane PP: blo -= d, bhi -= d;   every lane: e += At[.][PP] * d
+// i.e. the dependent chain through e is  med3 -> readlane -> fmac.  d is Bullet's per-row residual
+// "deltaVel"; its running max lives on the scalar unit as IEEE bits (res_i).
+// f32 fast path: hand-written, the commit to lane PP is done by narrowing EXEC to that lane
+// (s_lshl_b64 exec, 1, PP) instead of keeping 48 lane masks alive.  The compiler path does the same
+// arithmetic in the same order; tests assert the two are bit-identical.
+// ------------------------------------------------------------------------------------------------
 template <bool FAST, int PP, typename real>
-__device__ __forceinline__ void pgs_row(real &r, real &u, const real rv, const real lo, const real hi, const real acol, const int lane, unsigned &res_i) {
+__device__ __forceinline__ void pgs_row2(real &e, real &blo, real &bhi, const real acol, const int lane, unsigned &res_i) {
     if constexpr (FAST && sizeof(real) == 4) {
-        float t, d;
+        float d;
         int sd;
-        unsigned long long sv;
-        constexpr unsigned mlo = PP < 32 ? (1u << PP) : 0u, mhi = PP >= 32 ? (1u << (PP - 32)) : 0u;
         asm volatile(
-            "v_sub_f32 %[t], %[rv], %[r]\n\t"
-            "v_add_f32 %[t], %[u], %[t]\n\t"
-            "v_med3_f32 %[t], %[t], %[lo], %[hi]\n\t"
-            "v_sub_f32 %[d], %[t], %[u]\n\t"
-            "s_mov_b64 %[sv], exec\n\t"
-            "s_mov_b32 exec_lo, %[mlo]\n\t"
-            "s_mov_b32 exec_hi, %[mhi]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "s_lshl_b64 exec, 1, %[pp]\n\t"
             "v_readlane_b32 %[sd], %[d], %[pp]\n\t"
-            "v_mov_b32 %[u], %[t]\n\t"
-            "s_mov_b64 exec, %[sv]\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f32 %[r], %[sd], %[a]\n\t"
-            : [t] "=&v"(t), [d] "=&v"(d), [sd] "=&s"(sd), [sv] "=&s"(sv), [u] "+v"(u), [r] "+v"(r)
-            : [rv] "v"(rv), [lo] "v"(lo), [hi] "v"(hi), [a] "v"(acol), [mlo] "i"(mlo), [mhi] "i"(mhi), [pp] "i"(PP));
+            "v_sub_f32 %[blo], %[blo], %[d]\n\t"
+            "v_sub_f32 %[bhi], %[bhi], %[d]\n\t"
+            "s_mov_b64 exec, -1\n\t"
+            "v_fmac_f32 %[e], %[sd], %[a]\n\t"
+            : [d] "=&v"(d), [sd] "=&s"(sd), [blo] "+v"(blo), [bhi] "+v"(bhi), [e] "+v"(e)
+            : [a] "v"(acol), [pp] "i"(PP));
         res_i = max(res_i, (unsigned)sd & 0x7fffffffu);
     } else {
-        const real t = u + (rv - r);
-        const real nu = min_(max_(t, lo), hi);
-        const real d = nu - u;
-        if (lane == PP) u = nu;
+#pragma clang fp contract(off)
+        const real d = min_(max_(-e, blo), bhi);
+        if (lane == PP) { blo -= d; bhi -= d; }
         const real db = bcast(d, PP);
         res_i = max(res_i, absbits(db));
-        r += acol * db;
+        e = fma_(db, acol, e);
     }
 }
 
-// limit rows have Jacobian sgn * e_d on the joint's port (rare: only while a joint limit is violated)
+// one-sided row (contact normal: lambda >= 0, Bullet's upper limit 1e10 is never reached): blo = -u
+template <bool FAST, int PP, typename real>
+__device__ __forceinline__ void pgs_row1(real &e, real &blo, const real acol, const int lane, unsigned &res_i) {
+    if constexpr (FAST && sizeof(real) == 4) {
+        float d;
+        int sd;
+        asm volatile(
+            "v_max_f32 %[d], -%[e], %[blo]\n\t"
+            "s_lshl_b64 exec, 1, %[pp]\n\t"
+            "v_readlane_b32 %[sd], %[d], %[pp]\n\t"
+            "v_sub_f32 %[blo], %[blo], %[d]\n\t"
+            "s_mov_b64 exec, -1\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f32 %[e], %[sd], %[a]\n\t"
+            : [d] "=&v"(d), [sd] "=&s"(sd), [blo] "+v"(blo), [e] "+v"(e)
+            : [a] "v"(acol), [pp] "i"(PP));
+        res_i = max(res_i, (unsigned)sd & 0x7fffffffu);
+    } else {
+#pragma clang fp contract(off)
+        const real d = max_(-e, blo);
+        if (lane == PP) blo -= d;
+        const real db = bcast(d, PP);
+        res_i = max(res_i, absbits(db));
+        e = fma_(db, acol, e);
+    }
+}
+
+// symmetric row with a bound that changes every visit (torsional friction: |lambda| <= mu * lambda_n): explicit u
+template <bool FAST, int PP, typename real>
+__device__ __forceinline__ void pgs_rowT(real &e, real &u, const real lim, const real acol, const int lane, unsigned &res_i) {
+    if constexpr (FAST && sizeof(real) == 4) {
+        float d, t1, t2;
+        int sd;
+        asm volatile(
+            "v_add_f32 %[t1], %[lim], %[u]\n\t"
+            "v_sub_f32 %[t2], %[lim], %[u]\n\t"
+            "v_med3_f32 %[d], -%[e], -%[t1], %[t2]\n\t"
+            "s_lshl_b64 exec, 1, %[pp]\n\t"
+            "v_readlane_b32 %[sd], %[d], %[pp]\n\t"
+            "v_add_f32 %[u], %[u], %[d]\n\t"
+            "s_mov_b64 exec, -1\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f32 %[e], %[sd], %[a]\n\t"
+            : [d] "=&v"(d), [t1] "=&v"(t1), [t2] "=&v"(t2), [sd] "=&s"(sd), [u] "+v"(u), [e] "+v"(e)
+            : [lim] "v"(lim), [a] "v"(acol), [pp] "i"(PP));
+        res_i = max(res_i, (unsigned)sd & 0x7fffffffu);
+    } else {
+#pragma clang fp contract(off)
+        const real t1 = lim + u, t2 = lim - u;
+        const real d = min_(max_(-e, -t1), t2);
+        if (lane == PP) u += d;
+        const real db = bcast(d, PP);
+        res_i = max(res_i, absbits(db));
+        e = fma_(db, acol, e);
+    }
+}
+
+// limit rows have Jacobian sgn * e_d on the joint's port (rare: only while a joint limit is violated);
+// they share the lane's e (which is relative to the MOTOR row's rv), so J*deltaV = e + rv_motor.
 template <int PP, typename real>
-__device__ __forceinline__ void pgs_row_signed(real &r, real &u, const real rv, const real lo, const real hi, const real acol, const real sgn, const int lane, unsigned &res_i) {
+__device__ __forceinline__ void pgs_row_signed(real &e, real &u, const real rv_motor, const real rv, const real lo, const real hi, const real acol,
+                                               const real sgn, const int lane, unsigned &res_i) {
+    const real r = e + rv_motor;
     const real t = u + (rv - sgn * r);
     const real nu = min_(max_(t, lo), hi);
     const real d = nu - u;
     if (lane == PP) u = nu;
     const real db = bcast(d, PP);
     res_i = max(res_i, absbits(db));
-    r += acol * (bcast(sgn, PP) * db);
+    e = fma_(bcast(sgn, PP) * db, acol, e);
 }
 
-// cone-coupled lateral friction pair of contact point with normal port PN (rows at PN+1, PN+2),
-// btMultiBodyConstraintSolver::resolveConeFrictionConstraintRows, evaluated in lambda space
-template <bool FAST, int PN, typename real>
-__device__ __forceinline__ void pgs_cone(real &r, real &u0, const real rv, const real jdi, const real diag, const real fcl, const real aA, const real aB,
+// cone-coupled lateral friction pair of the contact point with normal port PN (rows at PN+1, PN+2),
+// btMultiBodyConstraintSolver::resolveConeFrictionConstraintRows, evaluated in lambda space.
+//   limn (valid in lane PN) = mu * lambda_n;  u (lanes PA, PB) = lambda * diag of the two rows
+template <int PN, typename real>
+__device__ __forceinline__ void pgs_cone(real &e, real &u, const real limn, const real jdi, const real diag, const real aA, const real aB,
                                          const int lane, unsigned &res_i) {
+#pragma clang fp contract(off)      // same roundings in every instantiation: fused ops are written out
     constexpr int PA = PN + 1, PB = PN + 2;
-    const real un = bcast(u0, PN);
-    const real sl = (u0 + (rv - r)) * jdi;          // candidate lambda of this lane's row
-    const real ll = u0 * jdi;                       // current lambda
-    const real lim = fcl * un;                      // mu * lambda_n (valid in lanes PA, PB)
-    const real sA = bcast(sl, PA), sB = bcast(sl, PB);
-    const real lA = bcast(ll, PA), lB = bcast(ll, PB);
-    const real lm = bcast(lim, PA);
-    real nA = sA, nB = sB;
-    const real len2 = sA * sA + sB * sB;
+    const real s = (u - e) * jdi;                   // candidate lambda of this lane's row
+    const real sA = bcast(s, PA), sB = bcast(s, PB);
+    const real lm = bcast(limn, PN);
+    const real len2 = fma_(sA, sA, sB * sB);
+    real scale = 1;
     if (len2 >= lm * lm) {
-        // |lim*sin(atan2(sA,sB))| = lim*|sA|/hypot ; each row is clamped to its own bound
-        real inv;
-        if constexpr (sizeof(real) == 4) inv = len2 > 0 ? __builtin_amdgcn_rsqf(len2) : 0.0f;   // 1 ulp, f32 path only
-        else inv = len2 > 0 ? (real)1 / sqrt_(len2) : (real)0;
-        const real cA = abs_(lm * (sA * inv)), cB = len2 > 0 ? abs_(lm * (sB * inv)) : abs_(lm);
-        nA = min_(max_(sA, -cA), cA);
-        nB = min_(max_(sB, -cB), cB);
+        // Bullet clamps row A to |lim*sin(atan2(sA,sB))| and row B to |lim*cos(..)|: a radial projection onto the circle
+        if constexpr (sizeof(real) == 4) scale = len2 > 0 ? lm * __builtin_amdgcn_rsqf(len2) : 0.0f;   // 1 ulp, f32 path only
+        else scale = len2 > 0 ? lm / sqrt_(len2) : (real)0;
+        scale = abs_(scale);
     }
-    const real dgA = bcast(diag, PA), dgB = bcast(diag, PB);
-    const real dA = (nA - lA) * dgA, dB = (nB - lB) * dgB;     // deltaVel of each row
-    if (lane == PA) u0 = nA * dgA;
-    if (lane == PB) u0 = nB * dgB;
+    const real n = s * scale;                       // lane-local: the new lambda of this lane's row (len2 == 0 -> s == 0)
+    const real d = fma_(n, diag, -u);               // deltaVel of this lane's row
+    if (lane == PA || lane == PB) u += d;
+    const real dA = bcast(d, PA), dB = bcast(d, PB);
     res_i = max(res_i, absbits(dA + dB));
-    r += aA * dA + aB * dB;
+    e = fma_(dB, aB, fma_(dA, aA, e));
 }
 
 template <typename real> __device__ inline void cross3(real *c, const real *a, const real *b) {
@@ -229,17 +295,22 @@ struct Smem {
     real tgt[NV];
     real RO[NB][12];    // world rotation (9, row major) + frame origin (3)
     real CA[NB][8];     // COM world (3) | pad | joint axis world (3) | pad
-    real kin[NB][12];   // omega | velocity-product alpha | v_origin | velocity-product a_origin
-    real I[NB][16];     // m, m*c (3), Io (xx yy zz xy xz yz) about the base origin; then F(3), N(3): subtree sums
-    real S[NV][8];      // motion subspace about the base origin: [angular; linear]
-    real M[NV][NV + 1]; // mass matrix, later its Cholesky factor L (lower)
-    real tau[NV];
+    alignas(16) real M[NV][NV]; // mass matrix, later its Cholesky factor L (lower); rows read as broadcast b128
     real v[NV];         // generalized velocity after the unconstrained update
     real col[NV];       // broadcast buffer
-    real Y[NPORT][NV + 1];  // J (then L^-1 J^T) per port
     real lamP[NPORT];
-    real misc[16];
+    // phase-exclusive storage: the dynamics scratch (phases A-D) is dead before the solver's Y (phases E-H)
+    union {
+        struct {
+            real kin[NB][12];   // omega | velocity-product alpha | v_origin | velocity-product a_origin
+            real I[NB][16];     // m, m*c (3), Io (xx yy zz xy xz yz) about the base origin; then F(3), N(3): subtree sums
+            real S[NV][8];      // motion subspace about the base origin: [angular; linear]
+            real tau[NV];
+        };
+        alignas(16) real YT[NV][YTS];  // J, then Y = L^-1 J^T, coordinate-major: YT[j][port]
+    };
 };
+
 
 // ---------------------------------------------------------------- forward kinematics + velocity recursion
 // lane b < 19 owns body b.  Fills RO, CA, kin.  with_vel=false: orientation/position only.
@@ -425,9 +496,16 @@ __device__ __forceinline__ void euler_from_quat(const real *q, real *rpy) {   //
 template <bool FAST, typename real>
 __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P, const int lane, const real mass_scale, const real mu_lat,
                                int &rc, int &lc, int &iters, real *dump) {
+    // phase stamps (shader clock) into the debug dump: diagnostic only, never in the timed path
+    int stamp_i = 0;
+    long long stamp_t0 = 0;
+#define STAMP() do { if (dump) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); if (stamp_i == 0) stamp_t0 = t_; if (lane == 0) dump[3800 + stamp_i] = (real)(double)(t_ - stamp_t0); stamp_i++; } } while (0)
+    STAMP();
     // ---------------- A. kinematics, inertias, bias ----------------
     kinematics(s, P, lane, true);
+    STAMP();
     body_dynamics(s, P, lane, mass_scale);
+    STAMP();
     const real O0[3] = {s.st[0], s.st[1], s.st[2]};
 
     // ---------------- B. motion subspaces, mass matrix, bias force ----------------
@@ -486,6 +564,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         dump[576 + lane] = s.tau[lane];
     }
 
+    STAMP();
     // ---------------- C. Cholesky  M = L L^T, row `lane` in registers ----------------
     real Lr[NV];
 #pragma unroll
@@ -499,16 +578,15 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         if (lane == j) { lij = d; inv_diag = rd; }
         if (lane < j) lij = 0;
         Lr[j] = lij;
-        if (lane < NV) s.col[lane] = lij;
-        WSYNC();
+        // trailing update M[i][c] -= L[i][j] L[c][j]; column j is broadcast lane by lane (no LDS round trip)
 #pragma unroll
-        for (int c = j + 1; c < NV; c++) Lr[c] -= lij * s.col[c];
-        WSYNC();
+        for (int c = j + 1; c < NV; c++) Lr[c] -= lij * bcast(lij, c);
     }
     if (lane < NV) {
 #pragma unroll
         for (int j = 0; j < NV; j++) s.M[k][j] = Lr[j];
     }
+    STAMP();
     // ---------------- D. unconstrained velocity update  v* = clamp(v + dt M^-1 tau) ----------------
     real vstar;
     {
@@ -542,6 +620,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         dump[600 + lane] = s.v[lane];
     }
 
+    STAMP();
     // ---------------- E. collision (feet vs ground) and port Jacobians ----------------
     // port p: 0..17 joint d | 18+15f+{0,1,2} foot f torsional (n, dir1, dir2) | 18+15f+3+3k+{0,1,2} point k linear
     const int p = lane < NPORT ? lane : 0;
@@ -557,7 +636,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     real Pw[3] = {0, 0, 0};
     if (lane >= ND && lane < NPORT) {
 #pragma unroll
-        for (int j = 0; j < NV; j++) s.Y[p][j] = 0;
+        for (int j = 0; j < NV; j++) s.YT[j][p] = 0;
         real ax[3] = {pax == 2 ? (real)1 : (real)0, pax == 1 ? (real)-1 : (real)0, pax == 0 ? (real)1 : (real)0};
         if (is_lin) {
             const real *pt = P.pts[pf][pk];
@@ -568,10 +647,10 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             real r[3] = {Pw[0] - O0[0], Pw[1] - O0[1], Pw[2] - O0[2]}, t1[3];
             cross3(t1, r, ax);
 #pragma unroll
-            for (int i = 0; i < 3; i++) { s.Y[p][i] = t1[i]; s.Y[p][3 + i] = ax[i]; }
+            for (int i = 0; i < 3; i++) { s.YT[i][p] = t1[i]; s.YT[3 + i][p] = ax[i]; }
         } else {
 #pragma unroll
-            for (int i = 0; i < 3; i++) s.Y[p][i] = ax[i];
+            for (int i = 0; i < 3; i++) s.YT[i][p] = ax[i];
         }
         for (int i = 0; i < 6; i++) {           // the six leg joints that move this foot
             const int b = fb - 5 + i;
@@ -582,7 +661,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                 cross3(t1, r, ax);
                 val = dot3(a, t1);
             } else val = dot3(a, ax);
-            s.Y[p][5 + b] = val;
+            s.YT[5 + b][p] = val;
         }
     }
     const bool cp_active = is_lin && dist <= P.brk[pf];
@@ -596,7 +675,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     // own Jacobian row into registers, b = J v*, then Y = L^-1 J^T by forward substitution
     real Jr[NV];
 #pragma unroll
-    for (int j = 0; j < NV; j++) Jr[j] = is_joint ? (j == 6 + p ? (real)1 : (real)0) : s.Y[p][j];
+    for (int j = 0; j < NV; j++) Jr[j] = is_joint ? (j == 6 + p ? (real)1 : (real)0) : s.YT[j][p];
     real bvel = 0;
 #pragma unroll
     for (int j = 0; j < NV; j++) bvel += Jr[j] * s.v[j];
@@ -612,9 +691,10 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     }
     if (lane < NPORT) {
 #pragma unroll
-        for (int j = 0; j < NV; j++) s.Y[p][j] = Jr[j];
+        for (int j = 0; j < NV; j++) s.YT[j][p] = Jr[j];
     }
     WSYNC();
+    STAMP();
     // ---------------- F. port Delassus matrix, one row per lane in registers ----------------
     // A[p][q] = Y_p . Y_q, accumulated over the 24 generalized coordinates (outer loop kept rolled so
     // that only the 48 accumulators are live)
@@ -623,9 +703,9 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     for (int q = 0; q < NPORT; q++) Ar[q] = 0;
 #pragma unroll 1
     for (int j = 0; j < NV; j++) {
-        const real yj = s.Y[p][j];
+        const real yj = s.YT[j][p];
 #pragma unroll
-        for (int q = 0; q < NPORT; q++) Ar[q] += yj * s.Y[q][j];
+        for (int q = 0; q < NPORT; q++) Ar[q] += yj * s.YT[j][q];
     }
     real diag = 0;
 #pragma unroll
@@ -648,17 +728,20 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
 #pragma unroll
     for (int q = 0; q < NPORT; q++) Ar[q] *= s.lamP[q];
 
+    STAMP();
     // ---------------- G. rows ----------------
     // joint lanes: motor row (+ a limit row when violated); contact lanes: one row per port, except the
     // torsional ports which carry one row per active contact point of their foot (same Jacobian).
-    // rv = velocity-level right-hand side (Bullet's m_rhs / jacDiagABInv)
-    real rv = 0, u0 = 0, u1 = 0, u2 = 0, u3 = 0;   // u0..3: torsional per point; u0: everything else
+    real rv = 0;                                   // velocity-level right-hand side of this lane's port
+    real blo = 0, bhi = 0;                         // bounds relative to the impulse (motor / normal rows)
+    real u0 = 0, u1 = 0, u2 = 0, u3 = 0;           // explicit u: torsional rows per point (u0..u3), lateral friction (u0)
     real rv_lim = 0, u_lim = 0, sgn_lim = 1;
     bool lim_active = false;
     const real dis = jdi > 0 ? (real)1 : (real)0;  // a row whose diagonal vanished is disabled (m_jacDiagABInv = 0)
     if (is_joint) {
         const real q = s.st[13 + p], tgt = s.tgt[p];
         rv = (P.kp * ((tgt - q) * P.inv_dt) + bvel + P.kd * (0 - bvel) - bvel) * dis;
+        bhi = P.max_imp * diag; blo = -bhi;        // lambda in [-0.15 dt, 0.15 dt]  <=>  u in [-mh, mh]
         const real lo = (real)GEN_LOWER_LIMIT, hi = (real)GEN_UPPER_LIMIT;
         const real pen_lo = q - lo, pen_hi = hi - q;
         if (pen_lo <= 0) {
@@ -682,60 +765,58 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     }
     const unsigned long long lim_ballot = __ballot(lim_active);
     const unsigned lim_mask = (unsigned)(lim_ballot & 0x3ffffull);
-    // bounds in u units: lambda in [lo, hi]  <=>  u in [lo*diag, hi*diag]
-    const real motor_hi = P.max_imp * diag;
     const real lim_hi = (real)100 * diag;
-    const real nrm_hi = (real)1e10 * diag;
-    // friction bound of a row = mu * lambda_n = (mu * diag_row * jdi_n) * u_n ; jdi of every port is in lamP
+    // friction bound of a row = mu * lambda_n = (mu * diag_row * jdi_n) * u_n ; jdi of every port is in lamP.
+    // the normal rows keep blo = -u_n, hence the sign folded into the coefficients
     real fc0 = 0, fc1 = 0, fc2 = 0, fc3 = 0;
     if (is_tors) {
-        const real mu = (pl == 0 ? P.mu_spin : P.mu_roll) * diag;
+        const real mu = -(pl == 0 ? P.mu_spin : P.mu_roll) * diag;
         const int pn0 = 18 + 15 * pf + 3;
         fc0 = mu * s.lamP[pn0]; fc1 = mu * s.lamP[pn0 + 3]; fc2 = mu * s.lamP[pn0 + 6]; fc3 = mu * s.lamP[pn0 + 9];
     }
-    // lateral friction is cone-coupled in lambda space: keep mu_lat * jdi_n for the point's normal port
-    const real fcl = (is_lin && pax != 0) ? mu_lat * s.lamP[p - pax] : (real)0;
+    const real nfcn = (is_lin && pax == 0) ? -mu_lat * jdi : (real)0;   // lane PN: mu_lat * lambda_n = nfcn * blo
 
-    real r = 0;                    // J_port * deltaV, this lane's port
+    real e = -rv;                  // e = J_port * deltaV - rv
     unsigned res_i = 0;            // wave-uniform running max |deltaVel| of this iteration (IEEE bits, non-negative)
     const unsigned thr_i = __builtin_bit_cast(unsigned, (float)sqrt((double)P.res_thr));
 
+    STAMP();
     int it = 0;
     for (it = 0; it < P.num_iterations; it++) {
         res_i = 0;
         // -- non-contact rows: sorted order (motors, then limits) on odd iterations, reversed on even ones --
         if (it & 1) {
-            static_for<ND>([&](auto ic) { constexpr int PP = NC_ORDER[decltype(ic)::value]; pgs_row<FAST, PP>(r, u0, rv, -motor_hi, motor_hi, Ar[PP], lane, res_i); });
+            static_for<ND>([&](auto ic) { constexpr int PP = NC_ORDER[decltype(ic)::value]; pgs_row2<FAST, PP>(e, blo, bhi, Ar[PP], lane, res_i); });
             if (lim_mask) {
                 static_for<ND>([&](auto ic) {
                     constexpr int PP = NC_ORDER[decltype(ic)::value];
-                    if (lim_mask & (1u << PP)) pgs_row_signed<PP>(r, u_lim, rv_lim, (real)0, lim_hi, Ar[PP], sgn_lim, lane, res_i);
+                    if (lim_mask & (1u << PP)) pgs_row_signed<PP>(e, u_lim, rv, rv_lim, (real)0, lim_hi, Ar[PP], sgn_lim, lane, res_i);
                 });
             }
         } else {
             if (lim_mask) {
                 static_for<ND>([&](auto ic) {
                     constexpr int PP = NC_ORDER[ND - 1 - decltype(ic)::value];
-                    if (lim_mask & (1u << PP)) pgs_row_signed<PP>(r, u_lim, rv_lim, (real)0, lim_hi, Ar[PP], sgn_lim, lane, res_i);
+                    if (lim_mask & (1u << PP)) pgs_row_signed<PP>(e, u_lim, rv, rv_lim, (real)0, lim_hi, Ar[PP], sgn_lim, lane, res_i);
                 });
             }
-            static_for<ND>([&](auto ic) { constexpr int PP = NC_ORDER[ND - 1 - decltype(ic)::value]; pgs_row<FAST, PP>(r, u0, rv, -motor_hi, motor_hi, Ar[PP], lane, res_i); });
+            static_for<ND>([&](auto ic) { constexpr int PP = NC_ORDER[ND - 1 - decltype(ic)::value]; pgs_row2<FAST, PP>(e, blo, bhi, Ar[PP], lane, res_i); });
         }
         // -- normal rows (manifold order: right foot points, then left foot points) --
         static_for<8>([&](auto ic) {
             constexpr int c = decltype(ic)::value, PP = port_normal(c);
-            if (act & (1u << c)) pgs_row<FAST, PP>(r, u0, rv, (real)0, nrm_hi, Ar[PP], lane, res_i);
+            if (act & (1u << c)) pgs_row1<FAST, PP>(e, blo, Ar[PP], lane, res_i);
         });
         // -- spinning rows (one per active point, all on the foot's normal-axis torsional port) --
         if (P.mu_spin > 0) {
             static_for<8>([&](auto ic) {
                 constexpr int c = decltype(ic)::value, PN = port_normal(c), PP = 18 + 15 * (c / 4);
                 if (act & (1u << c)) {
-                    const real un = bcast(u0, PN);
-                    if (un > 0) {
+                    const real nb = bcast(blo, PN);                 // -u_n of the point's normal row
+                    if (nb < 0) {                                   // Bullet: only while the normal impulse is positive
                         real &uu = (c % 4) == 0 ? u0 : (c % 4) == 1 ? u1 : (c % 4) == 2 ? u2 : u3;
-                        const real lim = ((c % 4) == 0 ? fc0 : (c % 4) == 1 ? fc1 : (c % 4) == 2 ? fc2 : fc3) * un;
-                        pgs_row<FAST, PP>(r, uu, rv, -lim, lim, Ar[PP], lane, res_i);
+                        const real lim = mul_rn_((c % 4) == 0 ? fc0 : (c % 4) == 1 ? fc1 : (c % 4) == 2 ? fc2 : fc3, nb);
+                        pgs_rowT<FAST, PP>(e, uu, lim, Ar[PP], lane, res_i);
                     }
                 }
             });
@@ -745,12 +826,12 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             static_for<8>([&](auto ic) {
                 constexpr int c = decltype(ic)::value, PN = port_normal(c), PP = 18 + 15 * (c / 4);
                 if (act & (1u << c)) {
-                    const real un = bcast(u0, PN);
-                    if (un > 0) {
+                    const real nb = bcast(blo, PN);
+                    if (nb < 0) {
                         real &uu = (c % 4) == 0 ? u0 : (c % 4) == 1 ? u1 : (c % 4) == 2 ? u2 : u3;
-                        const real lim = ((c % 4) == 0 ? fc0 : (c % 4) == 1 ? fc1 : (c % 4) == 2 ? fc2 : fc3) * un;
-                        pgs_row<FAST, PP + 1>(r, uu, rv, -lim, lim, Ar[PP + 1], lane, res_i);
-                        pgs_row<FAST, PP + 2>(r, uu, rv, -lim, lim, Ar[PP + 2], lane, res_i);
+                        const real lim = mul_rn_((c % 4) == 0 ? fc0 : (c % 4) == 1 ? fc1 : (c % 4) == 2 ? fc2 : fc3, nb);
+                        pgs_rowT<FAST, PP + 1>(e, uu, lim, Ar[PP + 1], lane, res_i);
+                        pgs_rowT<FAST, PP + 2>(e, uu, lim, Ar[PP + 2], lane, res_i);
                     }
                 }
             });
@@ -758,22 +839,26 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         // -- lateral friction, cone-coupled pairs --
         static_for<8>([&](auto ic) {
             constexpr int c = decltype(ic)::value, PN = port_normal(c);
-            if (act & (1u << c)) pgs_cone<FAST, PN>(r, u0, rv, jdi, diag, fcl, Ar[PN + 1], Ar[PN + 2], lane, res_i);
+            if (act & (1u << c)) pgs_cone<PN>(e, u0, mul_rn_(nfcn, blo), jdi, diag, Ar[PN + 1], Ar[PN + 2], lane, res_i);
         });
         if (res_i <= thr_i || it >= P.num_iterations - 1) { it++; break; }
     }
     iters = it;
-    const real lam0 = u0 * jdi, lam1 = u1 * jdi, lam2 = u2 * jdi, lam3 = u3 * jdi, lam_lim = u_lim * jdi;
+    // back to impulses: joint lanes u = -(mh + blo) (+ the limit row), normal lanes u = -blo, the rest explicit
+    real lam_sum;
+    if (is_joint) lam_sum = (-(P.max_imp * diag) - blo + sgn_lim * u_lim) * jdi;
+    else if (is_lin && pax == 0) lam_sum = -blo * jdi;
+    else lam_sum = (u0 + u1 + u2 + u3) * jdi;
 
     // ---------------- H. apply impulses:  dv = L^-T (Y Lambda),  v = clamp(v* + dv) ----------------
     {
-        real lamP = lam0 + lam1 + lam2 + lam3 + sgn_lim * lam_lim;
+        const real lamP = lam_sum;
         if (lane < NPORT) s.lamP[p] = lamP;
         WSYNC();
         real z = 0;
         if (lane < NV) {
 #pragma unroll
-            for (int q = 0; q < NPORT; q++) z += s.Y[q][k] * s.lamP[q];
+            for (int q = 0; q < NPORT; q++) z += s.YT[k][q] * s.lamP[q];
         }
         real x = 0;
 #pragma unroll
@@ -791,6 +876,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         if (dump && lane == 0) dump[3700] = (real)it;
     }
     WSYNC();
+    STAMP();
     // ---------------- I. integrate positions (btMultiBody::stepPositionsMultiDof) ----------------
     {
         const real w0 = s.v[0], w1 = s.v[1], w2 = s.v[2];
@@ -813,7 +899,8 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         if (lane < 4) s.st[3 + lane] = rq[lane] / nrm;
         if (lane >= 6 && lane < NV) { s.st[13 + lane - 6] += P.dt * s.v[lane]; s.st[31 + lane - 6] = s.v[lane]; }
     }
-    WSYNC();
+    WSYNC();    STAMP();
+#undef STAMP
 }
 
 // ================================================================================================
@@ -845,7 +932,7 @@ __device__ inline double agent_to_env(int j, double a) {
 }
 
 template <typename real, bool FAST>
-__global__ __launch_bounds__(64, sizeof(real) == 8 ? 2 : 4) void plen_env_kernel(StepArgs<real> a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real) == 8 ? 2 : 4, sizeof(real) == 8 ? 2 : 4))) void plen_env_kernel(StepArgs<real> a) {
     __shared__ Smem<real> s;
     const int env = blockIdx.x;
     const int lane = threadIdx.x;
