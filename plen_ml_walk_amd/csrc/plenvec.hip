@@ -38,6 +38,9 @@
 #define NPORT 48
 #define REC 64          // reals per env state record
 #define AUXN 8          // int32 per env aux record
+#ifndef WPE32
+#define WPE32 4        // waves per SIMD the f32 kernel is register-allocated for
+#endif
 #define YTS 52          // row stride of the transposed Y buffer (48 ports + pad: conflict-free b128 row reads)
 
 // ------------------------------------------------------------------------------------------------
@@ -174,6 +177,58 @@ __device__ __forceinline__ void pgs_row2(real &e, real &blo, real &bhi, const re
         const real d = min_(max_(-e, blo), bhi);
         if (lane == PP) { blo -= d; bhi -= d; }
         const real db = bcast(d, PP);
+        res_i = max(res_i, absbits(db));
+        e = fma_(db, acol, e);
+    }
+}
+
+// Deferred-commit forms: the row's delta is dropped into lane PP of `dvec` with v_writelane (no EXEC
+// narrowing); the caller applies  blo -= dvec (bhi -= dvec)  once after the pass.  Valid because a
+// lane hosts at most one such row per pass.
+template <bool FAST, int PP, typename real>
+__device__ __forceinline__ void pgs_row2d(real &e, const real blo, const real bhi, real &dvec, const real acol, const int lane, unsigned &res_i) {
+    if constexpr (FAST && sizeof(real) == 4) {
+        float d;
+        int sd;
+        asm volatile(
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "s_nop 0\n\t"
+            "v_readlane_b32 %[sd], %[d], %[pp]\n\t"
+            "s_nop 1\n\t"
+            "v_writelane_b32 %[dv], %[sd], %[pp]\n\t"
+            "v_fmac_f32 %[e], %[sd], %[a]\n\t"
+            : [d] "=&v"(d), [sd] "=&s"(sd), [dv] "+v"(dvec), [e] "+v"(e)
+            : [blo] "v"(blo), [bhi] "v"(bhi), [a] "v"(acol), [pp] "i"(PP));
+        res_i = max(res_i, (unsigned)sd & 0x7fffffffu);
+    } else {
+#pragma clang fp contract(off)
+        const real d = min_(max_(-e, blo), bhi);
+        const real db = bcast(d, PP);
+        if (lane == PP) dvec = db;
+        res_i = max(res_i, absbits(db));
+        e = fma_(db, acol, e);
+    }
+}
+template <bool FAST, int PP, typename real>
+__device__ __forceinline__ void pgs_row1d(real &e, const real blo, real &dvec, const real acol, const int lane, unsigned &res_i) {
+    if constexpr (FAST && sizeof(real) == 4) {
+        float d;
+        int sd;
+        asm volatile(
+            "v_max_f32 %[d], -%[e], %[blo]\n\t"
+            "s_nop 0\n\t"
+            "v_readlane_b32 %[sd], %[d], %[pp]\n\t"
+            "s_nop 1\n\t"
+            "v_writelane_b32 %[dv], %[sd], %[pp]\n\t"
+            "v_fmac_f32 %[e], %[sd], %[a]\n\t"
+            : [d] "=&v"(d), [sd] "=&s"(sd), [dv] "+v"(dvec), [e] "+v"(e)
+            : [blo] "v"(blo), [a] "v"(acol), [pp] "i"(PP));
+        res_i = max(res_i, (unsigned)sd & 0x7fffffffu);
+    } else {
+#pragma clang fp contract(off)
+        const real d = max_(-e, blo);
+        const real db = bcast(d, PP);
+        if (lane == PP) dvec = db;
         res_i = max(res_i, absbits(db));
         e = fma_(db, acol, e);
     }
@@ -777,16 +832,21 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     const real nfcn = (is_lin && pax == 0) ? -mu_lat * jdi : (real)0;   // lane PN: mu_lat * lambda_n = nfcn * blo
 
     real e = -rv;                  // e = J_port * deltaV - rv
+    real dvec = 0;                 // per-pass deltas of the rows hosted by this lane (deferred commit)
     unsigned res_i = 0;            // wave-uniform running max |deltaVel| of this iteration (IEEE bits, non-negative)
     const unsigned thr_i = __builtin_bit_cast(unsigned, (float)sqrt((double)P.res_thr));
 
+    // loop-invariant parameters into registers (a reference into global memory would be re-read every iteration)
+    const int n_iter = __builtin_amdgcn_readfirstlane(P.num_iterations);
+    const bool has_spin = P.mu_spin > 0, has_roll = P.mu_roll > 0;
     STAMP();
     int it = 0;
-    for (it = 0; it < P.num_iterations; it++) {
+    for (it = 0; it < n_iter; it++) {
         res_i = 0;
         // -- non-contact rows: sorted order (motors, then limits) on odd iterations, reversed on even ones --
         if (it & 1) {
-            static_for<ND>([&](auto ic) { constexpr int PP = NC_ORDER[decltype(ic)::value]; pgs_row2<FAST, PP>(e, blo, bhi, Ar[PP], lane, res_i); });
+            static_for<ND>([&](auto ic) { constexpr int PP = NC_ORDER[decltype(ic)::value]; pgs_row2d<FAST, PP>(e, blo, bhi, dvec, Ar[PP], lane, res_i); });
+            blo -= dvec; bhi -= dvec; dvec = 0;
             if (lim_mask) {
                 static_for<ND>([&](auto ic) {
                     constexpr int PP = NC_ORDER[decltype(ic)::value];
@@ -800,15 +860,18 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                     if (lim_mask & (1u << PP)) pgs_row_signed<PP>(e, u_lim, rv, rv_lim, (real)0, lim_hi, Ar[PP], sgn_lim, lane, res_i);
                 });
             }
-            static_for<ND>([&](auto ic) { constexpr int PP = NC_ORDER[ND - 1 - decltype(ic)::value]; pgs_row2<FAST, PP>(e, blo, bhi, Ar[PP], lane, res_i); });
+            static_for<ND>([&](auto ic) { constexpr int PP = NC_ORDER[ND - 1 - decltype(ic)::value]; pgs_row2d<FAST, PP>(e, blo, bhi, dvec, Ar[PP], lane, res_i); });
+            blo -= dvec; bhi -= dvec; dvec = 0;
         }
+        if (act) {     // airborne: one branch skips every contact row
         // -- normal rows (manifold order: right foot points, then left foot points) --
         static_for<8>([&](auto ic) {
             constexpr int c = decltype(ic)::value, PP = port_normal(c);
-            if (act & (1u << c)) pgs_row1<FAST, PP>(e, blo, Ar[PP], lane, res_i);
+            if (act & (1u << c)) pgs_row1d<FAST, PP>(e, blo, dvec, Ar[PP], lane, res_i);
         });
+        blo -= dvec; dvec = 0;
         // -- spinning rows (one per active point, all on the foot's normal-axis torsional port) --
-        if (P.mu_spin > 0) {
+        if (has_spin) {
             static_for<8>([&](auto ic) {
                 constexpr int c = decltype(ic)::value, PN = port_normal(c), PP = 18 + 15 * (c / 4);
                 if (act & (1u << c)) {
@@ -822,7 +885,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             });
         }
         // -- rolling rows (two per active point) --
-        if (P.mu_roll > 0) {
+        if (has_roll) {
             static_for<8>([&](auto ic) {
                 constexpr int c = decltype(ic)::value, PN = port_normal(c), PP = 18 + 15 * (c / 4);
                 if (act & (1u << c)) {
@@ -841,7 +904,8 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             constexpr int c = decltype(ic)::value, PN = port_normal(c);
             if (act & (1u << c)) pgs_cone<PN>(e, u0, mul_rn_(nfcn, blo), jdi, diag, Ar[PN + 1], Ar[PN + 2], lane, res_i);
         });
-        if (res_i <= thr_i || it >= P.num_iterations - 1) { it++; break; }
+        }
+        if (res_i <= thr_i || it >= n_iter - 1) { it++; break; }
     }
     iters = it;
     // back to impulses: joint lanes u = -(mh + blo) (+ the limit row), normal lanes u = -blo, the rest explicit
@@ -932,7 +996,7 @@ __device__ inline double agent_to_env(int j, double a) {
 }
 
 template <typename real, bool FAST>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real) == 8 ? 2 : 4, sizeof(real) == 8 ? 2 : 4))) void plen_env_kernel(StepArgs<real> a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real) == 8 ? 2 : WPE32, sizeof(real) == 8 ? 2 : WPE32))) void plen_env_kernel(StepArgs<real> a) {
     __shared__ Smem<real> s;
     const int env = blockIdx.x;
     const int lane = threadIdx.x;
@@ -968,8 +1032,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real)
     WSYNC();
 
     int rc = 0, lc = 0, iters = 0;
-    for (int sub = 0; sub < a.nsub; sub++)
-        substep<FAST>(s, P, lane, mass_scale, mu_lat, rc, lc, iters, (sub == a.nsub - 1) ? dump : nullptr);
+    for (int sub = 0; sub < a.nsub; sub++) {
+        // keep loop-invariant parameter/model loads INSIDE the substep: hoisted out of this loop they would
+        // stay live across everything and be spilled to scratch
+        int ln = lane;
+        asm volatile("" : "+v"(ln) : : "memory");     // ... and so would every lane-dependent constant (one-hots, masks, addresses)
+        substep<FAST>(s, P, ln, mass_scale, mu_lat, rc, lc, iters, (sub == a.nsub - 1) ? dump : nullptr);
+    }
 
     if (a.mode == MODE_DEBUG) {
         a.state[(size_t)env * REC + lane] = s.st[lane];
