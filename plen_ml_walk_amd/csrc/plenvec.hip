@@ -291,6 +291,33 @@ __device__ __forceinline__ void pgs_rowT(real &e, real &u, const real lim, const
     }
 }
 
+// torsional row with bounds prepared by the caller for this pass (nt1 = -(lim + u), t2 = lim - u) and a
+// deferred commit (u += dvec after the pass): med3 -> readlane -> writelane -> fmac
+template <bool FAST, int PP, typename real>
+__device__ __forceinline__ void pgs_rowTd(real &e, const real nt1, const real t2, real &dvec, const real acol, const int lane, unsigned &res_i) {
+    if constexpr (FAST && sizeof(real) == 4) {
+        float d;
+        int sd;
+        asm volatile(
+            "v_med3_f32 %[d], -%[e], %[nt1], %[t2]\n\t"
+            "s_nop 0\n\t"
+            "v_readlane_b32 %[sd], %[d], %[pp]\n\t"
+            "s_nop 1\n\t"
+            "v_writelane_b32 %[dv], %[sd], %[pp]\n\t"
+            "v_fmac_f32 %[e], %[sd], %[a]\n\t"
+            : [d] "=&v"(d), [sd] "=&s"(sd), [dv] "+v"(dvec), [e] "+v"(e)
+            : [nt1] "v"(nt1), [t2] "v"(t2), [a] "v"(acol), [pp] "i"(PP));
+        res_i = max(res_i, (unsigned)sd & 0x7fffffffu);
+    } else {
+#pragma clang fp contract(off)
+        const real d = min_(max_(-e, nt1), t2);
+        const real db = bcast(d, PP);
+        if (lane == PP) dvec = db;
+        res_i = max(res_i, absbits(db));
+        e = fma_(db, acol, e);
+    }
+}
+
 // limit rows have Jacobian sgn * e_d on the joint's port (rare: only while a joint limit is violated);
 // they share the lane's e (which is relative to the MOTOR row's rv), so J*deltaV = e + rv_motor.
 template <int PP, typename real>
@@ -864,46 +891,72 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             blo -= dvec; bhi -= dvec; dvec = 0;
         }
         if (act) {     // airborne: one branch skips every contact row
-        // -- normal rows (manifold order: right foot points, then left foot points) --
-        static_for<8>([&](auto ic) {
-            constexpr int c = decltype(ic)::value, PP = port_normal(c);
-            if (act & (1u << c)) pgs_row1d<FAST, PP>(e, blo, dvec, Ar[PP], lane, res_i);
-        });
-        blo -= dvec; dvec = 0;
-        // -- spinning rows (one per active point, all on the foot's normal-axis torsional port) --
-        if (has_spin) {
-            static_for<8>([&](auto ic) {
-                constexpr int c = decltype(ic)::value, PN = port_normal(c), PP = 18 + 15 * (c / 4);
-                if (act & (1u << c)) {
-                    const real nb = bcast(blo, PN);                 // -u_n of the point's normal row
-                    if (nb < 0) {                                   // Bullet: only while the normal impulse is positive
-                        real &uu = (c % 4) == 0 ? u0 : (c % 4) == 1 ? u1 : (c % 4) == 2 ? u2 : u3;
-                        const real lim = mul_rn_((c % 4) == 0 ? fc0 : (c % 4) == 1 ? fc1 : (c % 4) == 2 ? fc2 : fc3, nb);
-                        pgs_rowT<FAST, PP>(e, uu, lim, Ar[PP], lane, res_i);
-                    }
+            // Bullet's order is type-major: all normals, all spinning, all rolling, all lateral pairs.  Taken
+            // scalar branches cost ~30 cycles each, so inactive points are skipped a whole foot at a time.
+            // -- normal rows (manifold order: right foot points, then left foot points) --
+            static_for<2>([&](auto fc_) {
+                constexpr int f = decltype(fc_)::value;
+                if (act & (0xfu << (4 * f))) {
+                    static_for<4>([&](auto ic) {
+                        constexpr int c = 4 * f + decltype(ic)::value, PP = port_normal(c);
+                        if (act & (1u << c)) pgs_row1d<FAST, PP>(e, blo, dvec, Ar[PP], lane, res_i);
+                    });
                 }
             });
-        }
-        // -- rolling rows (two per active point) --
-        if (has_roll) {
-            static_for<8>([&](auto ic) {
-                constexpr int c = decltype(ic)::value, PN = port_normal(c), PP = 18 + 15 * (c / 4);
-                if (act & (1u << c)) {
-                    const real nb = bcast(blo, PN);
-                    if (nb < 0) {
-                        real &uu = (c % 4) == 0 ? u0 : (c % 4) == 1 ? u1 : (c % 4) == 2 ? u2 : u3;
-                        const real lim = mul_rn_((c % 4) == 0 ? fc0 : (c % 4) == 1 ? fc1 : (c % 4) == 2 ? fc2 : fc3, nb);
-                        pgs_rowT<FAST, PP + 1>(e, uu, lim, Ar[PP + 1], lane, res_i);
-                        pgs_rowT<FAST, PP + 2>(e, uu, lim, Ar[PP + 2], lane, res_i);
+            blo -= dvec; dvec = 0;
+            // -- torsional friction: spinning rows (all points), then rolling rows (all points) --
+            // Bounds of a point's three torsional rows (spin lane, two roll lanes; each lane has its own
+            // mu*diag/diag_n coefficient fck and its own impulse uk) are prepared ONCE per iteration, for all
+            // three lanes at the same time: lim = fck * (-u_n), nt1 = -(lim + uk), t2 = lim - uk.  Valid
+            // because u_n only changes in the normal pass and uk only at its own row.
+            if (has_spin || has_roll) {
+                real nbv0 = 0, nbv1 = 0, nbv2 = 0, nbv3 = 0;     // -u_n of point k of THIS lane's foot
+                unsigned posmask = 0;                             // points whose normal impulse is positive
+                static_for<8>([&](auto ic) {
+                    constexpr int c = decltype(ic)::value, k = c % 4, f = c / 4, PN = port_normal(c);
+                    if (act & (1u << c)) {
+                        const real nb = bcast(blo, PN);
+                        if (nb < 0) posmask |= 1u << c;
+                        real &nbv = k == 0 ? nbv0 : k == 1 ? nbv1 : k == 2 ? nbv2 : nbv3;
+                        if (pf == f) nbv = nb;
                     }
+                });
+                const real lim0 = mul_rn_(fc0, nbv0), lim1 = mul_rn_(fc1, nbv1), lim2 = mul_rn_(fc2, nbv2), lim3 = mul_rn_(fc3, nbv3);
+                const real nt10 = -(lim0 + u0), nt11 = -(lim1 + u1), nt12 = -(lim2 + u2), nt13 = -(lim3 + u3);
+                const real t20 = lim0 - u0, t21 = lim1 - u1, t22 = lim2 - u2, t23 = lim3 - u3;
+                real dv0 = 0, dv1 = 0, dv2 = 0, dv3 = 0;
+                if (has_spin) {
+                    static_for<8>([&](auto ic) {
+                        constexpr int c = decltype(ic)::value, k = c % 4, PP = 18 + 15 * (c / 4);
+                        if (posmask & (1u << c)) {                   // Bullet: only while the normal impulse is positive
+                            pgs_rowTd<FAST, PP>(e, k == 0 ? nt10 : k == 1 ? nt11 : k == 2 ? nt12 : nt13, k == 0 ? t20 : k == 1 ? t21 : k == 2 ? t22 : t23,
+                                                k == 0 ? dv0 : k == 1 ? dv1 : k == 2 ? dv2 : dv3, Ar[PP], lane, res_i);
+                        }
+                    });
+                }
+                if (has_roll) {
+                    static_for<8>([&](auto ic) {
+                        constexpr int c = decltype(ic)::value, k = c % 4, PP = 18 + 15 * (c / 4);
+                        if (posmask & (1u << c)) {
+                            pgs_rowTd<FAST, PP + 1>(e, k == 0 ? nt10 : k == 1 ? nt11 : k == 2 ? nt12 : nt13, k == 0 ? t20 : k == 1 ? t21 : k == 2 ? t22 : t23,
+                                                    k == 0 ? dv0 : k == 1 ? dv1 : k == 2 ? dv2 : dv3, Ar[PP + 1], lane, res_i);
+                            pgs_rowTd<FAST, PP + 2>(e, k == 0 ? nt10 : k == 1 ? nt11 : k == 2 ? nt12 : nt13, k == 0 ? t20 : k == 1 ? t21 : k == 2 ? t22 : t23,
+                                                    k == 0 ? dv0 : k == 1 ? dv1 : k == 2 ? dv2 : dv3, Ar[PP + 2], lane, res_i);
+                        }
+                    });
+                }
+                u0 += dv0; u1 += dv1; u2 += dv2; u3 += dv3;
+            }
+            // -- lateral friction, cone-coupled pairs --
+            static_for<2>([&](auto fc_) {
+                constexpr int f = decltype(fc_)::value;
+                if (act & (0xfu << (4 * f))) {
+                    static_for<4>([&](auto ic) {
+                        constexpr int c = 4 * f + decltype(ic)::value, PN = port_normal(c);
+                        if (act & (1u << c)) pgs_cone<PN>(e, u0, mul_rn_(nfcn, blo), jdi, diag, Ar[PN + 1], Ar[PN + 2], lane, res_i);
+                    });
                 }
             });
-        }
-        // -- lateral friction, cone-coupled pairs --
-        static_for<8>([&](auto ic) {
-            constexpr int c = decltype(ic)::value, PN = port_normal(c);
-            if (act & (1u << c)) pgs_cone<PN>(e, u0, mul_rn_(nfcn, blo), jdi, diag, Ar[PN + 1], Ar[PN + 2], lane, res_i);
-        });
         }
         if (res_i <= thr_i || it >= n_iter - 1) { it++; break; }
     }
