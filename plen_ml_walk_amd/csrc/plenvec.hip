@@ -121,6 +121,17 @@ __device__ inline double bcast(double x, int l) {
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 __device__ inline int bcast(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+// write the wave-uniform value `val` into lane L of `dst`, other lanes keep dst.  f32: v_writelane (no lane
+// mask to keep alive); the s_nop covers the VALU-wrote-SGPR -> v_writelane hazard (val comes from v_readlane).
+template <int L>
+__device__ __forceinline__ float wrlane(float dst, float val, int lane) {
+    (void)lane;
+    const int sv = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, val));
+    asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(sv), "i"(L));
+    return dst;
+}
+template <int L>
+__device__ __forceinline__ double wrlane(double dst, double val, int lane) { return lane == L ? val : dst; }
 
 // all 64 lanes of the single-wave workgroup see each other's LDS writes after this
 #define WSYNC() __syncthreads()
@@ -321,13 +332,14 @@ __device__ __forceinline__ void pgs_rowTd(real &e, const real nt1, const real t2
 // limit rows have Jacobian sgn * e_d on the joint's port (rare: only while a joint limit is violated);
 // they share the lane's e (which is relative to the MOTOR row's rv), so J*deltaV = e + rv_motor.
 template <int PP, typename real>
-__device__ __forceinline__ void pgs_row_signed(real &e, real &u, const real rv_motor, const real rv, const real lo, const real hi, const real acol,
-                                               const real sgn, const int lane, unsigned &res_i) {
+__device__ __forceinline__ void pgs_row_signed(real (&lim)[4][NV], real &e, const real diag, const real acol, const int lane, unsigned &res_i) {
+    const int l = lane < NV ? lane : 0;
+    const real rv_motor = lim[0][l], rv = lim[1][l], sgn = lim[2][l], u = lim[3][l];
     const real r = e + rv_motor;
     const real t = u + (rv - sgn * r);
-    const real nu = min_(max_(t, lo), hi);
+    const real nu = min_(max_(t, (real)0), (real)100 * diag);     // lambda in [0, 100] (btMultiBodyConstraint default max impulse)
     const real d = nu - u;
-    if (lane == PP) u = nu;
+    if (lane == PP) lim[3][l] = nu;
     const real db = bcast(d, PP);
     res_i = max(res_i, absbits(db));
     e = fma_(bcast(sgn, PP) * db, acol, e);
@@ -337,7 +349,7 @@ __device__ __forceinline__ void pgs_row_signed(real &e, real &u, const real rv_m
 // btMultiBodyConstraintSolver::resolveConeFrictionConstraintRows, evaluated in lambda space.
 //   limn (valid in lane PN) = mu * lambda_n;  u (lanes PA, PB) = lambda * diag of the two rows
 template <int PN, typename real>
-__device__ __forceinline__ void pgs_cone(real &e, real &u, const real limn, const real jdi, const real diag, const real aA, const real aB,
+__device__ __forceinline__ void pgs_cone(real &e, const real u, real &dvec, const real limn, const real jdi, const real diag, const real aA, const real aB,
                                          const int lane, unsigned &res_i) {
 #pragma clang fp contract(off)      // same roundings in every instantiation: fused ops are written out
     constexpr int PA = PN + 1, PB = PN + 2;
@@ -354,8 +366,8 @@ __device__ __forceinline__ void pgs_cone(real &e, real &u, const real limn, cons
     }
     const real n = s * scale;                       // lane-local: the new lambda of this lane's row (len2 == 0 -> s == 0)
     const real d = fma_(n, diag, -u);               // deltaVel of this lane's row
-    if (lane == PA || lane == PB) u += d;
     const real dA = bcast(d, PA), dB = bcast(d, PB);
+    dvec = wrlane<PA>(dvec, dA, lane); dvec = wrlane<PB>(dvec, dB, lane);     // u += dvec after the pass (no lane masks kept alive)
     res_i = max(res_i, absbits(dA + dB));
     e = fma_(dB, aB, fma_(dA, aA, e));
 }
@@ -381,6 +393,7 @@ struct Smem {
     real v[NV];         // generalized velocity after the unconstrained update
     real col[NV];       // broadcast buffer
     real lamP[NPORT];
+    real lim[4][NV];    // joint-limit rows (rare): motor rv, limit rv, sign, accumulated u -- kept out of registers
     // phase-exclusive storage: the dynamics scratch (phases A-D) is dead before the solver's Y (phases E-H)
     union {
         struct {
@@ -576,8 +589,13 @@ __device__ __forceinline__ void euler_from_quat(const real *q, real *rpy) {   //
 // ---------------------------------------------------------------- one 1/240 s physics substep
 // Contact flags of this substep's collision pass are returned in rc/lc, solver iterations in iters.
 template <bool FAST, typename real>
-__device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P, const int lane, const real mass_scale, const real mu_lat,
+__device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P, const int lane_in, const real mass_scale, const real mu_lat,
                                int &rc, int &lc, int &iters, real *dump) {
+    // `lane` is re-laundered through an empty asm at phase boundaries: otherwise the compiler CSEs the
+    // `lane == j` masks of every unrolled phase (48 SGPR pairs), keeps them alive across the whole substep
+    // and spills them
+    int lane = lane_in;
+#define FRESH_LANE() asm volatile("" : "+v"(lane))
     // phase stamps (shader clock) into the debug dump: diagnostic only, never in the timed path
     int stamp_i = 0;
     long long stamp_t0 = 0;
@@ -647,6 +665,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     }
 
     STAMP();
+    FRESH_LANE();
     // ---------------- C. Cholesky  M = L L^T, row `lane` in registers ----------------
     real Lr[NV];
 #pragma unroll
@@ -669,6 +688,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         for (int j = 0; j < NV; j++) s.M[k][j] = Lr[j];
     }
     STAMP();
+    FRESH_LANE();
     // ---------------- D. unconstrained velocity update  v* = clamp(v + dt M^-1 tau) ----------------
     real vstar;
     {
@@ -703,6 +723,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     }
 
     STAMP();
+    FRESH_LANE();
     // ---------------- E. collision (feet vs ground) and port Jacobians ----------------
     // port p: 0..17 joint d | 18+15f+{0,1,2} foot f torsional (n, dir1, dir2) | 18+15f+3+3k+{0,1,2} point k linear
     const int p = lane < NPORT ? lane : 0;
@@ -777,6 +798,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     }
     WSYNC();
     STAMP();
+    FRESH_LANE();
     // ---------------- F. port Delassus matrix, one row per lane in registers ----------------
     // A[p][q] = Y_p . Y_q, accumulated over the 24 generalized coordinates (outer loop kept rolled so
     // that only the 48 accumulators are live)
@@ -811,13 +833,14 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     for (int q = 0; q < NPORT; q++) Ar[q] *= s.lamP[q];
 
     STAMP();
+    FRESH_LANE();
     // ---------------- G. rows ----------------
     // joint lanes: motor row (+ a limit row when violated); contact lanes: one row per port, except the
     // torsional ports which carry one row per active contact point of their foot (same Jacobian).
     real rv = 0;                                   // velocity-level right-hand side of this lane's port
     real blo = 0, bhi = 0;                         // bounds relative to the impulse (motor / normal rows)
     real u0 = 0, u1 = 0, u2 = 0, u3 = 0;           // explicit u: torsional rows per point (u0..u3), lateral friction (u0)
-    real rv_lim = 0, u_lim = 0, sgn_lim = 1;
+    real rv_lim = 0, sgn_lim = 1;
     bool lim_active = false;
     const real dis = jdi > 0 ? (real)1 : (real)0;  // a row whose diagonal vanished is disabled (m_jacDiagABInv = 0)
     if (is_joint) {
@@ -845,9 +868,9 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     } else if (lane < NPORT) {
         rv = (0 - bvel) * dis;
     }
+    if (lane < NV) { s.lim[0][lane] = rv; s.lim[1][lane] = rv_lim; s.lim[2][lane] = sgn_lim; s.lim[3][lane] = 0; }
     const unsigned long long lim_ballot = __ballot(lim_active);
     const unsigned lim_mask = (unsigned)(lim_ballot & 0x3ffffull);
-    const real lim_hi = (real)100 * diag;
     // friction bound of a row = mu * lambda_n = (mu * diag_row * jdi_n) * u_n ; jdi of every port is in lamP.
     // the normal rows keep blo = -u_n, hence the sign folded into the coefficients
     real fc0 = 0, fc1 = 0, fc2 = 0, fc3 = 0;
@@ -877,14 +900,14 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             if (lim_mask) {
                 static_for<ND>([&](auto ic) {
                     constexpr int PP = NC_ORDER[decltype(ic)::value];
-                    if (lim_mask & (1u << PP)) pgs_row_signed<PP>(e, u_lim, rv, rv_lim, (real)0, lim_hi, Ar[PP], sgn_lim, lane, res_i);
+                    if (lim_mask & (1u << PP)) pgs_row_signed<PP>(s.lim, e, diag, Ar[PP], lane, res_i);
                 });
             }
         } else {
             if (lim_mask) {
                 static_for<ND>([&](auto ic) {
                     constexpr int PP = NC_ORDER[ND - 1 - decltype(ic)::value];
-                    if (lim_mask & (1u << PP)) pgs_row_signed<PP>(e, u_lim, rv, rv_lim, (real)0, lim_hi, Ar[PP], sgn_lim, lane, res_i);
+                    if (lim_mask & (1u << PP)) pgs_row_signed<PP>(s.lim, e, diag, Ar[PP], lane, res_i);
                 });
             }
             static_for<ND>([&](auto ic) { constexpr int PP = NC_ORDER[ND - 1 - decltype(ic)::value]; pgs_row2d<FAST, PP>(e, blo, bhi, dvec, Ar[PP], lane, res_i); });
@@ -953,22 +976,26 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                 if (act & (0xfu << (4 * f))) {
                     static_for<4>([&](auto ic) {
                         constexpr int c = 4 * f + decltype(ic)::value, PN = port_normal(c);
-                        if (act & (1u << c)) pgs_cone<PN>(e, u0, mul_rn_(nfcn, blo), jdi, diag, Ar[PN + 1], Ar[PN + 2], lane, res_i);
+                        if (act & (1u << c)) pgs_cone<PN>(e, u0, dvec, mul_rn_(nfcn, blo), jdi, diag, Ar[PN + 1], Ar[PN + 2], lane, res_i);
                     });
                 }
             });
+            u0 += dvec; dvec = 0;
         }
         if (res_i <= thr_i || it >= n_iter - 1) { it++; break; }
     }
     iters = it;
     // back to impulses: joint lanes u = -(mh + blo) (+ the limit row), normal lanes u = -blo, the rest explicit
     real lam_sum;
-    if (is_joint) lam_sum = (-(P.max_imp * diag) - blo + sgn_lim * u_lim) * jdi;
+    if (is_joint) lam_sum = (-(P.max_imp * diag) - blo + s.lim[2][p] * s.lim[3][p]) * jdi;
     else if (is_lin && pax == 0) lam_sum = -blo * jdi;
     else lam_sum = (u0 + u1 + u2 + u3) * jdi;
 
+    FRESH_LANE();
     // ---------------- H. apply impulses:  dv = L^-T (Y Lambda),  v = clamp(v* + dv) ----------------
     {
+        const real inv_diag_r = lane < NV ? s.col[k] : (real)0;    // 1/L[k][k], parked in LDS since phase E
+        const real vstar_r = lane < NV ? s.v[k] : (real)0;         // v* parked in LDS since phase D
         const real lamP = lam_sum;
         if (lane < NPORT) s.lamP[p] = lamP;
         WSYNC();
@@ -980,12 +1007,12 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         real x = 0;
 #pragma unroll
         for (int j = NV - 1; j >= 0; j--) {
-            const real t = z * inv_diag;
+            const real t = z * inv_diag_r;
             const real xj = bcast(t, j);
             if (lane == j) x = t;
             if (lane < j) z -= s.M[j][k] * xj;
         }
-        real vn = vstar + x;
+        real vn = vstar_r + x;
         vn = min_(max_(vn, -P.vmax), P.vmax);
         WSYNC();
         if (lane < NV) s.v[k] = vn;
@@ -994,6 +1021,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     }
     WSYNC();
     STAMP();
+    FRESH_LANE();
     // ---------------- I. integrate positions (btMultiBody::stepPositionsMultiDof) ----------------
     {
         const real w0 = s.v[0], w1 = s.v[1], w2 = s.v[2];
@@ -1018,6 +1046,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     }
     WSYNC();    STAMP();
 #undef STAMP
+#undef FRESH_LANE
 }
 
 // ================================================================================================
