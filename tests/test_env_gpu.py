@@ -330,3 +330,23 @@ def test_vector_td3_training_step(golden_dir):
     s, a, s2, r, nd = replay.sample(64)
     assert s.is_cuda and s.shape == (64, 26) and nd.min() >= 0 and nd.max() <= 1
     env.close()
+
+
+def test_shipped_policy_statistics(golden_dir):
+    """the reference's trained actor (checkpoint 3229999, trained in PyBullet) rolled through
+    this environment.  No per-step parity is possible (PyBullet absent, chaotic contact dynamics), but the
+    policy must transfer statistically: with a little action noise its episodes last several times longer
+    and score far higher than an untrained actor's, and its mean return is in the range the reference's own
+    training log ends at (last 1000 episodes: +50, results/plen_walk_gazebo_.npy)."""
+    from plen_ml_walk_amd.walk_eval import load_policy, evaluate
+    from plen_ml_walk_amd.td3 import TD3Agent
+    pol = load_policy(os.path.join(golden_dir, "policy_3229999.npz"))
+    res = evaluate(pol, 256, 1, torch.float32, action_noise=0.01, seed=0)
+    r, l = np.array(res["returns"]), np.array(res["lengths"])
+    assert len(r) == 256 and np.isfinite(r).all()
+    torch.manual_seed(0)
+    rnd = evaluate(TD3Agent(26, 18, 1.0, data_parallel=False), 256, 1, torch.float32, action_noise=0.01, seed=0)
+    r0, l0 = np.array(rnd["returns"]), np.array(rnd["lengths"])
+    assert l.mean() >= 100 and l.mean() >= 2.5 * l0.mean()
+    assert r.mean() >= -60 and r.mean() >= r0.mean() + 150
+    assert (l >= 500).mean() >= 0.03          # some episodes walk the whole 500 steps
