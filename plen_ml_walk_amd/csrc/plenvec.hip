@@ -59,6 +59,8 @@ struct DevParams {
     real margin, brk[2];
     real pts[2][4][3];
     real mdl[NB][28];   // JR9 | JT3 | axis3 | com3 | inertia xx yy zz xy xz yz | mass | pad3
+    real memb[NB][GEN_MAXMEMB][4];   // member links of each composite body: COM (body frame) | mass  (per-link linear damping)
+    int nmemb[NB];
     int num_iterations, max_episode_steps, joint_act, pad;
 };
 
@@ -536,12 +538,31 @@ __device__ __forceinline__ void body_dynamics(Smem<real> &s, const DevParams<rea
         real f[3], n[3], Iwv[3];
         const real g[3] = {0, 0, P.gz};
 #pragma unroll
-        for (int i = 0; i < 3; i++) f[i] = ms * (ac[i] - g[i]) + ms * vc[i] * (P.lin_damp + P.lin_damp * vn);
+        for (int i = 0; i < 3; i++) f[i] = ms * (ac[i] - g[i]);
+        (void)vn;
         matvec3(Iwv, Iw, w);
         cross3(t1, w, Iwv);
         matvec3(n, Iw, al);
 #pragma unroll
         for (int i = 0; i < 3; i++) n[i] += t1[i];
+        if (P.lin_damp > 0) {
+            // Bullet's linear damping acts on every LINK: m_i v_i (k + k |v_i|) at the link COM (joint_act mode only,
+            // plen_env.py:472-480).  Sum the member links' forces and their moments about this body's COM.
+            for (int i = 0; i < P.nmemb[b]; i++) {
+                real ci[3], vi[3], fi[3], arm[3];
+                matvec3(ci, R, P.memb[b][i]);
+                cross3(t1, w, ci);
+#pragma unroll
+                for (int q = 0; q < 3; q++) vi[q] = vo[q] + t1[q];
+                const real vin = sqrt_(dot3(vi, vi));
+                const real mi = P.memb[b][i][3] * mass_scale;
+#pragma unroll
+                for (int q = 0; q < 3; q++) { fi[q] = mi * vi[q] * (P.lin_damp + P.lin_damp * vin); arm[q] = ci[q] - e[q]; }
+                cross3(t1, arm, fi);
+#pragma unroll
+                for (int q = 0; q < 3; q++) { f[q] += fi[q]; n[q] += t1[q]; }
+            }
+        }
         real cO[3] = {c[0] - s.st[0], c[1] - s.st[1], c[2] - s.st[2]};
         cross3(t1, cO, f);
         const real cc = dot3(cO, cO);
@@ -1312,6 +1333,11 @@ static void fill_params(const PlenCfg &c, DevParams<real> &p) {
         for (int i = 0; i < 3; i++) { p.mdl[b][9 + i] = (real)GEN_JT[b][i]; p.mdl[b][12 + i] = (real)GEN_AXIS[b][i]; p.mdl[b][15 + i] = (real)GEN_COM[b][i]; }
         for (int i = 0; i < 6; i++) p.mdl[b][18 + i] = (real)GEN_INERTIA[b][i];
         p.mdl[b][24] = (real)GEN_MASS[b];
+        p.nmemb[b] = GEN_NMEMB[b];
+        for (int i = 0; i < GEN_MAXMEMB; i++) {
+            for (int c = 0; c < 3; c++) p.memb[b][i][c] = (real)GEN_MEMB_COM[b][3 * i + c];
+            p.memb[b][i][3] = (real)GEN_MEMB_MASS[b][i];
+        }
     }
     p.num_iterations = c.num_iterations; p.max_episode_steps = c.max_episode_steps; p.joint_act = c.joint_act;
 }

@@ -63,6 +63,7 @@ def bodies():
         B.R = np.array(b["R"], dtype=float).reshape(3, 3)
         B.t = np.array(b["t"], dtype=float)
         B.axis = np.array(b["axis"], dtype=float)
+        B.member_mass = np.array(b["member_mass"]); B.member_com = np.array(b["member_com"])
         out.append(B)
     return out
 
@@ -152,8 +153,15 @@ def mass_matrix_and_bias(pos, quat, omega, vel, q, qd, lin_damp=0.0):
         ac[b] = ao[b] + np.cross(al[b], e) + np.cross(om[b], np.cross(om[b], e))
     F = np.zeros((NB, 3)); N = np.zeros((NB, 3))
     for b in range(NB):
-        f = m[b] * (ac[b] - G) + m[b] * vc[b] * (lin_damp + lin_damp * np.linalg.norm(vc[b]))
+        f = m[b] * (ac[b] - G)
         n = Iw[b] @ al[b] + np.cross(om[b], Iw[b] @ om[b])
+        if lin_damp > 0:           # Bullet damps every LINK: m_i v_i (k + k|v_i|) at the link COM
+            for mi, ci in zip(BODIES[b].member_mass, BODIES[b].member_com):
+                cw = R[b] @ ci
+                vi = vo[b] + np.cross(om[b], cw)
+                fi = mi * vi * (lin_damp + lin_damp * np.linalg.norm(vi))
+                f = f + fi
+                n = n + np.cross(O[b] + cw - Cw[b], fi)
         F[b] = f
         N[b] = n + np.cross(Cw[b] - O0, f)
     for b in range(NB - 1, 0, -1):

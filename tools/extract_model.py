@@ -283,7 +283,9 @@ def main():
             tj = tb[p] + Rb[p] @ np.array(ml["t"])
             bd = dict(body=b, parent=body_of_link[p], link=ml["index"], R=Rj.tolist(), t=tj.tolist(), axis=ml["axis"])
         bd.update(mass=m, com=c.tolist(), inertia=[I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]],
-                  members=[x["name"] for _, x in members])
+                  members=[x["name"] for _, x in members],
+                  member_mass=[x["mass"] for _, x in members],
+                  member_com=[(tb[i] + Rb[i] @ np.array(x["com"])).tolist() for i, x in members])
         bodies.append(bd)
     assert abs(sum(b["mass"] for b in bodies) - total_mass) < 1e-12
 
@@ -382,6 +384,12 @@ def write_merged_header(m, path):
             f.write("#define GEN_%s_BODY %d\n" % (tag, body))
             f.write("static const double GEN_%s_POINTS[4][3] = {\n%s};\n" % (tag, carr([x for v in ft["points"] for x in v], nested=3)))
             f.write("static const double GEN_%s_BREAK = %r;\n" % (tag, ft["break_threshold"]))
+        nmax = max(len(b["member_mass"]) for b in B)
+        f.write("/* member links of every composite body (mass, COM in the body frame): Bullet applies its linear damping per LINK */\n")
+        f.write("#define GEN_MAXMEMB %d\n" % nmax)
+        f.write("static const int GEN_NMEMB[19] = {%s};\n" % ", ".join(str(len(b["member_mass"])) for b in B))
+        f.write("static const double GEN_MEMB_MASS[19][%d] = {\n%s};\n" % (nmax, carr([x for b in B for x in (b["member_mass"] + [0.0] * nmax)[:nmax]], nested=nmax)))
+        f.write("static const double GEN_MEMB_COM[19][%d] = {\n%s};\n" % (nmax * 3, carr([x for b in B for v in (b["member_com"] + [[0.0, 0.0, 0.0]] * nmax)[:nmax] for x in v], nested=nmax * 3)))
         f.write("static const double GEN_MARGIN = %r;\n" % m["margin"])
         lows = set(l["lower"] for l in m["links"] if l["jtype"] == 1); ups = set(l["upper"] for l in m["links"] if l["jtype"] == 1)
         assert len(lows) == 1 and len(ups) == 1, "the HIP path assumes one common joint limit"
