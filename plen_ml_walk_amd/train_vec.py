@@ -89,6 +89,7 @@ def main(argv=None):
     ap.add_argument("--replay", type=int, default=1000000)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--save", default=None, help="checkpoint prefix (reference 4-file layout)")
+    ap.add_argument("--graphs", type=int, default=1, help="capture collect/update in hipGraphs (single rank only)")
     a = ap.parse_args(argv)
     from .vec_env import PlenVecEnv
     from .td3 import ReplayBuffer, TD3Agent
@@ -101,7 +102,10 @@ def main(argv=None):
     agent = TD3Agent(26, 18, 1.0, device=dev)
     replay = ReplayBuffer(a.replay, device=dev)
     replay.seed(a.seed + rank)
-    tr = VecTD3Trainer(env, agent, replay, a.start_timesteps, 0.1, a.batch, a.updates_per_step, seed=1000 + rank)
+    if a.graphs and world == 1:
+        tr = GraphedVecTD3Trainer(env, agent, replay, a.start_timesteps, 0.1, a.batch, a.updates_per_step, seed=1000 + rank)
+    else:
+        tr = VecTD3Trainer(env, agent, replay, a.start_timesteps, 0.1, a.batch, a.updates_per_step, seed=1000 + rank)
     for _ in range(a.warmup):
         tr.step()
     torch.cuda.synchronize()
@@ -121,13 +125,134 @@ def main(argv=None):
     if rank == 0:
         print(json.dumps({"metric": "td3_env_steps_per_sec", "value": world * (tr.env_steps - e0) / dt, "unit": "env-steps/s",
                           "grad_steps_per_sec": (tr.grad_steps - g0) / dt, "n_gpus": world, "envs_per_gpu": a.envs, "batch": a.batch,
-                          "updates_per_step": a.updates_per_step, "steps": a.steps, "ms_per_step": dt / a.steps * 1e3,
+                          "updates_per_step": a.updates_per_step, "hip_graphs": bool(a.graphs and world == 1), "steps": a.steps, "ms_per_step": dt / a.steps * 1e3,
                           "critic_loss": float(agent.last_critic_loss) if agent.last_critic_loss is not None else None}))
         if a.save:
             agent.save(a.save)
     env.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+
+class GraphedVecTD3Trainer(object):
+    """The same loop as VecTD3Trainer with the launch-bound parts captured in hipGraphs (single rank):
+      collect graph : actor forward (+ exploration noise) or uniform random actions -> libplenvec step kernel
+                      (launched on the capturing stream through the C ABI) -> ring write into the replay tensors
+                      -> next state;
+      update graphs : replay sampling on device -> TD3 critic update (-> actor + target update every
+                      `policy_freq`-th call), Adam with capturable state.
+    Write position / fill level of the ring live in device scalars that the graphs advance; the host mirrors the
+    same arithmetic, so nothing synchronises.  Gradients are not all-reduced here: use VecTD3Trainer (eager
+    updates) when world_size > 1."""
+
+    def __init__(self, env, agent, replay, start_timesteps=10000, expl_noise=0.1, batch_size=4096, updates_per_step=1, seed=0):
+        import torch.nn.functional as F
+        assert agent.device.type == "cuda"
+        self.env, self.agent, self.replay = env, agent, replay
+        self.start_timesteps, self.expl_noise = start_timesteps, expl_noise
+        self.batch_size, self.updates_per_step = batch_size, updates_per_step
+        dev = agent.device
+        n = env.num_envs
+        self.n = n
+        torch.manual_seed(seed)
+        # capturable Adam (step counters on device)
+        agent.actor_optimizer = torch.optim.Adam(agent.actor.parameters(), lr=3e-4, capturable=True)
+        agent.critic_optimizer = torch.optim.Adam(agent.critic.parameters(), lr=3e-4, capturable=True)
+        self.state = env.reset().to(torch.float32).clone()
+        self.total_t = torch.zeros((), dtype=torch.long, device=dev)        # transitions written so far
+        self.arange_n = torch.arange(n, device=dev)
+        self.env_steps = 0
+        self.grad_steps = 0
+        self.host_total = 0
+        self._graphs = {}
+        self._warm_side_stream = torch.cuda.Stream(device=dev)
+
+        def collect(random_actions):
+            if random_actions:
+                action = torch.rand(n, 18, device=dev) * 2 - 1
+            else:
+                with torch.no_grad():
+                    action = agent.actor(self.state)
+                    action = (action + torch.randn_like(action) * (agent.max_action * expl_noise)).clamp(-agent.max_action, agent.max_action)
+            next_obs, reward, done, info = env.step(action)
+            idx = (self.total_t + self.arange_n) % replay.max_size
+            terminal = ((done & 1) != 0) & ((done & 2) == 0)
+            replay.state.index_copy_(0, idx, self.state)
+            replay.action.index_copy_(0, idx, action)
+            replay.next_state.index_copy_(0, idx, next_obs.to(torch.float32))
+            replay.reward.index_copy_(0, idx, reward.to(torch.float32).reshape(n, 1))
+            replay.not_done.index_copy_(0, idx, 1.0 - terminal.to(torch.float32).reshape(n, 1))
+            self.total_t += n
+            self.state.copy_(info["obs"])
+
+        def update(with_policy):
+            size_t = torch.clamp(self.total_t, max=replay.max_size)
+            ind = (torch.rand(batch_size, device=dev) * size_t).long().clamp_(max=replay.max_size - 1)
+            ind = torch.minimum(ind, size_t - 1)
+            state, action, next_state = replay.state[ind], replay.action[ind], replay.next_state[ind]
+            reward, not_done = replay.reward[ind], replay.not_done[ind]
+            with torch.no_grad():
+                noise = (torch.randn_like(action) * agent.policy_noise).clamp(-agent.noise_clip, agent.noise_clip)
+                next_action = (agent.actor_target(next_state) + noise).clamp(-agent.max_action, agent.max_action)
+                q1, q2 = agent.critic_target(next_state, next_action)
+                target_q = reward + not_done * agent.discount * torch.min(q1, q2)
+            cq1, cq2 = agent.critic(state, action)
+            critic_loss = F.mse_loss(cq1, target_q) + F.mse_loss(cq2, target_q)
+            agent._critic_grads.zero()
+            critic_loss.backward()
+            agent.critic_optimizer.step()
+            self._critic_loss.copy_(critic_loss.detach())
+            if with_policy:
+                actor_loss = -agent.critic.Q1(state, agent.actor(state)).mean()
+                agent._actor_grads.zero()
+                actor_loss.backward()
+                agent.actor_optimizer.step()
+                with torch.no_grad():
+                    for net, tgt in ((agent.critic, agent.critic_target), (agent.actor, agent.actor_target)):
+                        ps, ts = list(net.parameters()), list(tgt.parameters())
+                        torch._foreach_mul_(ts, 1 - agent.tau)
+                        torch._foreach_add_(ts, ps, alpha=agent.tau)
+
+        self._critic_loss = torch.zeros((), device=dev)
+        self._collect_fn, self._update_fn = collect, update
+
+    def _graph(self, key, fn, *args):
+        g = self._graphs.get(key)
+        if g is None:
+            # warm up on a side stream (allocations, lazy init), then capture
+            s = self._warm_side_stream
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(2):
+                    fn(*args)
+                    if key[0] == "collect":
+                        self.host_total += self.n; self.env_steps += self.n
+                    else:
+                        self.grad_steps += 1
+            torch.cuda.current_stream().wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn(*args)
+            self._graphs[key] = g
+            # the capture itself does not execute: no counters to advance
+            return g
+        return g
+
+    def step(self):
+        warm = self.host_total < self.start_timesteps
+        self._graph(("collect", warm), self._collect_fn, warm).replay()
+        self.host_total += self.n
+        self.env_steps += self.n
+        if self.host_total >= self.start_timesteps:
+            for _ in range(self.updates_per_step):
+                with_policy = (self.grad_steps + 1) % self.agent.policy_freq == 0
+                self._graph(("update", with_policy), self._update_fn, with_policy).replay()
+                self.grad_steps += 1
+                self.agent.total_it = self.grad_steps
+        self.replay.size = min(self.host_total, self.replay.max_size)
+        self.replay.ptr = self.host_total % self.replay.max_size if self.host_total >= self.replay.max_size else 0
+        self.agent.last_critic_loss = self._critic_loss
 
 
 if __name__ == "__main__":

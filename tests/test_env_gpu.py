@@ -360,3 +360,27 @@ def test_shipped_policy_statistics(golden_dir):
     assert l.mean() >= 100 and l.mean() >= 2.5 * l0.mean()
     assert r.mean() >= -60 and r.mean() >= r0.mean() + 150
     assert (l >= 500).mean() >= 0.03          # some episodes walk the whole 500 steps
+
+
+def test_graphed_trainer_matches_ring_semantics():
+    """hipGraph-captured collect/update loop: the replay ring fills exactly like the eager ReplayBuffer
+    (write position, size, done_bool masking) and the TD3 update produces finite losses."""
+    from plen_ml_walk_amd.td3 import ReplayBuffer, TD3Agent
+    from plen_ml_walk_amd.train_vec import GraphedVecTD3Trainer
+    n = 128
+    env = _env(n, torch.float32)
+    agent = TD3Agent(26, 18, 1.0)
+    replay = ReplayBuffer(1000)                   # small ring: wraps during the test
+    tr = GraphedVecTD3Trainer(env, agent, replay, start_timesteps=256, batch_size=128, updates_per_step=1, seed=0)
+    for _ in range(12):
+        tr.step()
+    torch.cuda.synchronize()
+    assert tr.env_steps == 12 * n and int(tr.total_t) == 12 * n
+    assert replay.size == 1000 and replay.ptr == (12 * n) % 1000
+    assert tr.grad_steps >= 9 and torch.isfinite(agent.last_critic_loss)
+    assert torch.isfinite(replay.state).all() and torch.isfinite(replay.reward).all()
+    nd = replay.not_done[:replay.size]
+    assert ((nd == 0) | (nd == 1)).all()
+    # terminal transitions carry the dead penalty, non-terminal ones do not
+    assert (replay.reward[:replay.size][nd == 0] < -50).all()
+    env.close()
