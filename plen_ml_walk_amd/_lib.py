@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libplenvec.so")
+# PLENVEC_LIB: developer override used by scripts/gpu_ab.py to time two builds of the kernel side by side
+LIB_PATH = os.environ.get("PLENVEC_LIB") or os.path.join(_HERE, "csrc", "libplenvec.so")
 
 OBS, ACT, STATE, DUMP = 26, 18, 49, 4096
 DTYPE_F32, DTYPE_F64 = 0, 1

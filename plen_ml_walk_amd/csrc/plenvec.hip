@@ -135,6 +135,18 @@ __device__ __forceinline__ float wrlane(float dst, float val, int lane) {
 template <int L>
 __device__ __forceinline__ double wrlane(double dst, double val, int lane) { return lane == L ? val : dst; }
 
+// lane i receives x[i-1] (lane 0 keeps its own): one DPP move for f32, the LDS crossbar for f64
+__device__ __forceinline__ float shift_up1(float x) {
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double shift_up1(double x) { return __shfl_up(x, 1); }
+// lane i receives x[src_i] through the LDS crossbar (no LDS storage involved)
+__device__ __forceinline__ float gather_lane(float x, int src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, x)));
+}
+__device__ __forceinline__ double gather_lane(double x, int src) { return __shfl(x, src); }
+
 // all 64 lanes of the single-wave workgroup see each other's LDS writes after this
 #define WSYNC() __syncthreads()
 
@@ -150,6 +162,19 @@ template <int... Is, typename F>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) { (f(std::integral_constant<int, Is>{}), ...); }
 template <int N, typename F>
 __device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+// rows of the contact points of both feet.  A foot in the air is skipped as a whole; inside a touching foot
+// every point is tested: at 4 waves per SIMD the kernel is VALU-issue bound (PMC: one VALU instruction per
+// 4 cycles, ~66% busy), so a taken scalar branch (latency only) is cheaper than a wasted no-op row, and
+// a separate straight-line copy for "all four points in range" only added register spills (measured).
+template <typename F>
+__device__ __forceinline__ void for_foot_points(const unsigned act, F &&row) {
+    static_for<2>([&](auto fc_) {
+        constexpr int f = decltype(fc_)::value;
+        const unsigned nib = (act >> (4 * f)) & 0xfu;
+        if (nib) static_for<4>([&](auto kc) { if (nib & (1u << decltype(kc)::value)) row(fc_, kc); });
+    });
+}
 
 static constexpr int NC_ORDER[ND] = {NC_ORDER_LIST};
 __host__ __device__ constexpr int port_normal(int c) { return 18 + 15 * (c / 4) + 3 + 3 * (c % 4); }
@@ -169,37 +194,11 @@ __device__ __forceinline__ unsigned absbits(double x) { return __builtin_bit_cas
 // (s_lshl_b64 exec, 1, PP) instead of keeping 48 lane masks alive.  The compiler path does the same
 // arithmetic in the same order; tests assert the two are bit-identical.
 // ------------------------------------------------------------------------------------------------
-template <bool FAST, int PP, typename real>
-__device__ __forceinline__ void pgs_row2(real &e, real &blo, real &bhi, const real acol, const int lane, unsigned &res_i) {
-    if constexpr (FAST && sizeof(real) == 4) {
-        float d;
-        int sd;
-        asm volatile(
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "s_lshl_b64 exec, 1, %[pp]\n\t"
-            "v_readlane_b32 %[sd], %[d], %[pp]\n\t"
-            "v_sub_f32 %[blo], %[blo], %[d]\n\t"
-            "v_sub_f32 %[bhi], %[bhi], %[d]\n\t"
-            "s_mov_b64 exec, -1\n\t"
-            "v_fmac_f32 %[e], %[sd], %[a]\n\t"
-            : [d] "=&v"(d), [sd] "=&s"(sd), [blo] "+v"(blo), [bhi] "+v"(bhi), [e] "+v"(e)
-            : [a] "v"(acol), [pp] "i"(PP));
-        res_i = max(res_i, (unsigned)sd & 0x7fffffffu);
-    } else {
-#pragma clang fp contract(off)
-        const real d = min_(max_(-e, blo), bhi);
-        if (lane == PP) { blo -= d; bhi -= d; }
-        const real db = bcast(d, PP);
-        res_i = max(res_i, absbits(db));
-        e = fma_(db, acol, e);
-    }
-}
-
 // Deferred-commit forms: the row's delta is dropped into lane PP of `dvec` with v_writelane (no EXEC
 // narrowing); the caller applies  blo -= dvec (bhi -= dvec)  once after the pass.  Valid because a
 // lane hosts at most one such row per pass.
 template <bool FAST, int PP, typename real>
-__device__ __forceinline__ void pgs_row2d(real &e, const real blo, const real bhi, real &dvec, const real acol, const int lane, unsigned &res_i) {
+__device__ __forceinline__ void pgs_row2d(real &e, const real blo, const real bhi, real &dvec, const real acol, const int lane) {
     if constexpr (FAST && sizeof(real) == 4) {
         float d;
         int sd;
@@ -212,18 +211,16 @@ __device__ __forceinline__ void pgs_row2d(real &e, const real blo, const real bh
             "v_fmac_f32 %[e], %[sd], %[a]\n\t"
             : [d] "=&v"(d), [sd] "=&s"(sd), [dv] "+v"(dvec), [e] "+v"(e)
             : [blo] "v"(blo), [bhi] "v"(bhi), [a] "v"(acol), [pp] "i"(PP));
-        res_i = max(res_i, (unsigned)sd & 0x7fffffffu);
     } else {
 #pragma clang fp contract(off)
         const real d = min_(max_(-e, blo), bhi);
         const real db = bcast(d, PP);
         if (lane == PP) dvec = db;
-        res_i = max(res_i, absbits(db));
         e = fma_(db, acol, e);
     }
 }
 template <bool FAST, int PP, typename real>
-__device__ __forceinline__ void pgs_row1d(real &e, const real blo, real &dvec, const real acol, const int lane, unsigned &res_i) {
+__device__ __forceinline__ void pgs_row1d(real &e, const real blo, real &dvec, const real acol, const int lane) {
     if constexpr (FAST && sizeof(real) == 4) {
         float d;
         int sd;
@@ -236,70 +233,11 @@ __device__ __forceinline__ void pgs_row1d(real &e, const real blo, real &dvec, c
             "v_fmac_f32 %[e], %[sd], %[a]\n\t"
             : [d] "=&v"(d), [sd] "=&s"(sd), [dv] "+v"(dvec), [e] "+v"(e)
             : [blo] "v"(blo), [a] "v"(acol), [pp] "i"(PP));
-        res_i = max(res_i, (unsigned)sd & 0x7fffffffu);
     } else {
 #pragma clang fp contract(off)
         const real d = max_(-e, blo);
         const real db = bcast(d, PP);
         if (lane == PP) dvec = db;
-        res_i = max(res_i, absbits(db));
-        e = fma_(db, acol, e);
-    }
-}
-
-// one-sided row (contact normal: lambda >= 0, Bullet's upper limit 1e10 is never reached): blo = -u
-template <bool FAST, int PP, typename real>
-__device__ __forceinline__ void pgs_row1(real &e, real &blo, const real acol, const int lane, unsigned &res_i) {
-    if constexpr (FAST && sizeof(real) == 4) {
-        float d;
-        int sd;
-        asm volatile(
-            "v_max_f32 %[d], -%[e], %[blo]\n\t"
-            "s_lshl_b64 exec, 1, %[pp]\n\t"
-            "v_readlane_b32 %[sd], %[d], %[pp]\n\t"
-            "v_sub_f32 %[blo], %[blo], %[d]\n\t"
-            "s_mov_b64 exec, -1\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f32 %[e], %[sd], %[a]\n\t"
-            : [d] "=&v"(d), [sd] "=&s"(sd), [blo] "+v"(blo), [e] "+v"(e)
-            : [a] "v"(acol), [pp] "i"(PP));
-        res_i = max(res_i, (unsigned)sd & 0x7fffffffu);
-    } else {
-#pragma clang fp contract(off)
-        const real d = max_(-e, blo);
-        if (lane == PP) blo -= d;
-        const real db = bcast(d, PP);
-        res_i = max(res_i, absbits(db));
-        e = fma_(db, acol, e);
-    }
-}
-
-// symmetric row with a bound that changes every visit (torsional friction: |lambda| <= mu * lambda_n): explicit u
-template <bool FAST, int PP, typename real>
-__device__ __forceinline__ void pgs_rowT(real &e, real &u, const real lim, const real acol, const int lane, unsigned &res_i) {
-    if constexpr (FAST && sizeof(real) == 4) {
-        float d, t1, t2;
-        int sd;
-        asm volatile(
-            "v_add_f32 %[t1], %[lim], %[u]\n\t"
-            "v_sub_f32 %[t2], %[lim], %[u]\n\t"
-            "v_med3_f32 %[d], -%[e], -%[t1], %[t2]\n\t"
-            "s_lshl_b64 exec, 1, %[pp]\n\t"
-            "v_readlane_b32 %[sd], %[d], %[pp]\n\t"
-            "v_add_f32 %[u], %[u], %[d]\n\t"
-            "s_mov_b64 exec, -1\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f32 %[e], %[sd], %[a]\n\t"
-            : [d] "=&v"(d), [t1] "=&v"(t1), [t2] "=&v"(t2), [sd] "=&s"(sd), [u] "+v"(u), [e] "+v"(e)
-            : [lim] "v"(lim), [a] "v"(acol), [pp] "i"(PP));
-        res_i = max(res_i, (unsigned)sd & 0x7fffffffu);
-    } else {
-#pragma clang fp contract(off)
-        const real t1 = lim + u, t2 = lim - u;
-        const real d = min_(max_(-e, -t1), t2);
-        if (lane == PP) u += d;
-        const real db = bcast(d, PP);
-        res_i = max(res_i, absbits(db));
         e = fma_(db, acol, e);
     }
 }
@@ -307,7 +245,7 @@ __device__ __forceinline__ void pgs_rowT(real &e, real &u, const real lim, const
 // torsional row with bounds prepared by the caller for this pass (nt1 = -(lim + u), t2 = lim - u) and a
 // deferred commit (u += dvec after the pass): med3 -> readlane -> writelane -> fmac
 template <bool FAST, int PP, typename real>
-__device__ __forceinline__ void pgs_rowTd(real &e, const real nt1, const real t2, real &dvec, const real acol, const int lane, unsigned &res_i) {
+__device__ __forceinline__ void pgs_rowTd(real &e, const real nt1, const real t2, real &dvec, const real acol, const int lane) {
     if constexpr (FAST && sizeof(real) == 4) {
         float d;
         int sd;
@@ -320,13 +258,11 @@ __device__ __forceinline__ void pgs_rowTd(real &e, const real nt1, const real t2
             "v_fmac_f32 %[e], %[sd], %[a]\n\t"
             : [d] "=&v"(d), [sd] "=&s"(sd), [dv] "+v"(dvec), [e] "+v"(e)
             : [nt1] "v"(nt1), [t2] "v"(t2), [a] "v"(acol), [pp] "i"(PP));
-        res_i = max(res_i, (unsigned)sd & 0x7fffffffu);
     } else {
 #pragma clang fp contract(off)
         const real d = min_(max_(-e, nt1), t2);
         const real db = bcast(d, PP);
         if (lane == PP) dvec = db;
-        res_i = max(res_i, absbits(db));
         e = fma_(db, acol, e);
     }
 }
@@ -348,29 +284,27 @@ __device__ __forceinline__ void pgs_row_signed(real (&lim)[4][NV], real &e, cons
 }
 
 // cone-coupled lateral friction pair of the contact point with normal port PN (rows at PN+1, PN+2),
-// btMultiBodyConstraintSolver::resolveConeFrictionConstraintRows, evaluated in lambda space.
-//   limn (valid in lane PN) = mu * lambda_n;  u (lanes PA, PB) = lambda * diag of the two rows
+// btMultiBodyConstraintSolver::resolveConeFrictionConstraintRows.
+//   u (lanes PA, PB) = lambda * diag of the two rows;  lmv (lanes PA, PB) = mu * lambda_n of their point
+// The candidate impulses are broadcast, the radial projection onto the friction circle is evaluated in
+// the two lanes themselves: new u = (u - e) * scale, scale = min(1, lm / |s|).
 template <int PN, typename real>
-__device__ __forceinline__ void pgs_cone(real &e, const real u, real &dvec, const real limn, const real jdi, const real diag, const real aA, const real aB,
-                                         const int lane, unsigned &res_i) {
+__device__ __forceinline__ void pgs_cone(real &e, const real u, real &dvec, real &resv, const real lmv, const real jdi, const real aA, const real aB,
+                                         const int lane) {
 #pragma clang fp contract(off)      // same roundings in every instantiation: fused ops are written out
     constexpr int PA = PN + 1, PB = PN + 2;
-    const real s = (u - e) * jdi;                   // candidate lambda of this lane's row
+    const real w = u - e;                           // candidate lambda * diag of this lane's row
+    const real s = w * jdi;                         // candidate lambda
     const real sA = bcast(s, PA), sB = bcast(s, PB);
-    const real lm = bcast(limn, PN);
     const real len2 = fma_(sA, sA, sB * sB);
-    real scale = 1;
-    if (len2 >= lm * lm) {
-        // Bullet clamps row A to |lim*sin(atan2(sA,sB))| and row B to |lim*cos(..)|: a radial projection onto the circle
-        if constexpr (sizeof(real) == 4) scale = len2 > 0 ? lm * __builtin_amdgcn_rsqf(len2) : 0.0f;   // 1 ulp, f32 path only
-        else scale = len2 > 0 ? lm / sqrt_(len2) : (real)0;
-        scale = abs_(scale);
-    }
-    const real n = s * scale;                       // lane-local: the new lambda of this lane's row (len2 == 0 -> s == 0)
-    const real d = fma_(n, diag, -u);               // deltaVel of this lane's row
+    real scale;
+    // Bullet clamps row A to |lim*sin(atan2(sA,sB))| and row B to |lim*cos(..)|: a radial projection onto the circle
+    if constexpr (sizeof(real) == 4) scale = min_(1.0f, lmv * __builtin_amdgcn_rsqf(len2));   // 0*inf = NaN -> 1 (s == 0 then); 1 ulp, f32 path only
+    else scale = len2 >= lmv * lmv ? (len2 > 0 ? lmv / sqrt_(len2) : (real)0) : (real)1;
+    const real d = fma_(w, scale, -u);              // deltaVel of this lane's row
     const real dA = bcast(d, PA), dB = bcast(d, PB);
     dvec = wrlane<PA>(dvec, dA, lane); dvec = wrlane<PB>(dvec, dB, lane);     // u += dvec after the pass (no lane masks kept alive)
-    res_i = max(res_i, absbits(dA + dB));
+    resv = max_(resv, abs_(dA + dB));
     e = fma_(dB, aB, fma_(dA, aA, e));
 }
 
@@ -620,6 +554,11 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     // phase stamps (shader clock) into the debug dump: diagnostic only, never in the timed path
     int stamp_i = 0;
     long long stamp_t0 = 0;
+#ifdef PGS_STAMPS      // profiling build only: shader-clock stamps inside PGS iteration 3 and 4
+#define ISTAMP(k_) do { if (dump && (it == 3 || it == 4)) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); if (lane == 0) dump[3820 + 10 * (it - 3) + (k_)] = (real)(double)(t_ - stamp_t0); } } while (0)
+#else
+#define ISTAMP(k_) do { } while (0)
+#endif
 #define STAMP() do { if (dump) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); if (stamp_i == 0) stamp_t0 = t_; if (lane == 0) dump[3800 + stamp_i] = (real)(double)(t_ - stamp_t0); stamp_i++; } } while (0)
     STAMP();
     // ---------------- A. kinematics, inertias, bias ----------------
@@ -886,6 +825,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         real pos_err = 0, vel_err = rest - bvel;
         if (distance > 0) vel_err -= distance * P.inv_dt; else pos_err = -distance * P.erp2 * P.inv_dt;
         rv = (pos_err + vel_err) * dis;
+        bhi = cp_active ? (real)1e30 : (real)0;    // lambda_n in [0, 1e10] (never reached); a point out of range gets (0, 0): its row is a no-op
     } else if (lane < NPORT) {
         rv = (0 - bvel) * dis;
     }
@@ -900,12 +840,14 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         const int pn0 = 18 + 15 * pf + 3;
         fc0 = mu * s.lamP[pn0]; fc1 = mu * s.lamP[pn0 + 3]; fc2 = mu * s.lamP[pn0 + 6]; fc3 = mu * s.lamP[pn0 + 9];
     }
+    const int tors_src = 18 + 15 * pf + 3;                    // lane of the first normal port of this lane's foot
     const real nfcn = (is_lin && pax == 0) ? -mu_lat * jdi : (real)0;   // lane PN: mu_lat * lambda_n = nfcn * blo
 
     real e = -rv;                  // e = J_port * deltaV - rv
     real dvec = 0;                 // per-pass deltas of the rows hosted by this lane (deferred commit)
     unsigned res_i = 0;            // wave-uniform running max |deltaVel| of this iteration (IEEE bits, non-negative)
-    const unsigned thr_i = __builtin_bit_cast(unsigned, (float)sqrt((double)P.res_thr));
+    const float thr_f = (float)sqrt((double)P.res_thr);
+    const unsigned thr_i = __builtin_bit_cast(unsigned, thr_f);
 
     // loop-invariant parameters into registers (a reference into global memory would be re-read every iteration)
     const int n_iter = __builtin_amdgcn_readfirstlane(P.num_iterations);
@@ -914,10 +856,12 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     int it = 0;
     for (it = 0; it < n_iter; it++) {
         res_i = 0;
+        ISTAMP(0);
+        real resv = 0;           // per-lane |deltaVel| of the rows this lane hosted in this iteration (from the deferred deltas)
         // -- non-contact rows: sorted order (motors, then limits) on odd iterations, reversed on even ones --
         if (it & 1) {
-            static_for<ND>([&](auto ic) { constexpr int PP = NC_ORDER[decltype(ic)::value]; pgs_row2d<FAST, PP>(e, blo, bhi, dvec, Ar[PP], lane, res_i); });
-            blo -= dvec; bhi -= dvec; dvec = 0;
+            static_for<ND>([&](auto ic) { constexpr int PP = NC_ORDER[decltype(ic)::value]; pgs_row2d<FAST, PP>(e, blo, bhi, dvec, Ar[PP], lane); });
+            blo -= dvec; bhi -= dvec; resv = max_(resv, abs_(dvec)); dvec = 0;
             if (lim_mask) {
                 static_for<ND>([&](auto ic) {
                     constexpr int PP = NC_ORDER[decltype(ic)::value];
@@ -931,79 +875,74 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                     if (lim_mask & (1u << PP)) pgs_row_signed<PP>(s.lim, e, diag, Ar[PP], lane, res_i);
                 });
             }
-            static_for<ND>([&](auto ic) { constexpr int PP = NC_ORDER[ND - 1 - decltype(ic)::value]; pgs_row2d<FAST, PP>(e, blo, bhi, dvec, Ar[PP], lane, res_i); });
-            blo -= dvec; bhi -= dvec; dvec = 0;
+            static_for<ND>([&](auto ic) { constexpr int PP = NC_ORDER[ND - 1 - decltype(ic)::value]; pgs_row2d<FAST, PP>(e, blo, bhi, dvec, Ar[PP], lane); });
+            blo -= dvec; bhi -= dvec; resv = max_(resv, abs_(dvec)); dvec = 0;
         }
+        ISTAMP(1);
         if (act) {     // airborne: one branch skips every contact row
             // Bullet's order is type-major: all normals, all spinning, all rolling, all lateral pairs.  Taken
             // scalar branches cost ~30 cycles each, so inactive points are skipped a whole foot at a time.
             // -- normal rows (manifold order: right foot points, then left foot points) --
-            static_for<2>([&](auto fc_) {
-                constexpr int f = decltype(fc_)::value;
-                if (act & (0xfu << (4 * f))) {
-                    static_for<4>([&](auto ic) {
-                        constexpr int c = 4 * f + decltype(ic)::value, PP = port_normal(c);
-                        if (act & (1u << c)) pgs_row1d<FAST, PP>(e, blo, dvec, Ar[PP], lane, res_i);
-                    });
-                }
+            // (points out of range carry blo = bhi = 0 and mu*lambda_n = 0: their rows would be exact no-ops)
+            for_foot_points(act, [&](auto fc_, auto kc) {
+                constexpr int PP = port_normal(4 * decltype(fc_)::value + decltype(kc)::value);
+                pgs_row2d<FAST, PP>(e, blo, bhi, dvec, Ar[PP], lane);
             });
-            blo -= dvec; dvec = 0;
+            blo -= dvec; resv = max_(resv, abs_(dvec)); dvec = 0;     // bhi of a normal row is 1e30 or 0: unchanged
+            ISTAMP(2);
             // -- torsional friction: spinning rows (all points), then rolling rows (all points) --
             // Bounds of a point's three torsional rows (spin lane, two roll lanes; each lane has its own
             // mu*diag/diag_n coefficient fck and its own impulse uk) are prepared ONCE per iteration, for all
             // three lanes at the same time: lim = fck * (-u_n), nt1 = -(lim + uk), t2 = lim - uk.  Valid
-            // because u_n only changes in the normal pass and uk only at its own row.
+            // because u_n only changes in the normal pass and uk only at its own row.  Bullet skips the row
+            // while the normal impulse is not positive: bounds (0, 0) leave e and uk untouched.
             if (has_spin || has_roll) {
-                real nbv0 = 0, nbv1 = 0, nbv2 = 0, nbv3 = 0;     // -u_n of point k of THIS lane's foot
-                unsigned posmask = 0;                             // points whose normal impulse is positive
-                static_for<8>([&](auto ic) {
-                    constexpr int c = decltype(ic)::value, k = c % 4, f = c / 4, PN = port_normal(c);
-                    if (act & (1u << c)) {
-                        const real nb = bcast(blo, PN);
-                        if (nb < 0) posmask |= 1u << c;
-                        real &nbv = k == 0 ? nbv0 : k == 1 ? nbv1 : k == 2 ? nbv2 : nbv3;
-                        if (pf == f) nbv = nb;
-                    }
-                });
+                const real nbv0 = gather_lane(blo, tors_src), nbv1 = gather_lane(blo, tors_src + 3);
+                const real nbv2 = gather_lane(blo, tors_src + 6), nbv3 = gather_lane(blo, tors_src + 9);     // -u_n of point k of this lane's foot
                 const real lim0 = mul_rn_(fc0, nbv0), lim1 = mul_rn_(fc1, nbv1), lim2 = mul_rn_(fc2, nbv2), lim3 = mul_rn_(fc3, nbv3);
-                const real nt10 = -(lim0 + u0), nt11 = -(lim1 + u1), nt12 = -(lim2 + u2), nt13 = -(lim3 + u3);
-                const real t20 = lim0 - u0, t21 = lim1 - u1, t22 = lim2 - u2, t23 = lim3 - u3;
+                const real nt10 = nbv0 < 0 ? -(lim0 + u0) : (real)0, nt11 = nbv1 < 0 ? -(lim1 + u1) : (real)0;
+                const real nt12 = nbv2 < 0 ? -(lim2 + u2) : (real)0, nt13 = nbv3 < 0 ? -(lim3 + u3) : (real)0;
+                const real t20 = nbv0 < 0 ? lim0 - u0 : (real)0, t21 = nbv1 < 0 ? lim1 - u1 : (real)0;
+                const real t22 = nbv2 < 0 ? lim2 - u2 : (real)0, t23 = nbv3 < 0 ? lim3 - u3 : (real)0;
                 real dv0 = 0, dv1 = 0, dv2 = 0, dv3 = 0;
+                ISTAMP(3);
                 if (has_spin) {
-                    static_for<8>([&](auto ic) {
-                        constexpr int c = decltype(ic)::value, k = c % 4, PP = 18 + 15 * (c / 4);
-                        if (posmask & (1u << c)) {                   // Bullet: only while the normal impulse is positive
-                            pgs_rowTd<FAST, PP>(e, k == 0 ? nt10 : k == 1 ? nt11 : k == 2 ? nt12 : nt13, k == 0 ? t20 : k == 1 ? t21 : k == 2 ? t22 : t23,
-                                                k == 0 ? dv0 : k == 1 ? dv1 : k == 2 ? dv2 : dv3, Ar[PP], lane, res_i);
-                        }
+                    for_foot_points(act, [&](auto fc_, auto kc) {
+                        constexpr int k = decltype(kc)::value, PP = 18 + 15 * decltype(fc_)::value;
+                        pgs_rowTd<FAST, PP>(e, k == 0 ? nt10 : k == 1 ? nt11 : k == 2 ? nt12 : nt13, k == 0 ? t20 : k == 1 ? t21 : k == 2 ? t22 : t23,
+                                            k == 0 ? dv0 : k == 1 ? dv1 : k == 2 ? dv2 : dv3, Ar[PP], lane);
                     });
                 }
+                ISTAMP(4);
                 if (has_roll) {
-                    static_for<8>([&](auto ic) {
-                        constexpr int c = decltype(ic)::value, k = c % 4, PP = 18 + 15 * (c / 4);
-                        if (posmask & (1u << c)) {
-                            pgs_rowTd<FAST, PP + 1>(e, k == 0 ? nt10 : k == 1 ? nt11 : k == 2 ? nt12 : nt13, k == 0 ? t20 : k == 1 ? t21 : k == 2 ? t22 : t23,
-                                                    k == 0 ? dv0 : k == 1 ? dv1 : k == 2 ? dv2 : dv3, Ar[PP + 1], lane, res_i);
-                            pgs_rowTd<FAST, PP + 2>(e, k == 0 ? nt10 : k == 1 ? nt11 : k == 2 ? nt12 : nt13, k == 0 ? t20 : k == 1 ? t21 : k == 2 ? t22 : t23,
-                                                    k == 0 ? dv0 : k == 1 ? dv1 : k == 2 ? dv2 : dv3, Ar[PP + 2], lane, res_i);
-                        }
+                    for_foot_points(act, [&](auto fc_, auto kc) {
+                        constexpr int k = decltype(kc)::value, PP = 18 + 15 * decltype(fc_)::value;
+                        pgs_rowTd<FAST, PP + 1>(e, k == 0 ? nt10 : k == 1 ? nt11 : k == 2 ? nt12 : nt13, k == 0 ? t20 : k == 1 ? t21 : k == 2 ? t22 : t23,
+                                                k == 0 ? dv0 : k == 1 ? dv1 : k == 2 ? dv2 : dv3, Ar[PP + 1], lane);
+                        pgs_rowTd<FAST, PP + 2>(e, k == 0 ? nt10 : k == 1 ? nt11 : k == 2 ? nt12 : nt13, k == 0 ? t20 : k == 1 ? t21 : k == 2 ? t22 : t23,
+                                                k == 0 ? dv0 : k == 1 ? dv1 : k == 2 ? dv2 : dv3, Ar[PP + 2], lane);
                     });
                 }
                 u0 += dv0; u1 += dv1; u2 += dv2; u3 += dv3;
+                resv = max_(resv, max_(max_(abs_(dv0), abs_(dv1)), max_(abs_(dv2), abs_(dv3))));
             }
+            ISTAMP(5);
             // -- lateral friction, cone-coupled pairs --
-            static_for<2>([&](auto fc_) {
-                constexpr int f = decltype(fc_)::value;
-                if (act & (0xfu << (4 * f))) {
-                    static_for<4>([&](auto ic) {
-                        constexpr int c = 4 * f + decltype(ic)::value, PN = port_normal(c);
-                        if (act & (1u << c)) pgs_cone<PN>(e, u0, dvec, mul_rn_(nfcn, blo), jdi, diag, Ar[PN + 1], Ar[PN + 2], lane, res_i);
-                    });
-                }
-            });
+            {
+                // mu * lambda_n of each point, moved from its normal lane PN into the pair's lanes PN+1, PN+2
+                const real l1 = shift_up1(mul_rn_(nfcn, blo)), l2 = shift_up1(l1);
+                const real lmv = pax == 1 ? l1 : l2;
+                for_foot_points(act, [&](auto fc_, auto kc) {
+                    constexpr int PN = port_normal(4 * decltype(fc_)::value + decltype(kc)::value);
+                    pgs_cone<PN>(e, u0, dvec, resv, lmv, jdi, Ar[PN + 1], Ar[PN + 2], lane);
+                });
+            }
             u0 += dvec; dvec = 0;
         }
-        if (res_i <= thr_i || it >= n_iter - 1) { it++; break; }
+        ISTAMP(6);
+        ISTAMP(7);
+        // Bullet's leastSquaresResidual <= threshold: the rare scalar rows (limits) in res_i, every other row in resv
+        if ((res_i <= thr_i && __ballot((float)resv > thr_f) == 0) || it >= n_iter - 1) { it++; break; }
     }
     iters = it;
     // back to impulses: joint lanes u = -(mh + blo) (+ the limit row), normal lanes u = -blo, the rest explicit
@@ -1067,6 +1006,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     }
     WSYNC();    STAMP();
 #undef STAMP
+#undef ISTAMP
 #undef FRESH_LANE
 }
 
