@@ -74,6 +74,16 @@ __device__ __constant__ unsigned c_anc[NV] = {
     0x3f | (1u << 12), 0x3f | (3u << 12), 0x3f | (7u << 12), 0x3f | (15u << 12), 0x3f | (31u << 12), 0x3f | (63u << 12),
     0x3f | (1u << 18), 0x3f | (3u << 18), 0x3f | (7u << 18),
     0x3f | (1u << 21), 0x3f | (3u << 21), 0x3f | (7u << 21)};
+// the same masks at compile time: the factorization below only touches structurally nonzero entries
+static constexpr unsigned ANC[NV] = {
+    0x3f, 0x3f, 0x3f, 0x3f, 0x3f, 0x3f,
+    0x3f | (1u << 6), 0x3f | (3u << 6), 0x3f | (7u << 6), 0x3f | (15u << 6), 0x3f | (31u << 6), 0x3f | (63u << 6),
+    0x3f | (1u << 12), 0x3f | (3u << 12), 0x3f | (7u << 12), 0x3f | (15u << 12), 0x3f | (31u << 12), 0x3f | (63u << 12),
+    0x3f | (1u << 18), 0x3f | (3u << 18), 0x3f | (7u << 18),
+    0x3f | (1u << 21), 0x3f | (3u << 21), 0x3f | (7u << 21)};
+// L[r][i] of the factor M = L^T L can be nonzero only when DoF i (< r) supports DoF r
+static constexpr bool l_nz(int r, int i) { return i < r && ((ANC[r] >> i) & 1u); }
+static constexpr bool has_desc(int i) { for (int r = i + 1; r < NV; r++) if (l_nz(r, i)) return true; return false; }
 // plen_env.py:148-167
 __device__ __constant__ double c_range_lo[ND] = {-1.57, -0.15, -0.95, -0.9, -0.95, -0.8, -1.57, -1.5, -0.75, -0.3, -1.2, -0.4, -1.57, -0.15, -0.2, -1.57, -0.15, -0.2};
 __device__ __constant__ double c_range_hi[ND] = {1.57, 1.5, 0.75, 0.3, 1.2, 0.4, 1.57, 0.15, 0.95, 0.9, 0.95, 0.8, 1.57, 1.57, 0.35, 1.57, 1.57, 0.35};
@@ -338,7 +348,7 @@ struct Smem {
             real S[NV][8];      // motion subspace about the base origin: [angular; linear]
             real tau[NV];
         };
-        alignas(16) real YT[NV][YTS];  // J, then Y = L^-1 J^T, coordinate-major: YT[j][port]
+        alignas(16) real YT[NV][YTS];  // J, then Y = L^-T J^T, coordinate-major: YT[j][port]
     };
 };
 
@@ -599,10 +609,10 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
 #pragma unroll
         for (int r = 0; r < NV; r++) {
             real val = s.S[r][0] * n[0] + s.S[r][1] * n[1] + s.S[r][2] * n[2] + s.S[r][3] * f[0] + s.S[r][4] * f[1] + s.S[r][5] * f[2];
-            if (r <= k) {
+            if (r <= k) {          // upper triangle only: phase C factors it in place, rows = lanes
                 if (!((anc >> r) & 1u)) val = 0;
                 s.M[r][k] = val;
-                s.M[k][r] = val;
+                if (r < k) s.M[k][r] = 0;
             }
         }
         // generalized bias force (motors are constraints, so no joint torque here)
@@ -620,56 +630,64 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     WSYNC();
     if (dump && lane < NV) {
 #pragma unroll
-        for (int r = 0; r < NV; r++) dump[r * NV + lane] = s.M[r][lane];
+        for (int r = 0; r < NV; r++) dump[r * NV + lane] = r <= lane ? s.M[r][lane] : s.M[lane][r];
         dump[576 + lane] = s.tau[lane];
     }
 
     STAMP();
     FRESH_LANE();
-    // ---------------- C. Cholesky  M = L L^T, row `lane` in registers ----------------
+    // ---------------- C. sparse factorization  M = L^T L  (Featherstone's LTL), column `lane` of L in registers ----
+    // Processing the DoFs leaves-first keeps the branch-induced sparsity of M: L[r][i] != 0 only if DoF i
+    // supports DoF r (159 entries instead of 276), and no fill-in.  Lane i holds X[i][r] = L[r][i]; the
+    // diagonal is kept as its reciprocal (inv_diag) and stored as 0, which makes every triangular solve
+    // below a plain  broadcast + fma  per column, without lane predicates.
     real Lr[NV];
 #pragma unroll
     for (int j = 0; j < NV; j++) Lr[j] = lane < NV ? s.M[k][j] : (real)0;
-    real inv_diag = 0;      // 1 / L[lane][lane]
-#pragma unroll
-    for (int j = 0; j < NV; j++) {
-        const real djj = bcast(Lr[j], j);
-        const real d = sqrt_(djj), rd = (real)1 / d;
-        real lij = Lr[j] * rd;
-        if (lane == j) { lij = d; inv_diag = rd; }
-        if (lane < j) lij = 0;
-        Lr[j] = lij;
-        // trailing update M[i][c] -= L[i][j] L[c][j]; column j is broadcast lane by lane (no LDS round trip)
-#pragma unroll
-        for (int c = j + 1; c < NV; c++) Lr[c] -= lij * bcast(lij, c);
-    }
+    static_for<NV>([&](auto kc) {
+        constexpr int K = NV - 1 - decltype(kc)::value;
+        const real piv = bcast(Lr[K], K);
+        real rd;
+        if constexpr (sizeof(real) == 4) rd = __builtin_amdgcn_rsqf(piv);       // 1 ulp; f32 path only
+        else rd = (real)1 / sqrt_(piv);
+        if (lane == 0) s.col[K] = rd;                      // collected below: every lane needs its own 1/L[k][k]
+        const real lik = lane < K ? Lr[K] * rd : (real)0;      // L[K][i] in lane i < K; zero on and below the diagonal of L^T
+        Lr[K] = lik;
+        // trailing update X[i][j] -= L[K][i] L[K][j] for the supporting DoFs j < K
+        static_for<K>([&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            if constexpr (l_nz(K, J)) Lr[J] -= lik * bcast(lik, J);
+        });
+    });
     if (lane < NV) {
 #pragma unroll
-        for (int j = 0; j < NV; j++) s.M[k][j] = Lr[j];
+        for (int j = 0; j < NV; j++) s.M[k][j] = Lr[j];      // s.M[i][r] = L[r][i] (strictly upper part of L^T, zero diagonal)
     }
+    WSYNC();
+    const real inv_diag = lane < NV ? s.col[k] : (real)0;    // 1 / L[lane][lane]
     STAMP();
     FRESH_LANE();
-    // ---------------- D. unconstrained velocity update  v* = clamp(v + dt M^-1 tau) ----------------
+    // ---------------- D. unconstrained velocity update  v* = clamp(v + dt M^-1 tau),  M^-1 = L^-1 L^-T ----------------
     real vstar;
     {
-        real bi = lane < NV ? s.tau[k] : (real)0, y = 0;
-#pragma unroll
-        for (int j = 0; j < NV; j++) {        // L y = tau
-            const real t = bi * inv_diag;
-            const real yj = bcast(t, j);
-            if (lane == j) y = t;
-            if (lane > j) bi -= Lr[j] * yj;
-        }
+        // L^T y = tau, descending: lane i owns row i of L^T in its registers
+        real bi = lane < NV ? s.tau[k] : (real)0;
+        static_for<NV - 1>([&](auto jc) {
+            constexpr int J = NV - 1 - decltype(jc)::value;       // J = NV-1 .. 1 (DoF 0 supports nothing below it)
+            const real yj = bcast(bi * inv_diag, J);
+            bi -= Lr[J] * yj;
+        });
+        real yv = bi * inv_diag;
         WSYNC();
-        // L^T x = y : lane i needs column i of L
-        real x = 0;
-#pragma unroll
-        for (int j = NV - 1; j >= 0; j--) {
-            const real t = y * inv_diag;
-            const real xj = bcast(t, j);
-            if (lane == j) x = t;
-            if (lane < j) y -= s.M[j][k] * xj;
-        }
+        // L x = y, ascending: lane r needs column r of L^T, read from LDS
+        static_for<NV>([&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            if constexpr (has_desc(J)) {
+                const real xj = bcast(yv * inv_diag, J);
+                yv -= s.M[J][k] * xj;
+            }
+        });
+        const real x = yv * inv_diag;
         const real vk = lane < 3 ? s.st[7 + k] : (lane < 6 ? s.st[10 + k - 3] : (lane < NV ? s.st[31 + k - 6] : (real)0));
         vstar = vk + P.dt * x;
         vstar = min_(max_(vstar, -P.vmax), P.vmax);
@@ -678,7 +696,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     WSYNC();
     if (dump && lane < NV) {
 #pragma unroll
-        for (int r = 0; r < NV; r++) dump[640 + r * NV + lane] = s.M[r][lane];
+        for (int r = 0; r < NV; r++) dump[640 + lane * NV + r] = r == lane ? (real)1 / inv_diag : s.M[r][lane];    // L[lane][r]
         dump[600 + lane] = s.v[lane];
     }
 
@@ -735,23 +753,23 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     for (int c = 0; c < 8; c++) act |= (unsigned)((act_ballot >> (18 + 15 * (c / 4) + 3 + 3 * (c % 4))) & 1ull) << c;
     rc = (act & 0x0fu) != 0; lc = (act & 0xf0u) != 0;
     WSYNC();
-    // own Jacobian row into registers, b = J v*, then Y = L^-1 J^T by forward substitution
+    // own Jacobian row into registers, b = J v*, then Y = L^-T J^T by back substitution (A = J M^-1 J^T = Y^T Y)
     real Jr[NV];
 #pragma unroll
     for (int j = 0; j < NV; j++) Jr[j] = is_joint ? (j == 6 + p ? (real)1 : (real)0) : s.YT[j][p];
     real bvel = 0;
 #pragma unroll
     for (int j = 0; j < NV; j++) bvel += Jr[j] * s.v[j];
-    // inverse diagonal of L for every row, via LDS
-    if (lane < NV) s.col[lane] = inv_diag;
-    WSYNC();
-#pragma unroll
-    for (int i = 0; i < NV; i++) {
-        real acc = Jr[i];
-#pragma unroll
-        for (int j = 0; j < i; j++) acc -= s.M[i][j] * Jr[j];
-        Jr[i] = acc * s.col[i];
-    }
+    // (the inverse diagonal of L is in s.col since phase C)
+    static_for<NV>([&](auto ic) {                 // L^T y = J^T, descending; only the supported entries of L
+        constexpr int I = NV - 1 - decltype(ic)::value;
+        real acc = Jr[I];
+        static_for<NV - 1 - I>([&](auto rc) {
+            constexpr int R = I + 1 + decltype(rc)::value;
+            if constexpr (l_nz(R, I)) acc -= s.M[I][R] * Jr[R];
+        });
+        Jr[I] = acc * s.col[I];
+    });
     if (lane < NPORT) {
 #pragma unroll
         for (int j = 0; j < NV; j++) s.YT[j][p] = Jr[j];
@@ -760,26 +778,46 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     STAMP();
     FRESH_LANE();
     // ---------------- F. port Delassus matrix, one row per lane in registers ----------------
-    // A[p][q] = Y_p . Y_q, accumulated over the 24 generalized coordinates (outer loop kept rolled so
-    // that only the 48 accumulators are live)
-    real Ar[NPORT];
+    // A[p][q] = Y_p . Y_q.  Y inherits the tree sparsity: coordinate j of a port's column is nonzero only if
+    // DoF j supports the port, so the base coordinates couple all 48 ports, a leg's coordinates only that
+    // leg's 6 joint ports + 15 foot ports, an arm's coordinates its 3 joint ports (534 instead of 1152
+    // multiply-adds).  Accumulated as register pairs (v_pk_fma_f32), loops over j kept rolled so that only
+    // the accumulators are live.
+    using vec2 = real __attribute__((ext_vector_type(2)));
+    vec2 Ar2[NPORT / 2];
 #pragma unroll
-    for (int q = 0; q < NPORT; q++) Ar[q] = 0;
-#pragma unroll 1
-    for (int j = 0; j < NV; j++) {
-        const real yj = s.YT[j][p];
-#pragma unroll
-        for (int q = 0; q < NPORT; q++) Ar[q] += yj * s.YT[j][q];
-    }
+    for (int q = 0; q < NPORT / 2; q++) Ar2[q] = (vec2){0, 0};
     real diag = 0;
-#pragma unroll
-    for (int q = 0; q < NPORT; q++) if (lane == q) diag = Ar[q];
+    auto a_row = [&](const int j, auto lo_c, auto n_c, const bool first) {
+        constexpr int LO = decltype(lo_c)::value, N = decltype(n_c)::value;
+        const real yj = s.YT[j][p];
+        if (first) diag += yj * yj;
+        const vec2 y2 = {yj, yj};
+        const vec2 *rowp = reinterpret_cast<const vec2 *>(&s.YT[j][0]);
+        static_for<N>([&](auto ic) { constexpr int I = LO + decltype(ic)::value; Ar2[I] += y2 * rowp[I]; });
+    };
+    using std::integral_constant;
+#pragma unroll 1
+    for (int j = 0; j < 6; j++) a_row(j, integral_constant<int, 0>{}, integral_constant<int, NPORT / 2>{}, true);
+    static_for<2>([&](auto fc_) {        // leg f: DoFs 6+6f..11+6f, joint ports 6f..6f+5, foot ports 18+15f..32+15f (pair 16 = ports 32|33 is shared)
+        constexpr int f = decltype(fc_)::value;
+#pragma unroll 1
+        for (int j = 6 + 6 * f; j < 12 + 6 * f; j++) {
+            a_row(j, integral_constant<int, 3 * f>{}, integral_constant<int, 3>{}, true);
+            a_row(j, integral_constant<int, 9 + 7 * f>{}, integral_constant<int, 8>{}, false);
+        }
+    });
+    static_for<2>([&](auto ac_) {        // arm a: DoFs 18+3a..20+3a, joint ports 12+3a..14+3a
+        constexpr int a = decltype(ac_)::value;
+#pragma unroll 1
+        for (int j = 18 + 3 * a; j < 21 + 3 * a; j++) a_row(j, integral_constant<int, 6 + a>{}, integral_constant<int, 2>{}, true);
+    });
     const real EPS = sizeof(real) == 8 ? (real)2.220446049250313e-16 : (real)1.1920929e-07;
     const real jdi = diag > EPS ? (real)1 / diag : (real)0;
     if (dump) {
         if (lane < NPORT) {
 #pragma unroll
-            for (int q = 0; q < NPORT; q++) dump[1216 + lane * NPORT + q] = Ar[q];
+            for (int q = 0; q < NPORT; q++) dump[1216 + lane * NPORT + q] = Ar2[q / 2][q % 2];
             dump[3520 + lane] = bvel;
             dump[3568 + lane] = dist;
         }
@@ -789,8 +827,12 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     WSYNC();
     if (lane < NPORT) s.lamP[p] = jdi;
     WSYNC();
+    real Ar[NPORT];
 #pragma unroll
-    for (int q = 0; q < NPORT; q++) Ar[q] *= s.lamP[q];
+    for (int q = 0; q < NPORT / 2; q++) {
+        const vec2 a2 = Ar2[q] * *reinterpret_cast<const vec2 *>(&s.lamP[2 * q]);
+        Ar[2 * q] = a2[0]; Ar[2 * q + 1] = a2[1];
+    }
 
     STAMP();
     FRESH_LANE();
@@ -952,7 +994,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     else lam_sum = (u0 + u1 + u2 + u3) * jdi;
 
     FRESH_LANE();
-    // ---------------- H. apply impulses:  dv = L^-T (Y Lambda),  v = clamp(v* + dv) ----------------
+    // ---------------- H. apply impulses:  dv = L^-1 (Y Lambda),  v = clamp(v* + dv) ----------------
     {
         const real inv_diag_r = lane < NV ? s.col[k] : (real)0;    // 1/L[k][k], parked in LDS since phase E
         const real vstar_r = lane < NV ? s.v[k] : (real)0;         // v* parked in LDS since phase D
@@ -964,14 +1006,14 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
 #pragma unroll
             for (int q = 0; q < NPORT; q++) z += s.YT[k][q] * s.lamP[q];
         }
-        real x = 0;
-#pragma unroll
-        for (int j = NV - 1; j >= 0; j--) {
-            const real t = z * inv_diag_r;
-            const real xj = bcast(t, j);
-            if (lane == j) x = t;
-            if (lane < j) z -= s.M[j][k] * xj;
-        }
+        static_for<NV>([&](auto jc) {                 // L x = z, ascending, column k of L^T from LDS
+            constexpr int J = decltype(jc)::value;
+            if constexpr (has_desc(J)) {
+                const real xj = bcast(z * inv_diag_r, J);
+                z -= s.M[J][k] * xj;
+            }
+        });
+        const real x = z * inv_diag_r;
         real vn = vstar_r + x;
         vn = min_(max_(vn, -P.vmax), P.vmax);
         WSYNC();

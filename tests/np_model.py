@@ -4,7 +4,7 @@ The HIP path does NOT follow Bullet's articulated-body recursion; it uses
   * 19 composite bodies (fixed joints folded),
   * world-axes composite-rigid-body mass matrix M (24x24) about the base origin,
   * a classical-acceleration recursive Newton-Euler bias,
-  * Cholesky M = L L^T,
+  * sparse factorization M = L^T L (leaves first: no fill-in),
   * a 48-"port" Delassus matrix A = J M^-1 J^T and projected Gauss-Seidel in port space
     visiting rows in Bullet's order.
 This file states that formulation in float64 NumPy so the tests can check, on the CPU, that it is
@@ -231,12 +231,13 @@ def substep(state, target, w=None, info=None):
     s = np.array(state, dtype=float)
     pos, quat, omega, vel, q, qd = s[0:3], s[3:7], s[7:10], s[10:13], s[13:31], s[31:49]
     M, tau, kin = mass_matrix_and_bias(pos, quat, omega, vel, q, qd, w.linear_damping)
-    L = np.linalg.cholesky(M)
+    # M = L^T L (Featherstone's sparsity-preserving LTL factorization, as the kernel does it): L lower triangular
+    L = np.linalg.cholesky(M[::-1, ::-1])[::-1, ::-1].T
     v = np.concatenate([omega, vel, qd])
-    acc = np.linalg.solve(L.T, np.linalg.solve(L, tau))
+    acc = np.linalg.solve(L, np.linalg.solve(L.T, tau))
     v = np.clip(v + DT * acc, -w.max_coordinate_velocity, w.max_coordinate_velocity)
     J, pts, dist = port_jacobians(kin, pos)
-    Y = np.linalg.solve(L, J.T)            # 24 x 48
+    Y = np.linalg.solve(L.T, J.T)          # 24 x 48,  A = J M^-1 J^T = Y^T Y
     A = Y.T @ Y                            # port Delassus
     b = J @ v                              # port relative velocities
     diag = np.diag(A)
@@ -335,11 +336,11 @@ def substep(state, target, w=None, info=None):
         its = it + 1
         if res <= w.residual_threshold or it >= w.num_iterations - 1:
             break
-    # total impulse per port -> delta v = M^-1 J^T lambda = L^-T (Y lambda)
+    # total impulse per port -> delta v = M^-1 J^T lambda = L^-1 (Y lambda)
     lam_port = np.zeros(NPORT)
     for row in nc_rows + nrm + spin + roll + fric:
         lam_port[row["port"]] += row["sign"] * row["lam"]
-    dv = np.linalg.solve(L.T, Y @ lam_port)
+    dv = np.linalg.solve(L, Y @ lam_port)
     v = np.clip(v + dv, -w.max_coordinate_velocity, w.max_coordinate_velocity)
     omega, vel, qd = v[0:3], v[3:6], v[6:]
     # ---- integrate (btMultiBody::stepPositionsMultiDof) ----
