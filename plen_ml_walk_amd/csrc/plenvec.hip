@@ -252,6 +252,218 @@ __device__ __forceinline__ void pgs_row1d(real &e, const real blo, real &dvec, c
     }
 }
 
+// The 18 motor rows of one pass as ONE software-pipelined block (f32 fast path): the v_writelane that commits
+// row i-1 sits in the wait state between row i's v_med3 and its v_readlane, so a row costs
+// med3 | writelane(prev) | readlane | s_nop 1 | fmac  = 4 VALU + 1 wait instead of 4 VALU + 2 waits.
+// REV = false: Bullet's sorted order NC_ORDER (odd iterations), REV = true: reversed (even iterations).
+template <bool FAST, bool REV, typename real>
+__device__ __forceinline__ void pgs_motor_pass(real &e, const real blo, const real bhi, real &dvec, const real (&Ar)[NPORT], const int lane) {
+    if constexpr (FAST && sizeof(real) == 4) {
+        static_assert(NC_ORDER[0] == 6 && NC_ORDER[1] == 5 && NC_ORDER[2] == 8 && NC_ORDER[3] == 7 && NC_ORDER[4] == 4 && NC_ORDER[5] == 1 &&
+                      NC_ORDER[6] == 0 && NC_ORDER[7] == 3 && NC_ORDER[8] == 2 && NC_ORDER[9] == 15 && NC_ORDER[10] == 14 && NC_ORDER[11] == 17 &&
+                      NC_ORDER[12] == 16 && NC_ORDER[13] == 13 && NC_ORDER[14] == 10 && NC_ORDER[15] == 9 && NC_ORDER[16] == 12 && NC_ORDER[17] == 11,
+                      "the lane numbers in the asm below are NC_ORDER_LIST written out");
+        float d;
+        int sA, sB;
+        if constexpr (!REV) {
+            asm volatile(
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "s_nop 0\n\t"
+            "v_readlane_b32 %[sA], %[d], 6\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sA], %[a6]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sA], 6\n\t"
+            "v_readlane_b32 %[sB], %[d], 5\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sB], %[a5]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sB], 5\n\t"
+            "v_readlane_b32 %[sA], %[d], 8\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sA], %[a8]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sA], 8\n\t"
+            "v_readlane_b32 %[sB], %[d], 7\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sB], %[a7]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sB], 7\n\t"
+            "v_readlane_b32 %[sA], %[d], 4\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sA], %[a4]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sA], 4\n\t"
+            "v_readlane_b32 %[sB], %[d], 1\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sB], %[a1]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sB], 1\n\t"
+            "v_readlane_b32 %[sA], %[d], 0\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sA], %[a0]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sA], 0\n\t"
+            "v_readlane_b32 %[sB], %[d], 3\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sB], %[a3]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sB], 3\n\t"
+            "v_readlane_b32 %[sA], %[d], 2\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sA], %[a2]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sA], 2\n\t"
+            "v_readlane_b32 %[sB], %[d], 15\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sB], %[a15]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sB], 15\n\t"
+            "v_readlane_b32 %[sA], %[d], 14\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sA], %[a14]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sA], 14\n\t"
+            "v_readlane_b32 %[sB], %[d], 17\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sB], %[a17]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sB], 17\n\t"
+            "v_readlane_b32 %[sA], %[d], 16\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sA], %[a16]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sA], 16\n\t"
+            "v_readlane_b32 %[sB], %[d], 13\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sB], %[a13]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sB], 13\n\t"
+            "v_readlane_b32 %[sA], %[d], 10\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sA], %[a10]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sA], 10\n\t"
+            "v_readlane_b32 %[sB], %[d], 9\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sB], %[a9]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sB], 9\n\t"
+            "v_readlane_b32 %[sA], %[d], 12\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sA], %[a12]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sA], 12\n\t"
+            "v_readlane_b32 %[sB], %[d], 11\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sB], %[a11]\n\t"
+            "v_writelane_b32 %[dv], %[sB], 11\n\t"
+            : [d] "=&v"(d), [sA] "=&s"(sA), [sB] "=&s"(sB), [dv] "+v"(dvec), [e] "+v"(e)
+            : [blo] "v"(blo), [bhi] "v"(bhi), [a0] "v"(Ar[0]), [a1] "v"(Ar[1]), [a2] "v"(Ar[2]), [a3] "v"(Ar[3]), [a4] "v"(Ar[4]), [a5] "v"(Ar[5]), [a6] "v"(Ar[6]), [a7] "v"(Ar[7]), [a8] "v"(Ar[8]), [a9] "v"(Ar[9]), [a10] "v"(Ar[10]), [a11] "v"(Ar[11]), [a12] "v"(Ar[12]), [a13] "v"(Ar[13]), [a14] "v"(Ar[14]), [a15] "v"(Ar[15]), [a16] "v"(Ar[16]), [a17] "v"(Ar[17]));
+        } else {
+            asm volatile(
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "s_nop 0\n\t"
+            "v_readlane_b32 %[sA], %[d], 11\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sA], %[a11]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sA], 11\n\t"
+            "v_readlane_b32 %[sB], %[d], 12\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sB], %[a12]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sB], 12\n\t"
+            "v_readlane_b32 %[sA], %[d], 9\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sA], %[a9]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sA], 9\n\t"
+            "v_readlane_b32 %[sB], %[d], 10\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sB], %[a10]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sB], 10\n\t"
+            "v_readlane_b32 %[sA], %[d], 13\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sA], %[a13]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sA], 13\n\t"
+            "v_readlane_b32 %[sB], %[d], 16\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sB], %[a16]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sB], 16\n\t"
+            "v_readlane_b32 %[sA], %[d], 17\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sA], %[a17]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sA], 17\n\t"
+            "v_readlane_b32 %[sB], %[d], 14\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sB], %[a14]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sB], 14\n\t"
+            "v_readlane_b32 %[sA], %[d], 15\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sA], %[a15]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sA], 15\n\t"
+            "v_readlane_b32 %[sB], %[d], 2\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sB], %[a2]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sB], 2\n\t"
+            "v_readlane_b32 %[sA], %[d], 3\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sA], %[a3]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sA], 3\n\t"
+            "v_readlane_b32 %[sB], %[d], 0\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sB], %[a0]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sB], 0\n\t"
+            "v_readlane_b32 %[sA], %[d], 1\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sA], %[a1]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sA], 1\n\t"
+            "v_readlane_b32 %[sB], %[d], 4\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sB], %[a4]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sB], 4\n\t"
+            "v_readlane_b32 %[sA], %[d], 7\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sA], %[a7]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sA], 7\n\t"
+            "v_readlane_b32 %[sB], %[d], 8\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sB], %[a8]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sB], 8\n\t"
+            "v_readlane_b32 %[sA], %[d], 5\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sA], %[a5]\n\t"
+            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
+            "v_writelane_b32 %[dv], %[sA], 5\n\t"
+            "v_readlane_b32 %[sB], %[d], 6\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f32 %[e], %[sB], %[a6]\n\t"
+            "v_writelane_b32 %[dv], %[sB], 6\n\t"
+            : [d] "=&v"(d), [sA] "=&s"(sA), [sB] "=&s"(sB), [dv] "+v"(dvec), [e] "+v"(e)
+            : [blo] "v"(blo), [bhi] "v"(bhi), [a0] "v"(Ar[0]), [a1] "v"(Ar[1]), [a2] "v"(Ar[2]), [a3] "v"(Ar[3]), [a4] "v"(Ar[4]), [a5] "v"(Ar[5]), [a6] "v"(Ar[6]), [a7] "v"(Ar[7]), [a8] "v"(Ar[8]), [a9] "v"(Ar[9]), [a10] "v"(Ar[10]), [a11] "v"(Ar[11]), [a12] "v"(Ar[12]), [a13] "v"(Ar[13]), [a14] "v"(Ar[14]), [a15] "v"(Ar[15]), [a16] "v"(Ar[16]), [a17] "v"(Ar[17]));
+        }
+    } else {
+        static_for<ND>([&](auto ic) {
+            constexpr int PP = NC_ORDER[REV ? ND - 1 - decltype(ic)::value : decltype(ic)::value];
+            pgs_row2d<FAST, PP>(e, blo, bhi, dvec, Ar[PP], lane);
+        });
+    }
+}
+
 // torsional row with bounds prepared by the caller for this pass (nt1 = -(lim + u), t2 = lim - u) and a
 // deferred commit (u += dvec after the pass): med3 -> readlane -> writelane -> fmac
 template <bool FAST, int PP, typename real>
@@ -902,7 +1114,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         real resv = 0;           // per-lane |deltaVel| of the rows this lane hosted in this iteration (from the deferred deltas)
         // -- non-contact rows: sorted order (motors, then limits) on odd iterations, reversed on even ones --
         if (it & 1) {
-            static_for<ND>([&](auto ic) { constexpr int PP = NC_ORDER[decltype(ic)::value]; pgs_row2d<FAST, PP>(e, blo, bhi, dvec, Ar[PP], lane); });
+            pgs_motor_pass<FAST, false>(e, blo, bhi, dvec, Ar, lane);
             blo -= dvec; bhi -= dvec; resv = max_(resv, abs_(dvec)); dvec = 0;
             if (lim_mask) {
                 static_for<ND>([&](auto ic) {
@@ -917,7 +1129,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                     if (lim_mask & (1u << PP)) pgs_row_signed<PP>(s.lim, e, diag, Ar[PP], lane, res_i);
                 });
             }
-            static_for<ND>([&](auto ic) { constexpr int PP = NC_ORDER[ND - 1 - decltype(ic)::value]; pgs_row2d<FAST, PP>(e, blo, bhi, dvec, Ar[PP], lane); });
+            pgs_motor_pass<FAST, true>(e, blo, bhi, dvec, Ar, lane);
             blo -= dvec; bhi -= dvec; resv = max_(resv, abs_(dvec)); dvec = 0;
         }
         ISTAMP(1);
