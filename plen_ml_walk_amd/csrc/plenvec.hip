@@ -772,7 +772,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     // `lane == j` masks of every unrolled phase (48 SGPR pairs), keeps them alive across the whole substep
     // and spills them
     int lane = lane_in;
-#define FRESH_LANE() asm volatile("" : "+v"(lane))
+#define FRESH_LANE() asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane))     /* recomputed, so no copy of it has to live (or spill) across the phase */
     // phase stamps (shader clock) into the debug dump: diagnostic only, never in the timed path
     int stamp_i = 0;
     long long stamp_t0 = 0;
@@ -1298,22 +1298,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real)
     const int env = blockIdx.x;
     const int lane = threadIdx.x;
     const DevParams<real> &P = *a.P;
-    const real mass_scale = a.mass_scale ? a.mass_scale[env] : (real)1;
-    const real mu_lat = a.mu_lat ? a.mu_lat[env] : P.mu_lat;
+    // wave-uniform per-env parameters, pinned to scalar registers (as vector registers they would be spilled across the substeps)
+    const real mass_scale = bcast(a.mass_scale ? a.mass_scale[env] : (real)1, 0);
+    const real mu_lat = bcast(a.mu_lat ? a.mu_lat[env] : P.mu_lat, 0);
     real *dump = a.dump ? a.dump + (size_t)env * PLENVEC_DUMP : nullptr;
 
     // ---- load the env record (one coalesced 64-real read) ----
-    int gait_cnt, ds_cnt, ep_step, nhist;
     if (a.mode == MODE_RESET_BUILD) {
         real v = 0;
         if (lane == 2) v = P.spawn_z;
         if (lane == 6) v = 1;
         s.st[lane] = v;
-        gait_cnt = ds_cnt = ep_step = nhist = 0;
     } else {
         s.st[lane] = a.state[(size_t)env * REC + lane];
-        const int *ax = a.aux + (size_t)env * AUXN;
-        gait_cnt = ax[0]; ds_cnt = ax[1]; ep_step = ax[2]; nhist = ax[3];
     }
     // ---- motor targets ----
     if (lane < NV) {
@@ -1332,8 +1329,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real)
     for (int sub = 0; sub < a.nsub; sub++) {
         // keep loop-invariant parameter/model loads INSIDE the substep: hoisted out of this loop they would
         // stay live across everything and be spilled to scratch
-        int ln = lane;
-        asm volatile("" : "+v"(ln) : : "memory");     // ... and so would every lane-dependent constant (one-hots, masks, addresses)
+        int ln;                                       // ... and so would every lane-dependent constant (one-hots, masks, addresses)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln) : : "memory");
         substep<FAST>(s, P, ln, mass_scale, mu_lat, rc, lc, iters, (sub == a.nsub - 1) ? dump : nullptr);
     }
 
@@ -1344,6 +1341,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real)
     }
 
     // ================= env level: compute_observation / compute_done / compute_reward =================
+    // episode counters (loaded here, not before the substeps: they would only sit in registers meanwhile)
+    int gait_cnt = 0, ds_cnt = 0, ep_step = 0, nhist = 0;
+    if (a.mode != MODE_RESET_BUILD) {
+        const int *ax = a.aux + (size_t)env * AUXN;
+        gait_cnt = ax[0]; ds_cnt = ax[1]; ep_step = ax[2]; nhist = ax[3];
+    }
     kinematics(s, P, lane, false);            // link frames at the post-step configuration (getLinkState)
     real quat[4] = {s.st[3], s.st[4], s.st[5], s.st[6]}, rpy[3];
     euler_from_quat(quat, rpy);
