@@ -23,6 +23,18 @@ if ROOT not in sys.path:
 ENVS_PER_GPU = 4096
 ALGO_BYTES_PER_ENV_STEP = 776          # fp32 state+aux+action in, state+aux+obs+reward+done out
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_PEAK_GINST_S = 1024 * 2.4 / 4     # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles per SIMD, 2.4 GHz peak clock
+
+
+def _pmc_summary():
+    """HBM traffic and instruction counts per launch are PMC measurements (rocprofv3 --pmc, separate passes, gfx950 FETCH_SIZE
+    correction applied); bench.py cannot collect them itself, so it reports the newest committed summary under profiles/."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        return json.load(f)["env_kernel_per_launch"], os.path.relpath(files[-1], ROOT)
 
 
 def _cpu_worker(args):
@@ -124,6 +136,13 @@ def main():
         value = total_env_steps / elapsed
         launch_s = kernel_ms * 1e-3 / max(launches, 1)
         achieved = n * ALGO_BYTES_PER_ENV_STEP / launch_s / 1e9
+        pmc, pmc_file = _pmc_summary()
+        traffic = pmc["hbm_traffic_bytes"] if (pmc and n == ENVS_PER_GPU and a.dtype == "f32") else None
+        valu = None
+        if pmc and a.dtype == "f32":
+            ginst = pmc["valu_insts_per_env_step"] * n / launch_s / 1e9
+            valu = {"insts_per_env_step": pmc["valu_insts_per_env_step"], "achieved": ginst, "peak": VALU_PEAK_GINST_S, "unit": "G wave-inst/s",
+                    "frac": ginst / VALU_PEAK_GINST_S, "source": pmc_file}
         out = {
             "metric": "env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -133,10 +152,13 @@ def main():
                        "envs_per_gpu": n, "total_envs": world * n, "substeps": 4, "solver_iterations": 50,
                        "parallelism": "env-sharded, %d rank(s), no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
+                         "traffic": traffic, "valu_issue": valu,
                          "note": "algorithmic %d B/env-step x %d env-steps per launch / %.3f ms per launch (HIP events on the launch "
-                                 "stream). The step is FP32-VALU/latency bound (about 2.5 MFLOP per env-step), see DESIGN.md" %
-                                 (ALGO_BYTES_PER_ENV_STEP, n, launch_s * 1e3)},
+                                 "stream); traffic = PMC FETCH_SIZE x2 (gfx950 correction, calibrated on the reset-copy kernel) + WRITE_SIZE "
+                                 "per launch from %s. The contract's hbm/mfma bounds do not bind this kernel: it is a serial "
+                                 "projected-Gauss-Seidel chain per env, bound by wave64 VALU issue (valu_issue: one instruction per 4 cycles "
+                                 "per SIMD) and by the 4-waves-per-SIMD occupancy the 128-VGPR working set allows; see DESIGN.md" %
+                                 (ALGO_BYTES_PER_ENV_STEP, n, launch_s * 1e3, pmc_file)},
             "kernel_ms_per_launch": launch_s * 1e3,
         }
         if not a.no_cpu_baseline and world == 1:
