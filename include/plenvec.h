@@ -51,7 +51,8 @@ typedef struct PlenCfg {
     int32_t reset_substeps;      /* 8 = 2*sim_stepsize, plen_env.py:569-570 */
     int32_t num_iterations;      /* 50 */
     int32_t auto_reset;          /* 1: an env whose episode ended restarts inside the same step call */
-    int32_t reserved0;
+    int32_t reward_head;         /* 0: PlenWalkEnv-v1 reward/done/contact flags (plen_env.py, default); 1: the PlenWalkEnv-v0 contract on the same
+                                    physics: contact = |foot force| > weight/3 (plen_walk.py:346-396), done :597-618, reward :620-650 */
     double dt;                   /* 1/240 */
     double gravity_z;            /* -9.81, plen_env.py:296 */
     double erp, erp2;            /* 0.2, 0.08 */

@@ -53,6 +53,12 @@ def _lib(dtype="f64"):
         lib.oracle_step.argtypes = [C.c_void_p, dp, dp, ip]
         lib.oracle_rollout.restype = C.c_int
         lib.oracle_rollout.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), dp, dp, C.POINTER(C.c_uint8)]
+        lib.oracle_set_reward_head.argtypes = [C.c_void_p, C.c_int]
+        lib.oracle_foot_forces.argtypes = [C.c_void_p, dp]
+        lib.oracle_gazebo_contact.argtypes = [dp]
+        lib.oracle_gazebo_contact.restype = C.c_int
+        lib.oracle_gazebo_script.argtypes = [C.c_void_p] + [C.c_double] * 7 + [C.c_int, ip, ip]
+        lib.oracle_gazebo_script.restype = C.c_double
         _LIBS[dtype] = lib
     return _LIBS[dtype]
 
@@ -64,9 +70,27 @@ def _dp(a):
 class OracleEnv(object):
     """One PLEN environment on the CPU oracle; mirrors PlenWalkEnv.reset/step (plen_env.py:558,638)."""
 
-    def __init__(self, joint_act=False, dtype="f64"):
+    def __init__(self, joint_act=False, dtype="f64", reward_head=0):
         self.lib = _lib(dtype)
         self.h = self.lib.oracle_create(int(joint_act))
+        if reward_head:
+            self.lib.oracle_set_reward_head(self.h, int(reward_head))   # 1: PlenWalkEnv-v0 contract (plen_walk.py)
+
+    def foot_forces(self):
+        """Contact force on the right and left foot over the last substep, [2,3] N."""
+        f = np.zeros(6)
+        self.lib.oracle_foot_forces(self.h, _dp(f))
+        return f.reshape(2, 3)
+
+    def gazebo_contact(self, force3):
+        return int(self.lib.oracle_gazebo_contact(_dp(np.ascontiguousarray(force3, dtype=np.float64))))
+
+    def gazebo_script(self, vx, z, y, roll, pitch, yaw, x, episode_timestep):
+        """plen_walk.py:597-650 on hand-set attributes -> (reward, done, dead)."""
+        done, dead = C.c_int(0), C.c_int(0)
+        r = self.lib.oracle_gazebo_script(self.h, float(vx), float(z), float(y), float(roll), float(pitch), float(yaw), float(x),
+                                          int(episode_timestep), C.byref(done), C.byref(dead))
+        return r, bool(done.value), bool(dead.value)
 
     def __del__(self):
         try:

@@ -213,6 +213,8 @@ typedef struct {
     real IA[NL + 1][36], U[NL + 1][6], Dinv[NL + 1], S[NL + 1][6];
     /* ---- contact state of the last collision pass ---- */
     int ncp; int cp_foot[MAXCP]; real cp_pos[MAXCP][3]; real cp_dist[MAXCP];
+    int reward_head;                 /* 0: PlenWalkEnv-v1 (plen_env.py), 1: PlenWalkEnv-v0 contract (plen_walk.py:346-396, 597-650) */
+    real foot_force[2][3];           /* contact force on each foot over the last substep (impulses / dt), right then left */
     int right_contact, left_contact;
     int last_iterations; real last_residual;
     /* ---- env-level state (plen_env.py attributes) ---- */
@@ -608,6 +610,12 @@ static void substep(Oracle *o) {
         if (residual <= w->residual_threshold || it >= w->num_iterations - 1) { it++; break; }
     }
     o->last_iterations = it; o->last_residual = residual;
+    /* contact force per foot (what a Gazebo bumper reports): normal + lateral impulses of its points / dt */
+    memset(o->foot_force, 0, sizeof o->foot_force);
+    for (int c = 0; c < o->ncp; c++) {
+        real *F = o->foot_force[o->cp_foot[c]];
+        v3axpy(F, nrm[c].applied / dt, nrmW); v3axpy(F, fric[2 * c].applied / dt, dir1); v3axpy(F, fric[2 * c + 1].applied / dt, dir2);
+    }
     /* processDeltaVeeMultiDof2 */
     for (int k = 0; k < NV; k++) {
         v[k] += dv[k];
@@ -652,6 +660,8 @@ static double agent_to_env(const real *range, double agent_val) {
     return v;
 }
 
+static int gazebo_contact(const real *F);
+
 /* plen_env.py:768-871 */
 static void compute_observation(Oracle *o, real *obs) {
     real rpy[3]; quat_to_euler(rpy, o->base_quat);
@@ -659,6 +669,7 @@ static void compute_observation(Oracle *o, real *obs) {
     o->roll = rpy[0]; o->pitch = rpy[1]; o->yaw = rpy[2];
     for (int d = 0; d < ND; d++) obs[d] = o->q[d];
     obs[18] = o->torso_z; obs[19] = o->torso_vx; obs[20] = o->roll; obs[21] = o->pitch; obs[22] = o->yaw;
+    if (o->reward_head == 1) { o->right_contact = gazebo_contact(o->foot_force[0]); o->left_contact = gazebo_contact(o->foot_force[1]); }
     obs[23] = o->torso_y; obs[24] = (real)o->right_contact; obs[25] = (real)o->left_contact;
     static const int J[6] = {2, 8, 3, 9, 4, 10};
     if (o->nhist > 0) { for (int k = 0; k < 6; k++) o->diffs[k] = o->hist[k][o->nhist - 1] - o->q[J[k]]; o->first_pass = 0; }
@@ -736,6 +747,32 @@ static double reward_core(Oracle *o, double lr, double lp, double rr, double rp)
     if (o->left_contact == 1 && fabs(lr) <= 0.1 && fabs(lp) <= 0.1) reward += 0.1;
     if (o->right_contact == 1 && fabs(rr) <= 0.1 && fabs(rp) <= 0.1) reward += 0.1;
     if (o->dead) { reward -= 100.0; o->dead = 0; }
+    return reward;
+}
+
+/* ---- PlenWalkEnv-v0 (Gazebo) contract on the same state: plen_walk.py:346-396 contact rule, :597-618 done, :620-650 reward ---- */
+static int gazebo_contact(const real *F) {
+    double m = sqrt((double)F[0] * F[0] + (double)F[1] * F[1] + (double)F[2] * F[2]);
+    return m > 4.8559 / 3.0;
+}
+static int gazebo_done(Oracle *o, double torso_x, int episode_timestep, int *dead) {
+    const double PI3 = fabs(3.14159265358979323846 / 3.);
+    int done;
+    if (o->roll > PI3 || o->pitch > PI3 || o->torso_z < (real)0.08 || o->torso_y > 1) { done = 1; *dead = 1; }
+    else if (episode_timestep > 500 && torso_x < 1) { done = 1; *dead = 0; }
+    else { done = 0; *dead = 0; }
+    return done;
+}
+static double gazebo_reward(const Oracle *o, int dead) {
+    double reward = 0, vx = o->torso_vx;
+    reward += 100. / 500;                                             /* alive_reward = dead_penalty / max_episode_steps */
+    reward += (vx > 0 ? 1.0 : vx < 0 ? -1.0 : 0.0) * (vx * 3.) * (vx * 3.);
+    { double h = fabs(0.158 - (double)o->torso_z) * 20.; reward -= h * h; }
+    reward -= fabs((double)o->torso_y) * fabs((double)o->torso_y) * 1;
+    reward -= fabs((double)o->roll) * fabs((double)o->roll) * 1.;
+    reward -= fabs((double)o->pitch) * fabs((double)o->pitch) * 0.5;
+    reward -= fabs((double)o->yaw) * fabs((double)o->yaw) * 1.;
+    if (dead) reward -= 100.;
     return reward;
 }
 
@@ -854,10 +891,16 @@ API double oracle_step(Oracle *o, const double *action, double *obs_out, int *do
         o->target[d] = (real)(o->joint_act ? action[d] : agent_to_env(ENV_RANGES[d], action[d]));
     for (int i = 0; i < 4; i++) substep(o);
     real obs[26]; fk(o); compute_observation(o, obs);
-    int done = compute_done(o);
-    real lr, lp, rr, rp;
-    foot_rp(o, RAW_LFOOT_LINK, &lr, &lp); foot_rp(o, RAW_RFOOT_LINK, &rr, &rp);
-    double reward = reward_core(o, lr, lp, rr, rp);
+    int done; double reward;
+    if (o->reward_head == 1) {
+        int dead; done = gazebo_done(o, (double)o->base_pos[0], o->episode_timestep, &dead); o->dead = dead;
+        reward = gazebo_reward(o, dead);
+    } else {
+        done = compute_done(o);
+        real lr, lp, rr, rp;
+        foot_rp(o, RAW_LFOOT_LINK, &lr, &lp); foot_rp(o, RAW_RFOOT_LINK, &rr, &rp);
+        reward = reward_core(o, lr, lp, rr, rp);
+    }
     o->episode_timestep += 1; o->gait_period_counter += 1;
     for (int k = 0; k < 26; k++) obs_out[k] = obs[k];
     *done_out = done;
@@ -883,6 +926,16 @@ API int oracle_rollout(Oracle *o, int nsteps, const float *actions, double *obs,
 }
 
 API double oracle_last_residual(const Oracle *o) { return (double)o->last_residual; }
+API void oracle_set_reward_head(Oracle *o, int head) { o->reward_head = head; }
+API void oracle_foot_forces(const Oracle *o, double *f6) { for (int i = 0; i < 6; i++) f6[i] = o->foot_force[i / 3][i % 3]; }
+/* pins of the PlenWalkEnv-v0 head against tests/golden/gazebo_reward_done.npz */
+API int oracle_gazebo_contact(const double *force3) { real F[3] = {(real)force3[0], (real)force3[1], (real)force3[2]}; return gazebo_contact(F); }
+API double oracle_gazebo_script(Oracle *o, double vx, double z, double y, double roll, double pitch, double yaw, double x, int episode_timestep,
+                                int *done_out, int *dead_out) {
+    o->torso_vx = (real)vx; o->torso_z = (real)z; o->torso_y = (real)y; o->roll = (real)roll; o->pitch = (real)pitch; o->yaw = (real)yaw;
+    *done_out = gazebo_done(o, x, episode_timestep, dead_out);
+    return gazebo_reward(o, *dead_out);
+}
 
 /* single-state pin of compute_done + compute_reward (tests/golden/a78_reward_done.npz): install the
  * env attributes the reference's test harness set by hand, then run done -> reward. */

@@ -16,7 +16,7 @@ DONE_TERMINAL, DONE_TIMELIMIT = 1, 2
 
 class PlenCfg(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("joint_act", C.c_int32), ("max_episode_steps", C.c_int32), ("substeps", C.c_int32),
-                ("reset_substeps", C.c_int32), ("num_iterations", C.c_int32), ("auto_reset", C.c_int32), ("reserved0", C.c_int32),
+                ("reset_substeps", C.c_int32), ("num_iterations", C.c_int32), ("auto_reset", C.c_int32), ("reward_head", C.c_int32),
                 ("dt", C.c_double), ("gravity_z", C.c_double), ("erp", C.c_double), ("erp2", C.c_double),
                 ("linear_slop", C.c_double), ("residual_threshold", C.c_double), ("restitution_velocity_threshold", C.c_double),
                 ("max_coordinate_velocity", C.c_double), ("lateral_friction", C.c_double), ("spinning_friction", C.c_double),

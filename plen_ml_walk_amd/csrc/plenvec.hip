@@ -61,7 +61,7 @@ struct DevParams {
     real mdl[NB][28];   // JR9 | JT3 | axis3 | com3 | inertia xx yy zz xy xz yz | mass | pad3
     real memb[NB][GEN_MAXMEMB][4];   // member links of each composite body: COM (body frame) | mass  (per-link linear damping)
     int nmemb[NB];
-    int num_iterations, max_episode_steps, joint_act, pad;
+    int num_iterations, max_episode_steps, joint_act, reward_head;
 };
 
 __device__ __constant__ int c_parent[NB] = {-1, 0, 1, 2, 3, 4, 5, 0, 7, 8, 9, 10, 11, 0, 13, 14, 0, 16, 17};
@@ -1347,6 +1347,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real)
         const int *ax = a.aux + (size_t)env * AUXN;
         gait_cnt = ax[0]; ds_cnt = ax[1]; ep_step = ax[2]; nhist = ax[3];
     }
+    if (P.reward_head == 1) {
+        // PlenWalkEnv-v0 contact rule (plen_walk.py:346-396): |contact force on the foot| > weight / 3, the force being
+        // the last substep's normal + lateral impulses of the foot's points / dt (port axes: n = +z, t1 = -y, t2 = +x)
+        int flag[2];
+#pragma unroll
+        for (int f = 0; f < 2; f++) {
+            real fx = 0, fy = 0, fz = 0;
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const int b0 = 18 + 15 * f + 3 + 3 * kk;
+                fz += s.lamP[b0] * P.inv_dt; fy -= s.lamP[b0 + 1] * P.inv_dt; fx += s.lamP[b0 + 2] * P.inv_dt;
+            }
+            flag[f] = sqrt_(fx * fx + fy * fy + fz * fz) > (real)(4.8559 / 3.0);
+        }
+        rc = flag[0]; lc = flag[1];
+    }
     kinematics(s, P, lane, false);            // link frames at the post-step configuration (getLinkState)
     real quat[4] = {s.st[3], s.st[4], s.st[5], s.st[6]}, rpy[3];
     euler_from_quat(quat, rpy);
@@ -1386,6 +1402,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real)
         // compute_done (plen_env.py:1072-1093): one-sided on roll/pitch/y
         const real PI3 = (real)(3.14159265358979323846 / 3.0);
         const bool dead = (rpy[0] > PI3) || (rpy[1] > PI3) || (torso_z < (real)0.08) || (torso_y > (real)1);
+        bool gz_timeout = false;
+        if (P.reward_head == 1) {
+            // PlenWalkEnv-v0 contract: _is_done plen_walk.py:597-618, _compute_reward :620-650 (weights :93-107)
+            gz_timeout = !dead && ep_step > P.max_episode_steps && s.st[0] < (real)1;
+            reward += (real)(100. / 500);
+            reward += (torso_vx > 0 ? (real)1 : torso_vx < 0 ? (real)-1 : (real)0) * (torso_vx * (real)3) * (torso_vx * (real)3);
+            { const real h = abs_((real)0.158 - torso_z) * (real)20; reward -= h * h; }
+            reward -= torso_y * torso_y;
+            reward -= rpy[0] * rpy[0];
+            reward -= rpy[1] * rpy[1] * (real)0.5;
+            reward -= rpy[2] * rpy[2];
+        } else {
         // compute_reward (plen_env.py:873-1070)
         if (torso_vx < 0) reward -= exp_(torso_vx * (real)3); else reward += (torso_vx * (real)3) * (torso_vx * (real)3);
         { const real h = abs_((real)0.160178937611 - torso_z) * (real)40; reward -= h * h; }
@@ -1429,10 +1457,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real)
             if (lc == 1 && abs_(lroll) <= (real)0.1 && abs_(lpitch) <= (real)0.1) reward += (real)0.1;
             if (rc == 1 && abs_(rroll) <= (real)0.1 && abs_(rpitch) <= (real)0.1) reward += (real)0.1;
         }
+        }
         if (dead) reward -= 100;
         ep_step += 1; gait_cnt += 1;
         const bool trunc = ep_step >= P.max_episode_steps;
-        done_flag = (dead ? PLENVEC_DONE_TERMINAL : 0) | (trunc ? PLENVEC_DONE_TIMELIMIT : 0);
+        done_flag = (dead ? PLENVEC_DONE_TERMINAL : 0) | ((trunc || gz_timeout) ? PLENVEC_DONE_TIMELIMIT : 0);
         if (lane < PLENVEC_OBS) a.next_obs[(size_t)env * PLENVEC_OBS + lane] = ob;
         if (lane == 0) { a.reward[env] = reward; a.done[env] = (uint8_t)done_flag; }
     } else {
@@ -1536,7 +1565,7 @@ static void fill_params(const PlenCfg &c, DevParams<real> &p) {
             p.memb[b][i][3] = (real)GEN_MEMB_MASS[b][i];
         }
     }
-    p.num_iterations = c.num_iterations; p.max_episode_steps = c.max_episode_steps; p.joint_act = c.joint_act;
+    p.num_iterations = c.num_iterations; p.max_episode_steps = c.max_episode_steps; p.joint_act = c.joint_act; p.reward_head = c.reward_head;
 }
 
 template <typename real>

@@ -29,6 +29,8 @@ JOINT_NAMES = [  # plen_env.py:547-554
 MOVING_JOINTS = [5, 6, 7, 9, 10, 11, 13, 14, 15, 17, 18, 19, 20, 21, 24, 26, 27, 30]   # plen_env.py:318-320
 
 register(id="PlenWalkEnv-v1", entry_point="plen_ml_walk_amd.plen_env:PlenWalkEnv", max_episode_steps=500)
+# the Gazebo environment's contract (plen_ros_helpers/plen_walk.py:20-24: same id, 26-dim obs, 18 actions) on this simulator
+register(id="PlenWalkEnv-v0", entry_point="plen_ml_walk_amd.plen_env:PlenWalkEnvV0", max_episode_steps=500)
 try:                                   # also visible to a real gym, when there is one
     import gym as _gym
     _gym.envs.registration.register(id="PlenWalkEnv-v1", entry_point="plen_ml_walk_amd.plen_env:PlenWalkEnv", max_episode_steps=500)
@@ -39,7 +41,7 @@ except Exception:                      # noqa: BLE001 -- gym absent or id alread
 class PlenWalkEnv(Env):
     metadata = {'render.modes': ['human', 'rgb_array'], 'video.frames_per_second': 50}
 
-    def __init__(self, render=False, realtime=False, joint_act=False, device=None, dtype=torch.float64):
+    def __init__(self, render=False, realtime=False, joint_act=False, device=None, dtype=torch.float64, reward_head=0):
         if render or realtime:
             raise NotImplementedError("the GPU environment has no GUI / wall-clock mode (plen_env.py:275-292 are PyBullet GUI features)")
         self.joint_act = joint_act
@@ -62,7 +64,7 @@ class PlenWalkEnv(Env):
         self.total_timesteps = 0
         # the caller owns resets (plen_td3.py:122-133), the TimeLimit wrapper owns the 500-step limit
         self._vec = PlenVecEnv(1, device=device, dtype=dtype, joint_act=joint_act, auto_reset=False,
-                               cfg_overrides={"max_episode_steps": 2 ** 30})
+                               cfg_overrides={"max_episode_steps": 2 ** 30, "reward_head": int(reward_head)})
         self._dtype = dtype
 
     def _seed(self, seed=None):        # the reference defines _seed, not seed (plen_env.py:28); the env has no RNG
@@ -98,6 +100,14 @@ class PlenWalkEnv(Env):
 
     def close(self):
         self._vec.close()
+
+
+class PlenWalkEnvV0(PlenWalkEnv):
+    """`PlenWalkEnv-v0` (plen_ros_helpers/plen_walk.py) without ROS/Gazebo: its contact rule (force > weight/3, :346-396), `_is_done`
+    (:597-618) and `_compute_reward` (:620-650) evaluated in the kernel on this simulator's state."""
+
+    def __init__(self, device=None, dtype=torch.float64):
+        super().__init__(device=device, dtype=dtype, reward_head=1)
 
 
 def make(id="PlenWalkEnv-v1", **kwargs):   # noqa: A002

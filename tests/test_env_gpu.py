@@ -108,12 +108,14 @@ def test_solver_logic_exact_f64(nit):
     env.close()
 
 
-def _rollout_vs_oracle(dtype, n, T, acts, rolling=None, joint_act=False):
+def _rollout_vs_oracle(dtype, n, T, acts, rolling=None, joint_act=False, reward_head=0):
     ov = {} if rolling is None else {"rolling_friction": rolling}
+    if reward_head:
+        ov["reward_head"] = reward_head
     env = _env(n, dtype, joint_act=joint_act, cfg_overrides=ov)
     ors = []
     for _ in range(n):
-        o = OracleEnv(joint_act=joint_act)
+        o = OracleEnv(joint_act=joint_act, reward_head=reward_head)
         if rolling is not None:
             o.set_friction(rolling=rolling)
         o.reset(); ors.append(o)
@@ -142,6 +144,16 @@ def test_rollout_well_conditioned_f64():
     eo, er, mism, n = _rollout_vs_oracle(torch.float64, 24, 12, acts, rolling=0.0)
     assert n > 200 and mism == 0
     assert eo.max() <= 1e-5 and np.median(eo) <= 1e-11 and er.max() <= 1e-5
+
+
+def test_gazebo_reward_head_f64():
+    """PlenWalkEnv-v0 contract (force-threshold contact flags, its done and reward) on the same physics.
+    The oracle's head is pinned to the reference by tests/golden/gazebo_reward_done.npz."""
+    g = torch.Generator().manual_seed(3)
+    acts = (torch.rand(12, 24, 18, generator=g) * 2 - 1).float()
+    eo, er, mism, n = _rollout_vs_oracle(torch.float64, 24, 12, acts, rolling=0.0, reward_head=1)
+    assert n > 200 and mism == 0
+    assert eo.max() <= 1e-5 and np.median(eo) <= 1e-11 and er.max() <= 1e-5     # obs includes the two force-threshold flags
 
 
 def test_rollout_well_conditioned_f32():

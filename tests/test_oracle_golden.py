@@ -86,3 +86,19 @@ def test_a1_targets_in_script(golden_dir):
     acts, tg = g["actions_0"], g["targets_0"]
     got = np.array([[agent_to_env(j, acts[t, j]) for j in range(18)] for t in range(acts.shape[0])])
     assert np.max(np.abs(got - tg)) <= 1e-15
+
+
+def test_gazebo_head_reward_done_contact(golden_dir):
+    """the PlenWalkEnv-v0 contract (plen_walk.py:346-396, 597-650), oracle vs vectors captured
+    from the reference itself (tools/make_golden_gazebo.py)."""
+    g = np.load(os.path.join(golden_dir, "gazebo_reward_done.npz"))
+    w = g["weights"]
+    assert w.tolist() == [100.0, 0.2, 3.0, 0.158, 20.0, 1.0, 1.0, 0.5, 1.0, 500.0]     # constants restated in the oracle and the kernel
+    env = OracleEnv(reward_head=1)
+    st, ref = g["states"], g["done_dead_reward"]
+    for i in range(st.shape[0]):
+        r, done, dead = env.gazebo_script(*st[i, :7], int(st[i, 7]))
+        assert done == bool(ref[i, 0]) and dead == bool(ref[i, 1]), i
+        assert abs(r - ref[i, 2]) <= 1e-12 * max(1.0, abs(ref[i, 2])), (i, r, ref[i, 2])
+    for f, fl in zip(g["forces"], g["flags"]):
+        assert env.gazebo_contact(f) == int(fl[0]) == int(fl[1])
