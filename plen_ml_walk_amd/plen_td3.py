@@ -13,7 +13,7 @@ from . import gym_compat as gym
 
 
 def main(max_timesteps=4e6, start_timesteps=1e4, eval_freq=1e4, out_dir=None, seed=0, expl_noise=0.1, batch_size=100,
-         save_model=True, quiet=False):
+         save_model=True, quiet=False, policy_num=0, buffer_number=0):
     env_name = "PlenWalkEnv-v1"
     file_name = "plen_walk_gazebo_"
     my_path = out_dir or os.path.abspath(os.path.dirname(__file__))
@@ -30,7 +30,15 @@ def main(max_timesteps=4e6, start_timesteps=1e4, eval_freq=1e4, out_dir=None, se
     action_dim = env.action_space.shape[0]
     max_action = float(env.action_space.high[0])
     policy = TD3Agent(state_dim, action_dim, max_action)
+    if os.path.exists(models_path + "/" + "plen_walk_gazebo_" + str(policy_num) + "_critic"):     # plen_td3.py:57-62
+        if not quiet:
+            print("Loading Existing Policy")
+        policy.load(models_path + "/" + "plen_walk_gazebo_" + str(policy_num))
     replay_buffer = ReplayBuffer()
+    if os.path.exists(replay_buffer.buffer_path + "/" + "replay_buffer_" + str(buffer_number) + '.data'):   # plen_td3.py:64-69
+        if not quiet:
+            print("Loading Replay Buffer " + str(buffer_number))
+        replay_buffer.load(buffer_number)
     evaluations = []
     state = env.reset()
     done = False

@@ -38,6 +38,35 @@ def setup_distributed():
     return int(os.environ.get("RANK", "0")), world
 
 
+def save_training(agent, trainer, prefix):
+    """Checkpoint = the reference's four files (td3.py:358-366) + the two target networks (which the reference's
+    save/load silently drops, SURVEY App. A #10) + a small JSON with the loop counters."""
+    agent.save(prefix)
+    torch.save(agent.actor_target.state_dict(), prefix + "_actor_target")
+    torch.save(agent.critic_target.state_dict(), prefix + "_critic_target")
+    with open(prefix + "_trainer.json", "w") as fh:
+        json.dump({"env_steps": int(trainer.env_steps), "grad_steps": int(trainer.grad_steps), "total_it": int(agent.total_it)}, fh)
+
+
+def resume_training(agent, replay, prefix, replay_id=None):
+    """Counterpart of plen_td3.py:57-69: load an existing policy (and optionally a replay buffer) if present."""
+    counters = {"env_steps": 0, "grad_steps": 0, "total_it": 0}
+    if os.path.exists(prefix + "_critic"):
+        agent.load(prefix)
+        for net, tgt, suffix in ((agent.actor, agent.actor_target, "_actor_target"), (agent.critic, agent.critic_target, "_critic_target")):
+            if os.path.exists(prefix + suffix):
+                tgt.load_state_dict(torch.load(prefix + suffix, map_location=agent.device, weights_only=True))
+            else:                         # a reference-format checkpoint: start the targets at the loaded networks
+                tgt.load_state_dict(net.state_dict())
+        if os.path.exists(prefix + "_trainer.json"):
+            with open(prefix + "_trainer.json") as fh:
+                counters.update(json.load(fh))
+        agent.total_it = counters["total_it"]
+    if replay_id is not None and os.path.exists(replay.buffer_path + "/replay_buffer_" + str(replay_id) + ".data"):
+        replay.load(replay_id)
+    return counters
+
+
 class VecTD3Trainer(object):
     def __init__(self, env, agent, replay, start_timesteps=10000, expl_noise=0.1, batch_size=4096, updates_per_step=1, seed=0):
         self.env, self.agent, self.replay = env, agent, replay
@@ -54,6 +83,9 @@ class VecTD3Trainer(object):
         n = self.state.shape[0]
         self.ep_return = torch.zeros(n, device=dev)
         self.finished_returns = []
+
+    def restore_counters(self, c):
+        self.env_steps, self.grad_steps = int(c["env_steps"]), int(c["grad_steps"])
 
     def step(self):
         env, agent = self.env, self.agent
@@ -90,6 +122,10 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--save", default=None, help="checkpoint prefix (reference 4-file layout)")
     ap.add_argument("--graphs", type=int, default=1, help="capture collect/update in hipGraphs (single rank only)")
+    ap.add_argument("--resume", default=None, help="checkpoint prefix to continue from (4-file layout + <prefix>_trainer.json; plen_td3.py:57-69)")
+    ap.add_argument("--buffer-path", default=None, help="directory of replay_buffer_<n>.data files (td3.py:128-131)")
+    ap.add_argument("--save-replay", type=int, default=None, help="write the rank-local replay buffer as replay_buffer_<n>.data at the end")
+    ap.add_argument("--load-replay", type=int, default=None, help="read replay_buffer_<n>.data before training (with --resume)")
     a = ap.parse_args(argv)
     from .vec_env import PlenVecEnv
     from .td3 import ReplayBuffer, TD3Agent
@@ -102,10 +138,17 @@ def main(argv=None):
     agent = TD3Agent(26, 18, 1.0, device=dev)
     replay = ReplayBuffer(a.replay, device=dev)
     replay.seed(a.seed + rank)
+    if a.buffer_path:
+        replay.buffer_path = a.buffer_path if world == 1 else os.path.join(a.buffer_path, "rank%d" % rank)
+    resumed = None
+    if a.resume:
+        resumed = resume_training(agent, replay, a.resume, a.load_replay)
     if a.graphs and world == 1:
         tr = GraphedVecTD3Trainer(env, agent, replay, a.start_timesteps, 0.1, a.batch, a.updates_per_step, seed=1000 + rank)
     else:
         tr = VecTD3Trainer(env, agent, replay, a.start_timesteps, 0.1, a.batch, a.updates_per_step, seed=1000 + rank)
+    if resumed:
+        tr.restore_counters(resumed)
     for _ in range(a.warmup):
         tr.step()
     torch.cuda.synchronize()
@@ -128,7 +171,9 @@ def main(argv=None):
                           "updates_per_step": a.updates_per_step, "hip_graphs": bool(a.graphs and world == 1), "steps": a.steps, "ms_per_step": dt / a.steps * 1e3,
                           "critic_loss": float(agent.last_critic_loss) if agent.last_critic_loss is not None else None}))
         if a.save:
-            agent.save(a.save)
+            save_training(agent, tr, a.save)
+    if a.save_replay is not None:
+        replay.save(a.save_replay)
     env.close()
     if world > 1:
         dist.destroy_process_group()
@@ -216,6 +261,13 @@ class GraphedVecTD3Trainer(object):
 
         self._critic_loss = torch.zeros((), device=dev)
         self._collect_fn, self._update_fn = collect, update
+
+    def restore_counters(self, c):
+        """Continue a run: the ring position comes from the (loaded) replay buffer, the update cadence from the counters."""
+        r = self.replay
+        self.host_total = r.size if r.size < r.max_size else r.max_size + r.ptr
+        self.total_t.fill_(self.host_total)
+        self.env_steps, self.grad_steps = int(c["env_steps"]), int(c["grad_steps"])
 
     def _graph(self, key, fn, *args):
         g = self._graphs.get(key)

@@ -397,3 +397,43 @@ def test_graphed_trainer_matches_ring_semantics():
     # terminal transitions carry the dead penalty, non-terminal ones do not
     assert (replay.reward[:replay.size][nd == 0] < -50).all()
     env.close()
+
+
+def test_training_stop_and_resume(tmp_path):
+    """checkpoint (4-file layout + counters) and replay buffer written by one run are picked up by the next
+    (plen_td3.py:57-69): parameters, optimiser state, ring contents/position and update cadence continue."""
+    from plen_ml_walk_amd.td3 import ReplayBuffer, TD3Agent
+    from plen_ml_walk_amd.train_vec import GraphedVecTD3Trainer, VecTD3Trainer, resume_training, save_training
+    n = 64
+    env = _env(n, torch.float32)
+    agent = TD3Agent(26, 18, 1.0)
+    replay = ReplayBuffer(2000); replay.buffer_path = str(tmp_path / "replay")
+    tr = VecTD3Trainer(env, agent, replay, start_timesteps=128, batch_size=64, updates_per_step=1, seed=0)
+    for _ in range(8):
+        tr.step()
+    prefix = str(tmp_path / "ckpt")
+    save_training(agent, tr, prefix); replay.save(7)
+    env.close()
+    # second run, graph trainer this time
+    env2 = _env(n, torch.float32)
+    agent2 = TD3Agent(26, 18, 1.0)
+    replay2 = ReplayBuffer(2000); replay2.buffer_path = replay.buffer_path
+    c = resume_training(agent2, replay2, prefix, 7)
+    assert c["env_steps"] == tr.env_steps and c["grad_steps"] == tr.grad_steps and agent2.total_it == agent.total_it
+    for a, b in zip(agent.critic.parameters(), agent2.critic.parameters()):
+        assert torch.equal(a, b)
+    for a, b in zip(agent.actor_target.parameters(), agent2.actor_target.parameters()):
+        assert torch.equal(a, b)
+    assert replay2.size == replay.size == 8 * n and torch.equal(replay2.state[:replay.size], replay.state[:replay.size])
+    assert torch.equal(replay2.not_done[:replay.size], replay.not_done[:replay.size])
+    tr2 = GraphedVecTD3Trainer(env2, agent2, replay2, start_timesteps=128, batch_size=64, updates_per_step=1, seed=1)
+    tr2.restore_counters(c)
+    assert tr2.host_total == replay.size and int(tr2.total_t) == replay.size
+    for _ in range(3):
+        tr2.step()
+    torch.cuda.synchronize()
+    assert tr2.env_steps > tr.env_steps and tr2.grad_steps > tr.grad_steps and replay2.size > replay.size
+    # the earlier transitions are still there: the ring continued behind them
+    assert torch.equal(replay2.state[:replay.size], replay.state[:replay.size])
+    assert torch.isfinite(agent2.last_critic_loss)
+    env2.close()
