@@ -570,7 +570,10 @@ struct Smem {
 template <typename real>
 __device__ __forceinline__ void kinematics(Smem<real> &s, const DevParams<real> &P, int lane, bool with_vel) {
     const int b = lane < NB ? lane : 0;
-    const real *m = P.mdl[b];
+    // model row of this lane's body, addressed as (uniform base + 32-bit lane offset) so that no 64-bit per-lane pointer has to live in VGPRs
+    const real *const mdl0 = &P.mdl[0][0];
+    const unsigned mo = (unsigned)b * 28u;
+#define MDL(i_) mdl0[mo + (unsigned)(i_)]
     real R[9], O[3], w[3] = {0, 0, 0}, al[3] = {0, 0, 0}, vo[3] = {0, 0, 0}, ao[3] = {0, 0, 0};
     real L[9];
     real qd = 0;
@@ -594,7 +597,7 @@ __device__ __forceinline__ void kinematics(Smem<real> &s, const DevParams<real> 
             // local rotation  L = JR * Rot(axis, q)   (Rodrigues)
             real q = s.st[13 + b - 1];
             qd = s.st[31 + b - 1];
-            real a0 = m[12], a1 = m[13], a2 = m[14];
+            real a0 = MDL(12), a1 = MDL(13), a2 = MDL(14);
             real c = cos_(q), sn = sin_(q), t = 1 - c;
             real Rq[9] = {c + a0 * a0 * t, a0 * a1 * t - a2 * sn, a0 * a2 * t + a1 * sn,
                           a1 * a0 * t + a2 * sn, c + a1 * a1 * t, a1 * a2 * t - a0 * sn,
@@ -602,7 +605,7 @@ __device__ __forceinline__ void kinematics(Smem<real> &s, const DevParams<real> 
 #pragma unroll
             for (int i = 0; i < 3; i++)
 #pragma unroll
-                for (int j = 0; j < 3; j++) L[3 * i + j] = m[3 * i] * Rq[j] + m[3 * i + 1] * Rq[3 + j] + m[3 * i + 2] * Rq[6 + j];
+                for (int j = 0; j < 3; j++) L[3 * i + j] = MDL(3 * i) * Rq[j] + MDL(3 * i + 1) * Rq[3 + j] + MDL(3 * i + 2) * Rq[6 + j];
         }
     }
     const int depth = lane < NB ? c_depth[b] : -1;
@@ -620,7 +623,8 @@ __device__ __forceinline__ void kinematics(Smem<real> &s, const DevParams<real> 
 #pragma unroll
                 for (int j = 0; j < 3; j++) R[3 * i + j] = Rp[3 * i] * L[j] + Rp[3 * i + 1] * L[3 + j] + Rp[3 * i + 2] * L[6 + j];
             real d[3];
-            matvec3(d, Rp, &m[9]);
+            const real jt[3] = {MDL(9), MDL(10), MDL(11)};
+            matvec3(d, Rp, jt);
 #pragma unroll
             for (int i = 0; i < 3; i++) O[i] = Op[i] + d[i];
 #pragma unroll
@@ -631,7 +635,8 @@ __device__ __forceinline__ void kinematics(Smem<real> &s, const DevParams<real> 
                 real wp[3], alp[3], vop[3], aop[3], ax[3], rel[3], t1[3], t2[3];
 #pragma unroll
                 for (int i = 0; i < 3; i++) { wp[i] = s.kin[par][i]; alp[i] = s.kin[par][3 + i]; vop[i] = s.kin[par][6 + i]; aop[i] = s.kin[par][9 + i]; }
-                matvec3(ax, R, &m[12]);
+                const real jax[3] = {MDL(12), MDL(13), MDL(14)};
+                matvec3(ax, R, jax);
 #pragma unroll
                 for (int i = 0; i < 3; i++) { rel[i] = ax[i] * qd; w[i] = wp[i] + rel[i]; }
                 cross3(t1, wp, rel);
@@ -652,26 +657,31 @@ __device__ __forceinline__ void kinematics(Smem<real> &s, const DevParams<real> 
     WSYNC();
     if (lane < NB) {
         real e[3], ax[3];
-        matvec3(e, R, &m[15]);
-        matvec3(ax, R, &m[12]);
+        const real cl[3] = {MDL(15), MDL(16), MDL(17)}, jax[3] = {MDL(12), MDL(13), MDL(14)};
+        matvec3(e, R, cl);
+        matvec3(ax, R, jax);
 #pragma unroll
         for (int i = 0; i < 3; i++) { s.CA[b][i] = O[i] + e[i]; s.CA[b][4 + i] = ax[i]; }
     }
 }
+
+#undef MDL
 
 // ---------------------------------------------------------------- per-body inertia + bias wrench, subtree sums
 template <typename real>
 __device__ __forceinline__ void body_dynamics(Smem<real> &s, const DevParams<real> &P, int lane, real mass_scale) {
     if (lane < NB) {
         const int b = lane;
-        const real *m = P.mdl[b];
+        const real *const mdl0 = &P.mdl[0][0];
+        const unsigned mo = (unsigned)b * 28u;
+#define MDL(i_) mdl0[mo + (unsigned)(i_)]
         real R[9], w[3], al[3], vo[3], ao[3], O[3], c[3];
 #pragma unroll
         for (int i = 0; i < 9; i++) R[i] = s.RO[b][i];
 #pragma unroll
         for (int i = 0; i < 3; i++) { O[i] = s.RO[b][9 + i]; c[i] = s.CA[b][i]; w[i] = s.kin[b][i]; al[i] = s.kin[b][3 + i]; vo[i] = s.kin[b][6 + i]; ao[i] = s.kin[b][9 + i]; }
         // world inertia  Iw = R I R^T  (I symmetric: xx yy zz xy xz yz)
-        real Il[9] = {m[18], m[21], m[22], m[21], m[19], m[23], m[22], m[23], m[20]};
+        real Il[9] = {MDL(18), MDL(21), MDL(22), MDL(21), MDL(19), MDL(23), MDL(22), MDL(23), MDL(20)};
         real T[9], Iw[9];
 #pragma unroll
         for (int i = 0; i < 3; i++)
@@ -681,7 +691,8 @@ __device__ __forceinline__ void body_dynamics(Smem<real> &s, const DevParams<rea
         for (int i = 0; i < 3; i++)
 #pragma unroll
             for (int j = 0; j < 3; j++) Iw[3 * i + j] = (T[3 * i] * R[3 * j] + T[3 * i + 1] * R[3 * j + 1] + T[3 * i + 2] * R[3 * j + 2]) * mass_scale;
-        const real ms = m[24] * mass_scale;
+        const real ms = MDL(24) * mass_scale;
+#undef MDL
         real e[3] = {c[0] - O[0], c[1] - O[1], c[2] - O[2]}, t1[3], t2[3], vc[3], ac[3];
         cross3(t1, w, e);
 #pragma unroll
@@ -1208,6 +1219,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     FRESH_LANE();
     // ---------------- H. apply impulses:  dv = L^-1 (Y Lambda),  v = clamp(v* + dv) ----------------
     {
+        const int k = lane < NV ? lane : 0;                         // (re-derived: the phase-B copy would have to survive the solver)
         const real inv_diag_r = lane < NV ? s.col[k] : (real)0;    // 1/L[k][k], parked in LDS since phase E
         const real vstar_r = lane < NV ? s.v[k] : (real)0;         // v* parked in LDS since phase D
         const real lamP = lam_sum;
@@ -1296,7 +1308,7 @@ template <typename real, bool FAST>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real) == 8 ? 2 : WPE32, sizeof(real) == 8 ? 2 : WPE32))) void plen_env_kernel(StepArgs<real> a) {
     __shared__ Smem<real> s;
     const int env = blockIdx.x;
-    const int lane = threadIdx.x;
+    int lane = threadIdx.x;
     const DevParams<real> &P = *a.P;
     // wave-uniform per-env parameters, pinned to scalar registers (as vector registers they would be spilled across the substeps)
     const real mass_scale = bcast(a.mass_scale ? a.mass_scale[env] : (real)1, 0);
@@ -1334,6 +1346,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real)
         substep<FAST>(s, P, ln, mass_scale, mu_lat, rc, lc, iters, (sub == a.nsub - 1) ? dump : nullptr);
     }
 
+    // the lane id again (one wave per block): the copy from threadIdx.x would otherwise be spilled across the substeps
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
     if (a.mode == MODE_DEBUG) {
         a.state[(size_t)env * REC + lane] = s.st[lane];
         if (lane == 0) { int *ax = a.aux + (size_t)env * AUXN; ax[4] = rc; ax[5] = lc; ax[6] = iters; }
