@@ -778,7 +778,7 @@ __device__ __forceinline__ void euler_from_quat(const real *q, real *rpy) {   //
 // Contact flags of this substep's collision pass are returned in rc/lc, solver iterations in iters.
 template <bool FAST, typename real>
 __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P, const int lane_in, const real mass_scale, const real mu_lat,
-                               int &rc, int &lc, int &iters, real *dump) {
+                               int &rc, int &lc, int &iters, int &load, real *dump) {
     // `lane` is re-laundered through an empty asm at phase boundaries: otherwise the compiler CSEs the
     // `lane == j` masks of every unrolled phase (48 SGPR pairs), keeps them alive across the whole substep
     // and spills them
@@ -1210,6 +1210,9 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         if ((res_i <= thr_i && __ballot((float)resv > thr_f) == 0) || it >= n_iter - 1) { it++; break; }
     }
     iters = it;
+    // issue-slot estimate of this substep (setup + iterations x (motor pass + rows of the active contact points)), for the placement
+    // of the env in the NEXT launch (plen_balance_kernel)
+    load += 4100 + it * (78 + 37 * __builtin_popcount(act) + (act ? 50 : 0));
     // back to impulses: joint lanes u = -(mh + blo) (+ the limit row), normal lanes u = -blo, the rest explicit
     real lam_sum;
     if (is_joint) lam_sum = (-(P.max_imp * diag) - blo + s.lim[2][p] * s.lim[3][p]) * jdi;
@@ -1291,6 +1294,7 @@ struct StepArgs {
     real *next_obs; real *reward; uint8_t *done; real *cur_obs;
     const real *mass_scale; const real *mu_lat;  // per-env domain randomisation or null
     real *dump;                                  // [N][PLENVEC_DUMP] or null
+    const int *perm;                             // block -> env placement for SIMD load balance, or null (identity)
     int n, mode, nsub, auto_reset;
 };
 
@@ -1307,7 +1311,10 @@ __device__ inline double agent_to_env(int j, double a) {
 template <typename real, bool FAST>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real) == 8 ? 2 : WPE32, sizeof(real) == 8 ? 2 : WPE32))) void plen_env_kernel(StepArgs<real> a) {
     __shared__ Smem<real> s;
-    const int env = blockIdx.x;
+#ifdef PGS_STAMPS
+    const long long wave_t0 = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    const int env = a.perm ? a.perm[blockIdx.x] : (int)blockIdx.x;
     int lane = threadIdx.x;
     const DevParams<real> &P = *a.P;
     // wave-uniform per-env parameters, pinned to scalar registers (as vector registers they would be spilled across the substeps)
@@ -1337,13 +1344,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real)
     }
     WSYNC();
 
-    int rc = 0, lc = 0, iters = 0;
+    int rc = 0, lc = 0, iters = 0, load = 0;
     for (int sub = 0; sub < a.nsub; sub++) {
         // keep loop-invariant parameter/model loads INSIDE the substep: hoisted out of this loop they would
         // stay live across everything and be spilled to scratch
         int ln;                                       // ... and so would every lane-dependent constant (one-hots, masks, addresses)
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln) : : "memory");
-        substep<FAST>(s, P, ln, mass_scale, mu_lat, rc, lc, iters, (sub == a.nsub - 1) ? dump : nullptr);
+        substep<FAST>(s, P, ln, mass_scale, mu_lat, rc, lc, iters, load, (sub == a.nsub - 1) ? dump : nullptr);
     }
 
     // the lane id again (one wave per block): the copy from threadIdx.x would otherwise be spilled across the substeps
@@ -1495,7 +1502,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real)
         a.reset_state[(size_t)env * REC + lane] = s.st[lane];
         if (lane < PLENVEC_OBS) a.reset_obs[(size_t)env * PLENVEC_OBS + lane] = ob;
         if (lane < AUXN) {
-            const int v = lane == 4 ? rc : (lane == 5 ? lc : (lane == 6 ? iters : 0));
+            const int v = lane == 4 ? rc : (lane == 5 ? lc : (lane == 6 ? iters : (lane == 7 ? load : 0)));
             a.aux[(size_t)env * AUXN + lane] = v; a.reset_aux[(size_t)env * AUXN + lane] = v;
         }
         return;
@@ -1509,11 +1516,56 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real)
     } else {
         a.state[(size_t)env * REC + lane] = s.st[lane];
         if (lane < AUXN) {
-            const int v = lane == 0 ? gait_cnt : lane == 1 ? ds_cnt : lane == 2 ? ep_step : lane == 3 ? nhist : lane == 4 ? rc : lane == 5 ? lc : lane == 6 ? iters : 0;
+#ifdef PGS_STAMPS     // profiling build: wave lifetime in shader clocks in the spare aux slot
+#ifdef PGS_HWID       // ... or where the wave ran: HW_ID (wave, simd, cu, sh, se) | XCC_ID << 16
+            int hw0, hw1;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw0), "=s"(hw1));
+            const int wave_dt = (hw0 & 0xffff) | ((hw1 & 0xf) << 16);
+#else
+            const int wave_dt = (int)((long long)__builtin_amdgcn_s_memtime() - wave_t0);
+#endif
+#else
+            const int wave_dt = load;      // aux[7]: issue-slot estimate of this step, read by plen_balance_kernel before the next one
+#endif
+            const int v = lane == 0 ? gait_cnt : lane == 1 ? ds_cnt : lane == 2 ? ep_step : lane == 3 ? nhist : lane == 4 ? rc : lane == 5 ? lc : lane == 6 ? iters : wave_dt;
             a.aux[(size_t)env * AUXN + lane] = v;
         }
         if (a.cur_obs && lane < PLENVEC_OBS) a.cur_obs[(size_t)env * PLENVEC_OBS + lane] = ob;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Placement of envs on SIMDs.  One launch of N <= 4096 single-wave blocks is fully co-resident (16 waves per CU)
+// and the dispatcher puts blocks b, b+1024, b+2048, b+3072 on the same SIMD (measured with HW_ID, stable across
+// launches).  Waves differ in cost by 3x (airborne ... both feet planted) and the launch lasts as long as its
+// slowest SIMD, so envs are dealt to blocks by descending cost estimate of their previous step in snake order:
+// every SIMD gets one env of each quartile.  Counting sort on 256 buckets, one block, LDS atomics.
+// Which block an env runs in does not change its result (tests assert bitwise equality with the identity placement).
+// ------------------------------------------------------------------------------------------------
+#define BAL_BUCKETS 256
+__global__ __launch_bounds__(1024) void plen_balance_kernel(int n, const int *aux, int *perm) {
+    __shared__ int hist[BAL_BUCKETS], base[BAL_BUCKETS];
+    const int t = threadIdx.x;
+    if (t < BAL_BUCKETS) hist[t] = 0;
+    __syncthreads();
+    const int groups = 1024;                                  // SIMDs of the chip
+    const int slots = (n + groups - 1) / groups;              // waves per SIMD of this launch
+    for (int e = t; e < n; e += blockDim.x) {
+        const int b = min(BAL_BUCKETS - 1, max(0, aux[(size_t)e * AUXN + 7]) / 448);      // 4 substeps x 50 iterations, both feet: ~110 k
+        atomicAdd(&hist[BAL_BUCKETS - 1 - b], 1);             // heavy envs first
+    }
+    __syncthreads();
+    if (t == 0) { int acc = 0; for (int i = 0; i < BAL_BUCKETS; i++) { base[i] = acc; acc += hist[i]; } }
+    __syncthreads();
+    for (int e = t; e < n; e += blockDim.x) {
+        const int b = min(BAL_BUCKETS - 1, max(0, aux[(size_t)e * AUXN + 7]) / 448);
+        const int r = atomicAdd(&base[BAL_BUCKETS - 1 - b], 1);        // rank by descending cost
+        const int slot = r / groups, g = r % groups;
+        int blk = slot * groups + ((slot & 1) ? groups - 1 - g : g);  // snake over the SIMDs
+        if (blk >= n) blk = slot * groups + g;                      // ragged last slot (n not a multiple of 1024)
+        perm[blk] = e;
+    }
+    (void)slots;
 }
 
 // masked copy of the reset cache into the live state (plenvec_reset)
@@ -1552,8 +1604,8 @@ struct plenvec {
     int n, device, dtype;
     size_t rsz;
     void *P, *state, *reset_state, *reset_obs, *mass_scale, *mu_lat;
-    int *aux, *reset_aux;
-    bool reset_dirty, use_ms, use_mu, fast;
+    int *aux, *reset_aux, *perm;
+    bool reset_dirty, use_ms, use_mu, fast, balance;
     hipEvent_t ev0, ev1;
     int64_t launches, launches_mark;
 };
@@ -1594,6 +1646,11 @@ static int launch_env(plenvec *h, int mode, int nsub, const float *action, const
     a.mass_scale = h->use_ms ? (const real *)h->mass_scale : nullptr;
     a.mu_lat = h->use_mu ? (const real *)h->mu_lat : nullptr;
     a.dump = (real *)dump;
+    a.perm = nullptr;
+    if (mode == MODE_STEP && h->balance) {
+        hipLaunchKernelGGL(plen_balance_kernel, dim3(1), dim3(1024), 0, st, h->n, h->aux, h->perm);
+        a.perm = h->perm;
+    }
     a.n = h->n; a.mode = mode; a.nsub = nsub; a.auto_reset = h->cfg.auto_reset;
     if (h->fast) hipLaunchKernelGGL((plen_env_kernel<real, true>), dim3(h->n), dim3(64), 0, st, a);
     else hipLaunchKernelGGL((plen_env_kernel<real, false>), dim3(h->n), dim3(64), 0, st, a);
@@ -1663,6 +1720,7 @@ int plenvec_create(const PlenCfg *cfg, int num_envs, int device, plenvec_t **out
     HIPCHK(hipMalloc(&h->mu_lat, N * h->rsz));
     HIPCHK(hipMalloc((void **)&h->aux, N * AUXN * sizeof(int)));
     HIPCHK(hipMalloc((void **)&h->reset_aux, N * AUXN * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&h->perm, N * sizeof(int)));
     if (h->dtype == PLENVEC_DTYPE_F64) {
         DevParams<double> p; fill_params(h->cfg, p);
         HIPCHK(hipMalloc(&h->P, sizeof p)); HIPCHK(hipMemcpy(h->P, &p, sizeof p, hipMemcpyHostToDevice));
@@ -1673,6 +1731,8 @@ int plenvec_create(const PlenCfg *cfg, int num_envs, int device, plenvec_t **out
     HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
     h->use_ms = h->use_mu = false; h->launches = 0; h->launches_mark = 0;
     h->fast = getenv("PLENVEC_NO_ASM") == nullptr;
+    // SIMD load balancing pays once SIMDs hold more than one wave each (1024 SIMDs); PLENVEC_NO_BALANCE=1 keeps the identity placement
+    h->balance = num_envs > 1024 && getenv("PLENVEC_NO_BALANCE") == nullptr;
     int rcode = rebuild_reset_cache(h, 0);
     if (rcode != PLENVEC_OK) { plenvec_destroy(h); return rcode; }
     HIPCHK(hipStreamSynchronize(0));
@@ -1684,7 +1744,7 @@ int plenvec_destroy(plenvec_t *h) {
     if (!h) return PLENVEC_OK;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
-    void *bufs[] = {h->state, h->reset_state, h->reset_obs, h->mass_scale, h->mu_lat, h->aux, h->reset_aux, h->P};
+    void *bufs[] = {h->state, h->reset_state, h->reset_obs, h->mass_scale, h->mu_lat, h->aux, h->reset_aux, h->perm, h->P};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);

@@ -1,0 +1,21 @@
+"""Profiling build (-DPGS_STAMPS, variants/stamps.so): distribution of wave lifetimes inside one 4096-env launch."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["PLENVEC_LIB"] = os.path.join(ROOT, "plen_ml_walk_amd", "csrc", "variants", "stamps.so")
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from plen_ml_walk_amd.vec_env import PlenVecEnv
+n = 4096
+env = PlenVecEnv(n); env.reset()
+g = torch.Generator(device="cuda"); g.manual_seed(1)
+acts = torch.rand(60, n, 18, device="cuda", generator=g) * 2 - 1
+for t in range(60):
+    _, _, done, _ = env.step(acts[t])
+    if t in (5, 20, 40, 59):
+        aux = env.get_aux().cpu().numpy()
+        d = aux[:, 7].astype(np.float64); ok = d > 0          # envs that auto-reset this step carry the cached aux (0)
+        d = d[ok]; c = (aux[ok, 4] + aux[ok, 5])
+        print("step %2d: waves %d  cycles min %.0f  p10 %.0f  median %.0f  p90 %.0f  p99 %.0f  max %.0f | feet on ground 0/1/2: %s | median cycles by feet: %s" % (
+            t, len(d), d.min(), np.percentile(d, 10), np.median(d), np.percentile(d, 90), np.percentile(d, 99), d.max(),
+            [int((c == k).sum()) for k in range(3)], [int(np.median(d[c == k])) if (c == k).any() else -1 for k in range(3)]))
+env.close()
