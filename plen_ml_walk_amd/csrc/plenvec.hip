@@ -1355,6 +1355,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real)
 
     // the lane id again (one wave per block): the copy from threadIdx.x would otherwise be spilled across the substeps
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    load = load * 4 / max(a.nsub, 1);          // per 4-substep control step, whatever this launch ran (reset build: 8)
     if (a.mode == MODE_DEBUG) {
         a.state[(size_t)env * REC + lane] = s.st[lane];
         if (lane == 0) { int *ax = a.aux + (size_t)env * AUXN; ax[4] = rc; ax[5] = lc; ax[6] = iters; }
@@ -1516,17 +1517,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real)
     } else {
         a.state[(size_t)env * REC + lane] = s.st[lane];
         if (lane < AUXN) {
-#ifdef PGS_STAMPS     // profiling build: wave lifetime in shader clocks in the spare aux slot
-#ifdef PGS_HWID       // ... or where the wave ran: HW_ID (wave, simd, cu, sh, se) | XCC_ID << 16
+#ifdef PGS_STAMPS     // profiling build: aux[6] = wave lifetime in shader clocks (or HW_ID | XCC_ID << 16 with -DPGS_HWID) instead of the iteration count
+#ifdef PGS_HWID
             int hw0, hw1;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw0), "=s"(hw1));
-            const int wave_dt = (hw0 & 0xffff) | ((hw1 & 0xf) << 16);
+            iters = (hw0 & 0xffff) | ((hw1 & 0xf) << 16);
 #else
-            const int wave_dt = (int)((long long)__builtin_amdgcn_s_memtime() - wave_t0);
+            iters = (int)((long long)__builtin_amdgcn_s_memtime() - wave_t0);
 #endif
-#else
+#endif
             const int wave_dt = load;      // aux[7]: issue-slot estimate of this step, read by plen_balance_kernel before the next one
-#endif
             const int v = lane == 0 ? gait_cnt : lane == 1 ? ds_cnt : lane == 2 ? ep_step : lane == 3 ? nhist : lane == 4 ? rc : lane == 5 ? lc : lane == 6 ? iters : wave_dt;
             a.aux[(size_t)env * AUXN + lane] = v;
         }
