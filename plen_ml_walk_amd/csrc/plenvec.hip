@@ -151,6 +151,12 @@ __device__ __forceinline__ float shift_up1(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
 }
 __device__ __forceinline__ double shift_up1(double x) { return __shfl_up(x, 1); }
+// lane i receives x[i+1] (lane 63 keeps its own)
+__device__ __forceinline__ float shift_down1(float x) {
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double shift_down1(double x) { return __shfl_down(x, 1); }
 // lane i receives x[src_i] through the LDS crossbar (no LDS storage involved)
 __device__ __forceinline__ float gather_lane(float x, int src) {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, x)));
@@ -511,7 +517,7 @@ __device__ __forceinline__ void pgs_row_signed(real (&lim)[4][NV], real &e, cons
 // The candidate impulses are broadcast, the radial projection onto the friction circle is evaluated in
 // the two lanes themselves: new u = (u - e) * scale, scale = min(1, lm / |s|).
 template <int PN, typename real>
-__device__ __forceinline__ void pgs_cone(real &e, const real u, real &dvec, real &resv, const real lmv, const real jdi, const real aA, const real aB,
+__device__ __forceinline__ void pgs_cone(real &e, const real u, real &dvec, const real lmv, const real jdi, const real aA, const real aB,
                                          const int lane) {
 #pragma clang fp contract(off)      // same roundings in every instantiation: fused ops are written out
     constexpr int PA = PN + 1, PB = PN + 2;
@@ -526,7 +532,6 @@ __device__ __forceinline__ void pgs_cone(real &e, const real u, real &dvec, real
     const real d = fma_(w, scale, -u);              // deltaVel of this lane's row
     const real dA = bcast(d, PA), dB = bcast(d, PB);
     dvec = wrlane<PA>(dvec, dA, lane); dvec = wrlane<PB>(dvec, dB, lane);     // u += dvec after the pass (no lane masks kept alive)
-    resv = max_(resv, abs_(dA + dB));
     e = fma_(dB, aB, fma_(dA, aA, e));
 }
 
@@ -1105,6 +1110,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         const int pn0 = 18 + 15 * pf + 3;
         fc0 = mu * s.lamP[pn0]; fc1 = mu * s.lamP[pn0 + 3]; fc2 = mu * s.lamP[pn0 + 6]; fc3 = mu * s.lamP[pn0 + 9];
     }
+    const real selA = (is_lin && pax == 1) ? (real)1 : (real)0;     // 1 in the first lane of every lateral-friction pair
     const int tors_src = 18 + 15 * pf + 3;                    // lane of the first normal port of this lane's foot
     const real nfcn = (is_lin && pax == 0) ? -mu_lat * jdi : (real)0;   // lane PN: mu_lat * lambda_n = nfcn * blo
 
@@ -1199,9 +1205,12 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                 const real lmv = pax == 1 ? l1 : l2;
                 for_foot_points(act, [&](auto fc_, auto kc) {
                     constexpr int PN = port_normal(4 * decltype(fc_)::value + decltype(kc)::value);
-                    pgs_cone<PN>(e, u0, dvec, resv, lmv, jdi, Ar[PN + 1], Ar[PN + 2], lane);
+                    pgs_cone<PN>(e, u0, dvec, lmv, jdi, Ar[PN + 1], Ar[PN + 2], lane);
                 });
             }
+            // Bullet's residual of a pair is |dA + dB|: after the pass every pair's deltas sit in its two lanes of dvec,
+            // so one DPP add forms all the sums at once in the A lanes (instead of two VALU ops per pair)
+            resv = max_(resv, abs_(dvec + shift_down1(dvec)) * selA);
             u0 += dvec; dvec = 0;
         }
         ISTAMP(6);
