@@ -106,7 +106,8 @@ int plenvec_step(plenvec_t *h, const float *action, void *next_obs, void *reward
 int plenvec_get_state(plenvec_t *h, void *state, void *stream);
 int plenvec_set_state(plenvec_t *h, const void *state, void *stream);
 /* aux: int32[num_envs][8] = gait counter, double-support counter, episode step, history length,
- * right contact, left contact, solver iterations of the last substep, reserved */
+ * right contact, left contact, solver iterations of the last substep, issue-slot estimate of the last step
+ * (internal: plenvec_step places envs on SIMDs by it; any value is legal, results do not depend on it) */
 int plenvec_get_aux(plenvec_t *h, int32_t *aux, void *stream);
 
 /* Test hook: run `nsub` raw physics substeps (p.stepSimulation(), plen_env.py:667) with the given

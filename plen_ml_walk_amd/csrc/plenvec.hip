@@ -166,13 +166,6 @@ __device__ __forceinline__ double gather_lane(double x, int src) { return __shfl
 // all 64 lanes of the single-wave workgroup see each other's LDS writes after this
 #define WSYNC() __syncthreads()
 
-template <typename real>
-__device__ inline real wave_max(real x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x = max_(x, __shfl_xor(x, o));
-    return x;
-}
-
 // compile-time loop: f(std::integral_constant<int, i>) for i in [0, N)
 template <int... Is, typename F>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) { (f(std::integral_constant<int, Is>{}), ...); }
@@ -205,14 +198,14 @@ __device__ __forceinline__ unsigned absbits(double x) { return __builtin_bit_cas
 // bounds are fixed (blo = lo - u, bhi = hi - u), so that one row update is
 //     d = clamp(-e, blo, bhi);   lane PP: blo -= d, bhi -= d;   every lane: e += At[.][PP] * d
 // i.e. the dependent chain through e is  med3 -> readlane -> fmac.  d is Bullet's per-row residual
-// "deltaVel"; its running max lives on the scalar unit as IEEE bits (res_i).
-// f32 fast path: hand-written, the commit to lane PP is done by narrowing EXEC to that lane
-// (s_lshl_b64 exec, 1, PP) instead of keeping 48 lane masks alive.  The compiler path does the same
-// arithmetic in the same order; tests assert the two are bit-identical.
-// ------------------------------------------------------------------------------------------------
-// Deferred-commit forms: the row's delta is dropped into lane PP of `dvec` with v_writelane (no EXEC
-// narrowing); the caller applies  blo -= dvec (bhi -= dvec)  once after the pass.  Valid because a
-// lane hosts at most one such row per pass.
+// "deltaVel"; each lane keeps the max |d| of the rows it hosted and the exit test is one compare + ballot
+// (the rare joint-limit rows keep a scalar max of IEEE bits, res_i).
+// The commit is deferred: the row's delta is dropped into lane PP of `dvec` with v_writelane and the caller
+// applies  blo -= dvec (bhi -= dvec)  once after the pass; valid because a lane hosts at most one such row
+// per pass.  (Measured alternatives, all slower: narrowing EXEC to lane PP, an LDS slot written by lane PP,
+// skipping the broadcast of zero deltas with a scalar branch.)
+// f32 fast path: hand-written; the compiler path does the same arithmetic in the same order and tests
+// assert the two are bit-identical.
 template <bool FAST, int PP, typename real>
 __device__ __forceinline__ void pgs_row2d(real &e, const real blo, const real bhi, real &dvec, const real acol, const int lane) {
     if constexpr (FAST && sizeof(real) == 4) {
@@ -235,29 +228,6 @@ __device__ __forceinline__ void pgs_row2d(real &e, const real blo, const real bh
         e = fma_(db, acol, e);
     }
 }
-template <bool FAST, int PP, typename real>
-__device__ __forceinline__ void pgs_row1d(real &e, const real blo, real &dvec, const real acol, const int lane) {
-    if constexpr (FAST && sizeof(real) == 4) {
-        float d;
-        int sd;
-        asm volatile(
-            "v_max_f32 %[d], -%[e], %[blo]\n\t"
-            "s_nop 0\n\t"
-            "v_readlane_b32 %[sd], %[d], %[pp]\n\t"
-            "s_nop 1\n\t"
-            "v_writelane_b32 %[dv], %[sd], %[pp]\n\t"
-            "v_fmac_f32 %[e], %[sd], %[a]\n\t"
-            : [d] "=&v"(d), [sd] "=&s"(sd), [dv] "+v"(dvec), [e] "+v"(e)
-            : [blo] "v"(blo), [a] "v"(acol), [pp] "i"(PP));
-    } else {
-#pragma clang fp contract(off)
-        const real d = max_(-e, blo);
-        const real db = bcast(d, PP);
-        if (lane == PP) dvec = db;
-        e = fma_(db, acol, e);
-    }
-}
-
 // The 18 motor rows of one pass as ONE software-pipelined block (f32 fast path): the v_writelane that commits
 // row i-1 sits in the wait state between row i's v_med3 and its v_readlane, so a row costs
 // med3 | writelane(prev) | readlane | s_nop 1 | fmac  = 4 VALU + 1 wait instead of 4 VALU + 2 waits.
