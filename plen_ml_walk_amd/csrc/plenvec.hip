@@ -520,8 +520,13 @@ template <typename real>
 struct Smem {
     real st[REC];
     real tgt[NV];
-    real RO[NB][12];    // world rotation (9, row major) + frame origin (3)
-    real CA[NB][8];     // COM world (3) | pad | joint axis world (3) | pad
+    union {
+        struct {
+            real RO[NB][12];    // world rotation (9, row major) + frame origin (3)
+            real CA[NB][8];     // COM world (3) | pad | joint axis world (3) | pad
+        };
+        real park[2][64];       // phase F only (frames are dead after the collision pass): per-lane values parked out of registers
+    };
     alignas(16) real M[NV][NV]; // mass matrix, later its Cholesky factor L (lower); rows read as broadcast b128
     real v[NV];         // generalized velocity after the unconstrained update
     real col[NV];       // broadcast buffer
@@ -902,14 +907,19 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     FRESH_LANE();
     // ---------------- E. collision (feet vs ground) and port Jacobians ----------------
     // port p: 0..17 joint d | 18+15f+{0,1,2} foot f torsional (n, dir1, dir2) | 18+15f+3+3k+{0,1,2} point k linear
-    const int p = lane < NPORT ? lane : 0;
-    const bool is_joint = lane < ND;
-    const int pf = (p - 18) / 15;                 // foot (valid for p >= 18)
-    const int pl = (p - 18) - 15 * pf;            // 0..14 within foot
-    const bool is_tors = lane >= ND && lane < NPORT && pl < 3;
-    const bool is_lin = lane >= ND && lane < NPORT && pl >= 3;
-    const int pk = is_lin ? (pl - 3) / 3 : 0;     // contact point
-    const int pax = is_lin ? (pl - 3) % 3 : pl;   // 0 normal, 1 dir1 (0,-1,0), 2 dir2 (1,0,0)
+    // (not const: re-derived from the fresh lane id after phase F, so that none of them lives through it)
+    int p, pf, pl, pk, pax;
+    bool is_joint, is_tors, is_lin;
+#define LANE_ROLES() do { \
+        p = lane < NPORT ? lane : 0; is_joint = lane < ND; \
+        pf = (p - 18) / 15;                 /* foot (valid for p >= 18) */ \
+        pl = (p - 18) - 15 * pf;            /* 0..14 within foot */ \
+        is_tors = lane >= ND && lane < NPORT && pl < 3; \
+        is_lin = lane >= ND && lane < NPORT && pl >= 3; \
+        pk = is_lin ? (pl - 3) / 3 : 0;     /* contact point */ \
+        pax = is_lin ? (pl - 3) % 3 : pl;   /* 0 normal, 1 dir1 (0,-1,0), 2 dir2 (1,0,0) */ \
+    } while (0)
+    LANE_ROLES();
     const int fb = pf == 0 ? GEN_RFOOT_BODY : GEN_LFOOT_BODY;
     real dist = 0;
     real Pw[3] = {0, 0, 0};
@@ -972,9 +982,11 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
 #pragma unroll
         for (int j = 0; j < NV; j++) s.YT[j][p] = Jr[j];
     }
+    s.park[0][lane] = bvel; s.park[1][lane] = dist;      // needed again in phase G; phase F needs every register
     WSYNC();
     STAMP();
     FRESH_LANE();
+    p = lane < NPORT ? lane : 0;
     // ---------------- F. port Delassus matrix, one row per lane in registers ----------------
     // A[p][q] = Y_p . Y_q.  Y inherits the tree sparsity: coordinate j of a port's column is nonzero only if
     // DoF j supports the port, so the base coordinates couple all 48 ports, a leg's coordinates only that
@@ -986,29 +998,76 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
 #pragma unroll
     for (int q = 0; q < NPORT / 2; q++) Ar2[q] = (vec2){0, 0};
     real diag = 0;
-    auto a_row = [&](const int j, auto lo_c, auto n_c, const bool first) {
-        constexpr int LO = decltype(lo_c)::value, N = decltype(n_c)::value;
-        const real yj = s.YT[j][p];
-        if (first) diag += yj * yj;
-        const vec2 y2 = {yj, yj};
-        const vec2 *rowp = reinterpret_cast<const vec2 *>(&s.YT[j][0]);
-        static_for<N>([&](auto ic) { constexpr int I = LO + decltype(ic)::value; Ar2[I] += y2 * rowp[I]; });
-    };
+    // The rows of Y come from LDS (uniform addresses, b64 per pair).  The loops over j stay rolled (only the 48
+    // accumulators and two row buffers are live) and are software-pipelined by hand: the reads of the next
+    // (half-)row are issued before the multiply-adds of the current one, so the LDS latency of ~100 cycles per
+    // row is overlapped instead of exposed 24 times.
     using std::integral_constant;
+    auto row_ptr = [&](const int j) { return reinterpret_cast<const vec2 *>(&s.YT[j][0]); };
+    {   // base coordinates j = 0..5: all 24 pairs, in four chunks of 6 (two 12-register buffers in flight)
+        vec2 bufA[6], bufB[6];
+        auto ld = [&](vec2 (&b)[6], const int j, auto cc) {
+            const vec2 *r = row_ptr(j) + 6 * decltype(cc)::value;
+#pragma unroll
+            for (int i = 0; i < 6; i++) b[i] = r[i];
+        };
+        auto mac = [&](const vec2 (&b)[6], const vec2 y2, auto cc) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) Ar2[6 * decltype(cc)::value + i] += y2 * b[i];
+        };
+        integral_constant<int, 0> c0; integral_constant<int, 1> c1; integral_constant<int, 2> c2; integral_constant<int, 3> c3;
+        ld(bufA, 0, c0);
+        real yj = s.YT[0][p];
 #pragma unroll 1
-    for (int j = 0; j < 6; j++) a_row(j, integral_constant<int, 0>{}, integral_constant<int, NPORT / 2>{}, true);
-    static_for<2>([&](auto fc_) {        // leg f: DoFs 6+6f..11+6f, joint ports 6f..6f+5, foot ports 18+15f..32+15f (pair 16 = ports 32|33 is shared)
-        constexpr int f = decltype(fc_)::value;
+        for (int j = 0; j < 6; j++) {
+            const int jn = j < 5 ? j + 1 : 5;                 // (the last prefetch re-reads row 5: harmless, keeps the loop uniform)
+            const vec2 y2 = {yj, yj};
+            diag += yj * yj;
+            ld(bufB, j, c1); mac(bufA, y2, c0);
+            ld(bufA, j, c2); mac(bufB, y2, c1);
+            ld(bufB, j, c3); mac(bufA, y2, c2);
+            yj = s.YT[jn][p];
+            ld(bufA, jn, c0); mac(bufB, y2, c3);
+        }
+    }
+    static_for<2>([&](auto fc_) {        // leg f: DoFs 6+6f..11+6f, joint ports 6f..6f+5 (pairs 3f..3f+2), foot ports 18+15f..32+15f (pairs 9+7f..16+7f; pair 16 = ports 32|33 is shared)
+        constexpr int f = decltype(fc_)::value, J0 = 6 + 6 * f, PJ = 3 * f, PC = 9 + 7 * f;
+        vec2 bufA[6], bufB[5];           // A: the 3 joint pairs + the first 3 foot pairs, B: the other 5 foot pairs
+        auto ldA = [&](const int j) {
+            const vec2 *r = row_ptr(j);
+#pragma unroll
+            for (int i = 0; i < 3; i++) { bufA[i] = r[PJ + i]; bufA[3 + i] = r[PC + i]; }
+        };
+        ldA(J0);
+        real yj = s.YT[J0][p];
 #pragma unroll 1
-        for (int j = 6 + 6 * f; j < 12 + 6 * f; j++) {
-            a_row(j, integral_constant<int, 3 * f>{}, integral_constant<int, 3>{}, true);
-            a_row(j, integral_constant<int, 9 + 7 * f>{}, integral_constant<int, 8>{}, false);
+        for (int j = J0; j < J0 + 6; j++) {
+            const int jn = j < J0 + 5 ? j + 1 : J0 + 5;
+            const vec2 y2 = {yj, yj};
+            diag += yj * yj;
+            {
+                const vec2 *r = row_ptr(j);
+#pragma unroll
+                for (int i = 0; i < 5; i++) bufB[i] = r[PC + 3 + i];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++) { Ar2[PJ + i] += y2 * bufA[i]; Ar2[PC + i] += y2 * bufA[3 + i]; }
+            yj = s.YT[jn][p];
+            ldA(jn);
+#pragma unroll
+            for (int i = 0; i < 5; i++) Ar2[PC + 3 + i] += y2 * bufB[i];
         }
     });
-    static_for<2>([&](auto ac_) {        // arm a: DoFs 18+3a..20+3a, joint ports 12+3a..14+3a
+    static_for<2>([&](auto ac_) {        // arm a: DoFs 18+3a..20+3a, joint ports 12+3a..14+3a (pairs 6+a, 7+a); three rows, unrolled
         constexpr int a = decltype(ac_)::value;
-#pragma unroll 1
-        for (int j = 18 + 3 * a; j < 21 + 3 * a; j++) a_row(j, integral_constant<int, 6 + a>{}, integral_constant<int, 2>{}, true);
+#pragma unroll
+        for (int j = 18 + 3 * a; j < 21 + 3 * a; j++) {
+            const real yj = s.YT[j][p];
+            diag += yj * yj;
+            const vec2 y2 = {yj, yj};
+            const vec2 *r = row_ptr(j);
+            Ar2[6 + a] += y2 * r[6 + a]; Ar2[7 + a] += y2 * r[7 + a];
+        }
     });
     const real EPS = sizeof(real) == 8 ? (real)2.220446049250313e-16 : (real)1.1920929e-07;
     const real jdi = diag > EPS ? (real)1 / diag : (real)0;
@@ -1016,8 +1075,8 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         if (lane < NPORT) {
 #pragma unroll
             for (int q = 0; q < NPORT; q++) dump[1216 + lane * NPORT + q] = Ar2[q / 2][q % 2];
-            dump[3520 + lane] = bvel;
-            dump[3568 + lane] = dist;
+            dump[3520 + lane] = s.park[0][lane];
+            dump[3568 + lane] = s.park[1][lane];
         }
     }
     // The solver below works with velocity-scaled impulses u = lambda * diag (so a row's impulse
@@ -1035,6 +1094,9 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     STAMP();
     FRESH_LANE();
     // ---------------- G. rows ----------------
+    LANE_ROLES();
+    const real bvel_g = s.park[0][lane], dist_g = s.park[1][lane];
+    const bool cp_active_g = is_lin && dist_g <= P.brk[pf];
     // joint lanes: motor row (+ a limit row when violated); contact lanes: one row per port, except the
     // torsional ports which carry one row per active contact point of their foot (same Jacobian).
     real rv = 0;                                   // velocity-level right-hand side of this lane's port
@@ -1045,29 +1107,29 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     const real dis = jdi > 0 ? (real)1 : (real)0;  // a row whose diagonal vanished is disabled (m_jacDiagABInv = 0)
     if (is_joint) {
         const real q = s.st[13 + p], tgt = s.tgt[p];
-        rv = (P.kp * ((tgt - q) * P.inv_dt) + bvel + P.kd * (0 - bvel) - bvel) * dis;
+        rv = (P.kp * ((tgt - q) * P.inv_dt) + bvel_g + P.kd * (0 - bvel_g) - bvel_g) * dis;
         bhi = P.max_imp * diag; blo = -bhi;        // lambda in [-0.15 dt, 0.15 dt]  <=>  u in [-mh, mh]
         const real lo = (real)GEN_LOWER_LIMIT, hi = (real)GEN_UPPER_LIMIT;
         const real pen_lo = q - lo, pen_hi = hi - q;
         if (pen_lo <= 0) {
             lim_active = true; sgn_lim = 1;
             const real pos_err = pen_lo > (real)-0.04 ? -pen_lo * P.erp * P.inv_dt : (real)0;
-            rv_lim = (pos_err - bvel) * dis;
+            rv_lim = (pos_err - bvel_g) * dis;
         } else if (pen_hi <= 0) {
             lim_active = true; sgn_lim = -1;
             const real pos_err = pen_hi > (real)-0.04 ? -pen_hi * P.erp * P.inv_dt : (real)0;
-            rv_lim = (pos_err + bvel) * dis;
+            rv_lim = (pos_err + bvel_g) * dis;
         }
     } else if (is_lin && pax == 0) {
-        const real distance = dist + P.slop;
-        real rest = abs_(bvel) < P.rest_thr ? (real)0 : P.restitution * -bvel;
+        const real distance = dist_g + P.slop;
+        real rest = abs_(bvel_g) < P.rest_thr ? (real)0 : P.restitution * -bvel_g;
         rest = max_(rest, (real)0);
-        real pos_err = 0, vel_err = rest - bvel;
+        real pos_err = 0, vel_err = rest - bvel_g;
         if (distance > 0) vel_err -= distance * P.inv_dt; else pos_err = -distance * P.erp2 * P.inv_dt;
         rv = (pos_err + vel_err) * dis;
-        bhi = cp_active ? (real)1e30 : (real)0;    // lambda_n in [0, 1e10] (never reached); a point out of range gets (0, 0): its row is a no-op
+        bhi = cp_active_g ? (real)1e30 : (real)0;    // lambda_n in [0, 1e10] (never reached); a point out of range gets (0, 0): its row is a no-op
     } else if (lane < NPORT) {
-        rv = (0 - bvel) * dis;
+        rv = (0 - bvel_g) * dis;
     }
     if (lane < NV) { s.lim[0][lane] = rv; s.lim[1][lane] = rv_lim; s.lim[2][lane] = sgn_lim; s.lim[3][lane] = 0; }
     const unsigned long long lim_ballot = __ballot(lim_active);
