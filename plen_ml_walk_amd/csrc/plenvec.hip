@@ -177,11 +177,16 @@ __device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_in
 // 4 cycles, ~66% busy), so a taken scalar branch (latency only) is cheaper than a wasted no-op row, and
 // a separate straight-line copy for "all four points in range" only added register spills (measured).
 template <typename F>
-__device__ __forceinline__ void for_foot_points(const unsigned act, F &&row) {
+__device__ __forceinline__ void for_foot_points(unsigned act, F &&row) {
+    // `act` is laundered through an empty asm: loop-invariant, the compiler otherwise hoists the eight point tests out of
+    // the solver loop as 64-bit lane masks and lays the rows out as two interleaved copies in which a planted foot takes
+    // a TAKEN branch per row (~40 cycles each, 32 per iteration).  This way each test is s_bitcmp + a branch that falls
+    // through for a point in range.
+    asm volatile("" : "+s"(act));
     static_for<2>([&](auto fc_) {
         constexpr int f = decltype(fc_)::value;
         const unsigned nib = (act >> (4 * f)) & 0xfu;
-        if (nib) static_for<4>([&](auto kc) { if (nib & (1u << decltype(kc)::value)) row(fc_, kc); });
+        if (nib) static_for<4>([&](auto kc) { if (__builtin_expect((nib & (1u << decltype(kc)::value)) != 0, 1)) row(fc_, kc); });
     });
 }
 
