@@ -264,16 +264,17 @@ def test_asm_path_bitwise_equals_compiler_path(tmp_path):
     assert np.array_equal(outs[0], outs[1], equal_nan=True)
 
 
-def test_simd_load_balancing_does_not_change_results(tmp_path):
+@pytest.mark.parametrize("nenv", [2048, 1500, 3000])       # full slots, ragged odd last slot, ragged even last slot
+def test_simd_load_balancing_does_not_change_results(tmp_path, nenv):
     """plen_balance_kernel only decides WHICH block (hence SIMD) runs an env; 2048 envs x 25 steps must be bit-identical with
     the identity placement (PLENVEC_NO_BALANCE=1), including across auto-resets, and the placement must be a permutation."""
     code = ("import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
             "from plen_ml_walk_amd.vec_env import PlenVecEnv\n"
-            "g = torch.Generator().manual_seed(2); acts = (torch.rand(25, 2048, 18, generator=g) * 2 - 1).float().cuda()\n"
-            "env = PlenVecEnv(2048); env.reset(); out = []\n"
+            "g = torch.Generator().manual_seed(2); acts = (torch.rand(25, %d, 18, generator=g) * 2 - 1).float().cuda()\n"
+            "env = PlenVecEnv(%d); env.reset(); out = []\n"
             "for t in range(25):\n"
             "    o, r, d, _ = env.step(acts[t]); out.append(torch.cat([o, r[:, None], d.float()[:, None]], 1).cpu().numpy().copy())\n"
-            "np.save(sys.argv[1], np.array(out)); np.save(sys.argv[1] + '.state.npy', env.get_state().cpu().numpy())\n" % ROOT)
+            "np.save(sys.argv[1], np.array(out)); np.save(sys.argv[1] + '.state.npy', env.get_state().cpu().numpy())\n" % (ROOT, nenv, nenv))
     outs = []
     for tag, extra in (("bal", {}), ("ident", {"PLENVEC_NO_BALANCE": "1"})):
         p = str(tmp_path / (tag + ".npy"))
