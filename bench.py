@@ -82,11 +82,12 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--groups", type=int, default=2, help="independent sub-batches per GPU, one HIP stream each (1 = a single launch per step)")
     a = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from plen_ml_walk_amd.vec_env import PlenVecEnv
+    from plen_ml_walk_amd.vec_env import PlenVecEnvPipelined
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -101,7 +102,8 @@ def main():
 
     n = a.envs_per_gpu
     dtype = torch.float32 if a.dtype == "f32" else torch.float64
-    env = PlenVecEnv(n, device=dev, dtype=dtype)
+    # sub-batches on their own streams: the tail of one launch (its slowest waves) overlaps the body of the other's next step
+    env = PlenVecEnvPipelined(n, groups=a.groups, device=dev, dtype=dtype)
     env.reset()
     g = torch.Generator(device=dev).manual_seed(rank)
     # a ring of pre-generated action batches resident in HBM (64 x 4096 x 18 f32 = 19 MB)
@@ -110,16 +112,21 @@ def main():
     done_count = torch.zeros((), dtype=torch.int64, device=dev)
 
     for t in range(a.warmup):
-        env.step(actions[t % ring])
+        env.step_async(actions[t % ring])
+    env.sync()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    env.timing_begin()
+    with torch.cuda.stream(env.streams[0]):          # HIP events on the stream the dominant kernel is launched on (sub-batch 0)
+        env.envs[0].timing_begin()
     t0 = time.perf_counter()
     for t in range(a.steps):
-        _, _, done, _ = env.step(actions[(a.warmup + t) % ring])
-    kernel_ms, launches = env.timing_end()
+        env.step_async(actions[(a.warmup + t) % ring])
+    with torch.cuda.stream(env.streams[0]):
+        kernel_ms, launches = env.envs[0].timing_end()
+    env.sync()
+    done = env.outputs()[2]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -135,12 +142,13 @@ def main():
         total_env_steps = world * n * a.steps
         value = total_env_steps / elapsed
         launch_s = kernel_ms * 1e-3 / max(launches, 1)
-        achieved = n * ALGO_BYTES_PER_ENV_STEP / launch_s / 1e9
+        n_launch = n // a.groups                              # env-steps one launch processes
+        achieved = n_launch * ALGO_BYTES_PER_ENV_STEP / launch_s / 1e9
         pmc, pmc_file = _pmc_summary()
-        traffic = pmc["hbm_traffic_bytes"] if (pmc and n == ENVS_PER_GPU and a.dtype == "f32") else None
+        traffic = pmc["hbm_traffic_bytes"] * n_launch / ENVS_PER_GPU if (pmc and n == ENVS_PER_GPU and a.dtype == "f32") else None
         valu = None
         if pmc and a.dtype == "f32":
-            ginst = pmc["valu_insts_per_env_step"] * n / launch_s / 1e9
+            ginst = pmc["valu_insts_per_env_step"] * value / world / 1e9      # whole-GPU issue rate (all concurrent launches)
             valu = {"insts_per_env_step": pmc["valu_insts_per_env_step"], "achieved": ginst, "peak": VALU_PEAK_GINST_S, "unit": "G wave-inst/s",
                     "frac": ginst / VALU_PEAK_GINST_S, "source": pmc_file}
         out = {
@@ -150,6 +158,9 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: %d vectorised PLEN envs per MI355X, random-action rollout, auto-reset "
                                    "(done or 500-step limit), 4 x 240 Hz substeps per 60 Hz step" % n,
                        "envs_per_gpu": n, "total_envs": world * n, "substeps": 4, "solver_iterations": 50,
+                       "sub_batches": "%d x %d envs per GPU on %d HIP streams: every env advances one control step per bench step, sub-batches are "
+                                      "not synchronised with each other between steps (PlenVecEnvPipelined); --groups 1 = one launch per step" %
+                                      (a.groups, n_launch, a.groups),
                        "parallelism": "env-sharded, %d rank(s), no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "valu_issue": valu,
@@ -158,7 +169,7 @@ def main():
                                  "per launch from %s. The contract's hbm/mfma bounds do not bind this kernel: it is a serial "
                                  "projected-Gauss-Seidel chain per env, bound by wave64 VALU issue (valu_issue: one instruction per 4 cycles "
                                  "per SIMD) and by the 4-waves-per-SIMD occupancy the 128-VGPR working set allows; see DESIGN.md" %
-                                 (ALGO_BYTES_PER_ENV_STEP, n, launch_s * 1e3, pmc_file)},
+                                 (ALGO_BYTES_PER_ENV_STEP, n_launch, launch_s * 1e3, pmc_file)},
             "kernel_ms_per_launch": launch_s * 1e3,
         }
         if not a.no_cpu_baseline and world == 1:

@@ -42,7 +42,7 @@ class PlenVecEnv(object):
       `done_bool` the reference stores in the replay buffer (plen_td3.py:109-110);
       info["time_limit"] marks gym TimeLimit truncations (plen_env.py:15-19)."""
 
-    def __init__(self, num_envs, device=None, dtype=torch.float32, joint_act=False, auto_reset=True, cfg_overrides=None):
+    def __init__(self, num_envs, device=None, dtype=torch.float32, joint_act=False, auto_reset=True, cfg_overrides=None, out_buffers=None):
         if not torch.cuda.is_available():
             raise L.PlenvecError("PlenVecEnv needs a ROCm GPU (MI355X); there is no CPU fallback")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -64,10 +64,14 @@ class PlenVecEnv(object):
             L.check(self.lib.plenvec_create(C.byref(cfg), self.num_envs, idx, C.byref(h)))
         self.h = h
         n, dev = self.num_envs, self.device
-        self._next_obs = torch.empty(n, L.OBS, dtype=dtype, device=dev)
-        self._cur_obs = torch.empty(n, L.OBS, dtype=dtype, device=dev)
-        self._reward = torch.empty(n, dtype=dtype, device=dev)
-        self._done = torch.empty(n, dtype=torch.uint8, device=dev)
+        if out_buffers is None:
+            self._next_obs = torch.empty(n, L.OBS, dtype=dtype, device=dev)
+            self._cur_obs = torch.empty(n, L.OBS, dtype=dtype, device=dev)
+            self._reward = torch.empty(n, dtype=dtype, device=dev)
+            self._done = torch.empty(n, dtype=torch.uint8, device=dev)
+        else:                     # slices of a larger batch's outputs (PlenVecEnvPipelined)
+            self._next_obs, self._cur_obs, self._reward, self._done = out_buffers
+            assert all(t.is_contiguous() and t.shape[0] == n for t in out_buffers)
 
     def close(self):
         if getattr(self, "h", None):
@@ -136,3 +140,82 @@ class PlenVecEnv(object):
         ms, n = C.c_double(0), C.c_int64(0)
         L.check(self.lib.plenvec_timing_end(self.h, self._stream(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+class PlenVecEnvPipelined(object):
+    """`num_envs` environments as `groups` independent sub-batches, each with its own libplenvec handle and HIP stream.
+
+    Why: one launch lasts as long as its slowest wave (both feet planted, 50 solver iterations: ~2x the mean wave), so a
+    single-stream loop leaves ~30 % of the wave slots idle at every step boundary.  Environments are independent, so
+    sub-batch A's step t+1 need not wait for sub-batch B's step t: with two streams the tail of one launch overlaps the
+    body of the other (+17 % env-steps/s at 4096 envs, measured).  This is the usual asynchronous sub-batch mode of vector
+    environments; each environment still advances one control step per `step` call with its own action.
+
+    step_async(action) enqueues the sub-batches behind the caller's current stream (so `action` may have been produced on it)
+    and returns immediately; the outputs (shared [N, ...] tensors, group g owning rows [g*N/G, (g+1)*N/G)) may be read after
+    sync().  step() = step_async() + sync().  Outputs are overwritten by the next step: consume or copy them first."""
+
+    def __init__(self, num_envs, groups=2, device=None, dtype=torch.float32, **kw):
+        assert num_envs % groups == 0, "num_envs must be a multiple of groups"
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.num_envs, self.groups, self.dtype = int(num_envs), int(groups), dtype
+        n, g, dev = self.num_envs, self.groups, self.device
+        self.n_sub = n // g
+        self._next_obs = torch.empty(n, L.OBS, dtype=dtype, device=dev)
+        self._cur_obs = torch.empty(n, L.OBS, dtype=dtype, device=dev)
+        self._reward = torch.empty(n, dtype=dtype, device=dev)
+        self._done = torch.empty(n, dtype=torch.uint8, device=dev)
+        sl = [slice(i * self.n_sub, (i + 1) * self.n_sub) for i in range(g)]
+        self._slices = sl
+        self.envs = [PlenVecEnv(self.n_sub, device=dev, dtype=dtype, out_buffers=(self._next_obs[s], self._cur_obs[s], self._reward[s], self._done[s]), **kw)
+                     for s in sl]
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(g)]
+        self._ev_in = torch.cuda.Event()
+        self._ev_out = [torch.cuda.Event() for _ in range(g)]
+        self.max_episode_steps = self.envs[0].max_episode_steps
+
+    def close(self):
+        for e in self.envs:
+            e.close()
+
+    def reset(self, mask=None):
+        self.sync()
+        for e, s in zip(self.envs, self._slices):
+            e.reset(None if mask is None else mask[s])
+        return self._cur_obs
+
+    def step_async(self, action):
+        a = action
+        if a.dtype != torch.float32 or not a.is_contiguous() or a.device != self.device:
+            a = a.to(device=self.device, dtype=torch.float32).contiguous()
+        assert a.shape == (self.num_envs, L.ACT)
+        cur = torch.cuda.current_stream(self.device)
+        self._ev_in.record(cur)
+        for e, s, st, ev in zip(self.envs, self._slices, self.streams, self._ev_out):
+            st.wait_event(self._ev_in)
+            a.record_stream(st)
+            with torch.cuda.stream(st):
+                e.step(a[s])
+                ev.record(st)
+
+    def sync(self):
+        cur = torch.cuda.current_stream(self.device)
+        for ev in self._ev_out:
+            cur.wait_event(ev)
+
+    def step(self, action):
+        self.step_async(action)
+        self.sync()
+        return self._next_obs, self._reward, self._done, StepInfo(self._done, self._cur_obs)
+
+    def outputs(self):
+        """(next_obs, reward, done, info) of the last step; valid after sync()."""
+        return self._next_obs, self._reward, self._done, StepInfo(self._done, self._cur_obs)
+
+    def get_state(self):
+        self.sync()
+        return torch.cat([e.get_state() for e in self.envs], 0)
+
+    def get_aux(self):
+        self.sync()
+        return torch.cat([e.get_aux() for e in self.envs], 0)

@@ -457,3 +457,27 @@ def test_training_stop_and_resume(tmp_path):
     assert torch.equal(replay2.state[:replay.size], replay.state[:replay.size])
     assert torch.isfinite(agent2.last_critic_loss)
     env2.close()
+
+
+def test_pipelined_sub_batches_equal_single_batch():
+    """PlenVecEnvPipelined (independent sub-batches on their own streams, bench.py's mode) is the same environments: 512 envs in
+    two and four groups reproduce the single-launch run bit for bit, through auto-resets, with step() and with step_async()/sync()."""
+    from plen_ml_walk_amd.vec_env import PlenVecEnvPipelined
+    n, T = 512, 30
+    g = torch.Generator().manual_seed(4)
+    acts = (torch.rand(T, n, 18, generator=g) * 2 - 1).float().cuda()
+    ref = _env(n, torch.float32); ref.reset()
+    want = []
+    for t in range(T):
+        o, r, d, info = ref.step(acts[t]); want.append((o.clone(), r.clone(), d.clone(), info["obs"].clone()))
+    ref.close()
+    for groups, use_async in ((2, False), (4, True)):
+        env = PlenVecEnvPipelined(n, groups=groups); env.reset()
+        for t in range(T):
+            if use_async:
+                env.step_async(acts[t]); env.sync(); o, r, d, info = env.outputs()
+            else:
+                o, r, d, info = env.step(acts[t])
+            assert torch.equal(o, want[t][0]) and torch.equal(r, want[t][1]) and torch.equal(d, want[t][2]) and torch.equal(info["obs"], want[t][3]), (groups, t)
+        env.close()
+    assert sum(int(w[2].sum()) for w in want) > 0
