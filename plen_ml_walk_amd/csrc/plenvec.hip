@@ -95,9 +95,11 @@ __device__ __constant__ double c_range_hi[ND] = {1.57, 1.5, 0.75, 0.3, 1.2, 0.4,
 // ---------------------------------------------------------------- math wrappers
 __device__ inline float sqrt_(float x) { return sqrtf(x); }
 __device__ inline double sqrt_(double x) { return sqrt(x); }
-__device__ inline float sin_(float x) { return sinf(x); }
+// f32: the hardware sine/cosine (v_sin_f32 / v_cos_f32 on x / 2pi).  Arguments here are joint angles (|q| < pi) and half rotation
+// angles per substep (< pi/8); measured max abs error on [-pi, pi]: 2.7e-7 (sinf: 6e-8) for 2 instructions instead of ~40.
+__device__ inline float sin_(float x) { return __sinf(x); }
 __device__ inline double sin_(double x) { return sin(x); }
-__device__ inline float cos_(float x) { return cosf(x); }
+__device__ inline float cos_(float x) { return __cosf(x); }
 __device__ inline double cos_(double x) { return cos(x); }
 __device__ inline float atan2_(float y, float x) { return atan2f(y, x); }
 __device__ inline double atan2_(double y, double x) { return atan2(y, x); }
