@@ -1357,64 +1357,73 @@ __device__ inline double agent_to_env(int j, double a) {
 }
 
 template <typename real, bool FAST>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real) == 8 ? 2 : WPE32, sizeof(real) == 8 ? 2 : WPE32))) void plen_env_kernel(StepArgs<real> a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real) == 8 ? 2 : WPE32, sizeof(real) == 8 ? 2 : WPE32))) void plen_env_kernel(StepArgs<real> a_by_value) {
     __shared__ Smem<real> s;
+    // The 16-dword argument block is read through the kernarg pointer at the two places that need it (prologue, env epilogue) with
+    // scalar loads, the pointer being laundered so that the loads are not merged into one tuple held (and spilled into VGPR lanes,
+    // ~600 v_readlane per step to get it back) across the substeps.
+    (void)a_by_value;
+    typedef const StepArgs<real> __attribute__((address_space(4))) KArgs;
+#define KARGS() ({ KArgs *p_ = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(p_)); p_; })
+    KArgs *a = KARGS();
 #ifdef PGS_STAMPS
     const long long wave_t0 = (long long)__builtin_amdgcn_s_memtime();
 #endif
-    const int env = a.perm ? a.perm[blockIdx.x] : (int)blockIdx.x;
+    const int env = a->perm ? a->perm[blockIdx.x] : (int)blockIdx.x;
     int lane = threadIdx.x;
-    const DevParams<real> &P = *a.P;
+    const DevParams<real> &P = *a->P;
     // wave-uniform per-env parameters, pinned to scalar registers (as vector registers they would be spilled across the substeps)
-    const real mass_scale = bcast(a.mass_scale ? a.mass_scale[env] : (real)1, 0);
-    const real mu_lat = bcast(a.mu_lat ? a.mu_lat[env] : P.mu_lat, 0);
-    real *dump = a.dump ? a.dump + (size_t)env * PLENVEC_DUMP : nullptr;
+    const real mass_scale = bcast(a->mass_scale ? a->mass_scale[env] : (real)1, 0);
+    const real mu_lat = bcast(a->mu_lat ? a->mu_lat[env] : P.mu_lat, 0);
+    real *dump = a->dump ? a->dump + (size_t)env * PLENVEC_DUMP : nullptr;
+    const int nsub = a->nsub, mode = a->mode;
 
     // ---- load the env record (one coalesced 64-real read) ----
-    if (a.mode == MODE_RESET_BUILD) {
+    if (mode == MODE_RESET_BUILD) {
         real v = 0;
         if (lane == 2) v = P.spawn_z;
         if (lane == 6) v = 1;
         s.st[lane] = v;
     } else {
-        s.st[lane] = a.state[(size_t)env * REC + lane];
+        s.st[lane] = a->state[(size_t)env * REC + lane];
     }
     // ---- motor targets ----
     if (lane < NV) {
         real t = 0;
         if (lane < ND) {
-            if (a.mode == MODE_STEP) {
-                const double act = (double)a.action[(size_t)env * ND + lane];
+            if (mode == MODE_STEP) {
+                const double act = (double)a->action[(size_t)env * ND + lane];
                 t = (real)(P.joint_act ? act : agent_to_env(lane, act));
-            } else if (a.mode == MODE_DEBUG) t = a.targets[(size_t)env * ND + lane];
+            } else if (mode == MODE_DEBUG) t = a->targets[(size_t)env * ND + lane];
         }
         s.tgt[lane] = t;
     }
     WSYNC();
 
     int rc = 0, lc = 0, iters = 0, load = 0;
-    for (int sub = 0; sub < a.nsub; sub++) {
+    for (int sub = 0; sub < nsub; sub++) {
         // keep loop-invariant parameter/model loads INSIDE the substep: hoisted out of this loop they would
         // stay live across everything and be spilled to scratch
         int ln;                                       // ... and so would every lane-dependent constant (one-hots, masks, addresses)
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln) : : "memory");
-        substep<FAST>(s, P, ln, mass_scale, mu_lat, rc, lc, iters, load, (sub == a.nsub - 1) ? dump : nullptr);
+        substep<FAST>(s, P, ln, mass_scale, mu_lat, rc, lc, iters, load, (sub == nsub - 1) ? dump : nullptr);
     }
 
     // the lane id again (one wave per block): the copy from threadIdx.x would otherwise be spilled across the substeps
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
-    load = load * 4 / max(a.nsub, 1);          // per 4-substep control step, whatever this launch ran (reset build: 8)
-    if (a.mode == MODE_DEBUG) {
-        a.state[(size_t)env * REC + lane] = s.st[lane];
-        if (lane == 0) { int *ax = a.aux + (size_t)env * AUXN; ax[4] = rc; ax[5] = lc; ax[6] = iters; }
+    a = KARGS();
+    load = load * 4 / max(nsub, 1);          // per 4-substep control step, whatever this launch ran (reset build: 8)
+    if (mode == MODE_DEBUG) {
+        a->state[(size_t)env * REC + lane] = s.st[lane];
+        if (lane == 0) { int *ax = a->aux + (size_t)env * AUXN; ax[4] = rc; ax[5] = lc; ax[6] = iters; }
         return;
     }
 
     // ================= env level: compute_observation / compute_done / compute_reward =================
     // episode counters (loaded here, not before the substeps: they would only sit in registers meanwhile)
     int gait_cnt = 0, ds_cnt = 0, ep_step = 0, nhist = 0;
-    if (a.mode != MODE_RESET_BUILD) {
-        const int *ax = a.aux + (size_t)env * AUXN;
+    if (mode != MODE_RESET_BUILD) {
+        const int *ax = a->aux + (size_t)env * AUXN;
         gait_cnt = ax[0]; ds_cnt = ax[1]; ep_step = ax[2]; nhist = ax[3];
     }
     if (P.reward_head == 1) {
@@ -1468,7 +1477,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real)
 
     real reward = 0;
     int done_flag = 0;
-    if (a.mode == MODE_STEP) {
+    if (mode == MODE_STEP) {
         // compute_done (plen_env.py:1072-1093): one-sided on roll/pitch/y
         const real PI3 = (real)(3.14159265358979323846 / 3.0);
         const bool dead = (rpy[0] > PI3) || (rpy[1] > PI3) || (torso_z < (real)0.08) || (torso_y > (real)1);
@@ -1532,8 +1541,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real)
         ep_step += 1; gait_cnt += 1;
         const bool trunc = ep_step >= P.max_episode_steps;
         done_flag = (dead ? PLENVEC_DONE_TERMINAL : 0) | ((trunc || gz_timeout) ? PLENVEC_DONE_TIMELIMIT : 0);
-        if (lane < PLENVEC_OBS) a.next_obs[(size_t)env * PLENVEC_OBS + lane] = ob;
-        if (lane == 0) { a.reward[env] = reward; a.done[env] = (uint8_t)done_flag; }
+        if (lane < PLENVEC_OBS) a->next_obs[(size_t)env * PLENVEC_OBS + lane] = ob;
+        if (lane == 0) { a->reward[env] = reward; a->done[env] = (uint8_t)done_flag; }
     } else {
         // reset(): the observation is taken, then the gait bookkeeping is cleared (plen_env.py:574-590)
         nhist = 0; gait_cnt = 0; ds_cnt = 0; ep_step = 0;
@@ -1546,24 +1555,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real)
     if (lane < 9) s.st[55 + lane] = sums[lane];
     WSYNC();
 
-    if (a.mode == MODE_RESET_BUILD) {
-        a.state[(size_t)env * REC + lane] = s.st[lane];
-        a.reset_state[(size_t)env * REC + lane] = s.st[lane];
-        if (lane < PLENVEC_OBS) a.reset_obs[(size_t)env * PLENVEC_OBS + lane] = ob;
+    if (mode == MODE_RESET_BUILD) {
+        a->state[(size_t)env * REC + lane] = s.st[lane];
+        a->reset_state[(size_t)env * REC + lane] = s.st[lane];
+        if (lane < PLENVEC_OBS) a->reset_obs[(size_t)env * PLENVEC_OBS + lane] = ob;
         if (lane < AUXN) {
             const int v = lane == 4 ? rc : (lane == 5 ? lc : (lane == 6 ? iters : (lane == 7 ? load : 0)));
-            a.aux[(size_t)env * AUXN + lane] = v; a.reset_aux[(size_t)env * AUXN + lane] = v;
+            a->aux[(size_t)env * AUXN + lane] = v; a->reset_aux[(size_t)env * AUXN + lane] = v;
         }
         return;
     }
     // ---- MODE_STEP: store, auto-reset when the episode ended (TimeLimit + plen_td3.py:122-133) ----
-    const bool ended = done_flag != 0 && a.auto_reset;
+    const bool ended = done_flag != 0 && a->auto_reset;
     if (ended) {
-        a.state[(size_t)env * REC + lane] = a.reset_state[(size_t)env * REC + lane];
-        if (lane < AUXN) a.aux[(size_t)env * AUXN + lane] = a.reset_aux[(size_t)env * AUXN + lane];
-        if (a.cur_obs && lane < PLENVEC_OBS) a.cur_obs[(size_t)env * PLENVEC_OBS + lane] = a.reset_obs[(size_t)env * PLENVEC_OBS + lane];
+        a->state[(size_t)env * REC + lane] = a->reset_state[(size_t)env * REC + lane];
+        if (lane < AUXN) a->aux[(size_t)env * AUXN + lane] = a->reset_aux[(size_t)env * AUXN + lane];
+        if (a->cur_obs && lane < PLENVEC_OBS) a->cur_obs[(size_t)env * PLENVEC_OBS + lane] = a->reset_obs[(size_t)env * PLENVEC_OBS + lane];
     } else {
-        a.state[(size_t)env * REC + lane] = s.st[lane];
+        a->state[(size_t)env * REC + lane] = s.st[lane];
         if (lane < AUXN) {
 #ifdef PGS_STAMPS     // profiling build: aux[6] = wave lifetime in shader clocks (or HW_ID | XCC_ID << 16 with -DPGS_HWID) instead of the iteration count
 #ifdef PGS_HWID
@@ -1576,9 +1585,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real)
 #endif
             const int wave_dt = load;      // aux[7]: issue-slot estimate of this step, read by plen_balance_kernel before the next one
             const int v = lane == 0 ? gait_cnt : lane == 1 ? ds_cnt : lane == 2 ? ep_step : lane == 3 ? nhist : lane == 4 ? rc : lane == 5 ? lc : lane == 6 ? iters : wave_dt;
-            a.aux[(size_t)env * AUXN + lane] = v;
+            a->aux[(size_t)env * AUXN + lane] = v;
         }
-        if (a.cur_obs && lane < PLENVEC_OBS) a.cur_obs[(size_t)env * PLENVEC_OBS + lane] = ob;
+        if (a->cur_obs && lane < PLENVEC_OBS) a->cur_obs[(size_t)env * PLENVEC_OBS + lane] = ob;
     }
 }
 
