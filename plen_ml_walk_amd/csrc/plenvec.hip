@@ -553,105 +553,151 @@ struct Smem {
 
 
 // ---------------------------------------------------------------- forward kinematics + velocity recursion
-// lane b < 19 owns body b.  Fills RO, CA, kin.  with_vel=false: orientation/position only.
+// Fills RO, CA, kin for the 19 bodies.  with_vel=false: orientation/position only.
+// The tree is a base with four serial chains (6, 6, 3, 3 bodies), so the recursions along a chain are prefix
+// products / prefix sums: chain c lives in DPP row c (lanes 16c+8 ..), preceded by 8 identity lanes, and three
+// Hillis-Steele steps (row_shr 1, 2, 4) compose the chain's transforms; the velocity recursions
+//   w = w_par + rel,  al = al_par + w_par x rel,  vo = vo_par + w_par x d,  ao = ao_par + al_par x d + w_par x (w_par x d)
+// become four prefix sums of locally computable terms.  No LDS round trips, no level loop (which issued six times the
+// useful work with one level of lanes active at a time).
+template <int S>
+__device__ __forceinline__ float row_shr(float x) {        // lane i <- x[i - S] inside its 16-lane row, 0 shifted in
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x110 + S, 0xf, 0xf, true));
+}
+template <int S>
+__device__ __forceinline__ double row_shr(double x) { return __shfl_up(x, S, 16); }   // (lanes i < S keep their own value: they are padding)
+template <typename real>
+__device__ __forceinline__ void prefix3(real *v) {          // inclusive prefix sum along the row, offsets 1, 2, 4 (chains are <= 6 long)
+#pragma unroll
+    for (int i = 0; i < 3; i++) { v[i] += row_shr<1>(v[i]); }
+#pragma unroll
+    for (int i = 0; i < 3; i++) { v[i] += row_shr<2>(v[i]); }
+#pragma unroll
+    for (int i = 0; i < 3; i++) { v[i] += row_shr<4>(v[i]); }
+}
+
 template <typename real>
 __device__ __forceinline__ void kinematics(Smem<real> &s, const DevParams<real> &P, int lane, bool with_vel) {
-    const int b = lane < NB ? lane : 0;
+    const int c = lane >> 4, pos = (lane & 15) - 8;
+    const bool valid = pos >= 0 && pos < (c < 2 ? 6 : 3);
+    const int b = valid ? (c == 0 ? 1 : c == 1 ? 7 : c == 2 ? 13 : 16) + pos : 0;
     // model row of this lane's body, addressed as (uniform base + 32-bit lane offset) so that no 64-bit per-lane pointer has to live in VGPRs
     const real *const mdl0 = &P.mdl[0][0];
     const unsigned mo = (unsigned)b * 28u;
 #define MDL(i_) mdl0[mo + (unsigned)(i_)]
-    real R[9], O[3], w[3] = {0, 0, 0}, al[3] = {0, 0, 0}, vo[3] = {0, 0, 0}, ao[3] = {0, 0, 0};
-    real L[9];
-    real qd = 0;
-    if (lane < NB) {
-        if (b == 0) {
-            real x = s.st[3], y = s.st[4], z = s.st[5], ww = s.st[6];
-            real d = x * x + y * y + z * z + ww * ww, sc = (real)2 / d;
-            real xs = x * sc, ys = y * sc, zs = z * sc;
-            real wx = ww * xs, wy = ww * ys, wz = ww * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
-            R[0] = 1 - (yy + zz); R[1] = xy - wz; R[2] = xz + wy;
-            R[3] = xy + wz; R[4] = 1 - (xx + zz); R[5] = yz - wx;
-            R[6] = xz - wy; R[7] = yz + wx; R[8] = 1 - (xx + yy);
-            O[0] = s.st[0]; O[1] = s.st[1]; O[2] = s.st[2];
-            w[0] = s.st[7]; w[1] = s.st[8]; w[2] = s.st[9];
-            vo[0] = s.st[10]; vo[1] = s.st[11]; vo[2] = s.st[12];
+    // base frame (wave-uniform)
+    real R0[9], O0[3] = {s.st[0], s.st[1], s.st[2]};
+    {
+        const real x = s.st[3], y = s.st[4], z = s.st[5], ww = s.st[6];
+        const real d = x * x + y * y + z * z + ww * ww, sc = (real)2 / d;
+        const real xs = x * sc, ys = y * sc, zs = z * sc;
+        const real wx = ww * xs, wy = ww * ys, wz = ww * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
+        R0[0] = 1 - (yy + zz); R0[1] = xy - wz; R0[2] = xz + wy;
+        R0[3] = xy + wz; R0[4] = 1 - (xx + zz); R0[5] = yz - wx;
+        R0[6] = xz - wy; R0[7] = yz + wx; R0[8] = 1 - (xx + yy);
+    }
+    // transform of this body's frame in its parent's:  rotation Lc = JR * Rot(axis, q) (Rodrigues), translation tc = JT;  identity on the padding lanes
+    real Lc[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, tc[3] = {0, 0, 0}, qd = 0;
+    if (valid) {
+        const real q = s.st[13 + b - 1];
+        qd = s.st[31 + b - 1];
+        const real a0 = MDL(12), a1 = MDL(13), a2 = MDL(14);
+        const real cq = cos_(q), sn = sin_(q), t = 1 - cq;
+        const real Rq[9] = {cq + a0 * a0 * t, a0 * a1 * t - a2 * sn, a0 * a2 * t + a1 * sn,
+                            a1 * a0 * t + a2 * sn, cq + a1 * a1 * t, a1 * a2 * t - a0 * sn,
+                            a2 * a0 * t - a1 * sn, a2 * a1 * t + a0 * sn, cq + a2 * a2 * t};
 #pragma unroll
-            for (int i = 0; i < 9; i++) s.RO[0][i] = R[i];
+        for (int i = 0; i < 3; i++)
 #pragma unroll
-            for (int i = 0; i < 3; i++) { s.RO[0][9 + i] = O[i]; s.kin[0][i] = w[i]; s.kin[0][3 + i] = 0; s.kin[0][6 + i] = vo[i]; s.kin[0][9 + i] = 0; }
-        } else {
-            // local rotation  L = JR * Rot(axis, q)   (Rodrigues)
-            real q = s.st[13 + b - 1];
-            qd = s.st[31 + b - 1];
-            real a0 = MDL(12), a1 = MDL(13), a2 = MDL(14);
-            real c = cos_(q), sn = sin_(q), t = 1 - c;
-            real Rq[9] = {c + a0 * a0 * t, a0 * a1 * t - a2 * sn, a0 * a2 * t + a1 * sn,
-                          a1 * a0 * t + a2 * sn, c + a1 * a1 * t, a1 * a2 * t - a0 * sn,
-                          a2 * a0 * t - a1 * sn, a2 * a1 * t + a0 * sn, c + a2 * a2 * t};
+            for (int j = 0; j < 3; j++) Lc[3 * i + j] = MDL(3 * i) * Rq[j] + MDL(3 * i + 1) * Rq[3 + j] + MDL(3 * i + 2) * Rq[6 + j];
 #pragma unroll
-            for (int i = 0; i < 3; i++)
+        for (int i = 0; i < 3; i++) tc[i] = MDL(9 + i);
+    }
+    // prefix product along the chain:  X_b <- X_(b-S) o X_b,  (Rp, tp) o (Rc, tc) = (Rp Rc, tp + Rp tc)
+    static_for<3>([&](auto sc_) {
+        constexpr int S = 1 << decltype(sc_)::value;
+        real Rp[9], tp[3], Rn[9], tn[3];
 #pragma unroll
-                for (int j = 0; j < 3; j++) L[3 * i + j] = MDL(3 * i) * Rq[j] + MDL(3 * i + 1) * Rq[3 + j] + MDL(3 * i + 2) * Rq[6 + j];
+        for (int i = 0; i < 9; i++) Rp[i] = row_shr<S>(Lc[i]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) tp[i] = row_shr<S>(tc[i]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) Rn[3 * i + j] = Rp[3 * i] * Lc[j] + Rp[3 * i + 1] * Lc[3 + j] + Rp[3 * i + 2] * Lc[6 + j];
+            tn[i] = tp[i] + Rp[3 * i] * tc[0] + Rp[3 * i + 1] * tc[1] + Rp[3 * i + 2] * tc[2];
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++) Lc[i] = Rn[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) tc[i] = tn[i];
+    });
+    // world frame
+    real R[9], O[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) R[3 * i + j] = R0[3 * i] * Lc[j] + R0[3 * i + 1] * Lc[3 + j] + R0[3 * i + 2] * Lc[6 + j];
+        O[i] = O0[i] + R0[3 * i] * tc[0] + R0[3 * i + 1] * tc[1] + R0[3 * i + 2] * tc[2];
+    }
+    real ax[3] = {0, 0, 0};
+    if (valid) {
+        const real jax[3] = {MDL(12), MDL(13), MDL(14)};
+        matvec3(ax, R, jax);
+    }
+    if (with_vel) {
+        const real w0[3] = {s.st[7], s.st[8], s.st[9]}, v0[3] = {s.st[10], s.st[11], s.st[12]};
+        real rel[3], pw[3], w[3], wpar[3], tal[3], al[3], alpar[3], d[3], tvo[3], vo[3], tao[3], t1[3], t2[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) { rel[i] = ax[i] * qd; pw[i] = rel[i]; }
+        prefix3(pw);
+#pragma unroll
+        for (int i = 0; i < 3; i++) { w[i] = w0[i] + pw[i]; wpar[i] = w[i] - rel[i]; }
+        cross3(tal, wpar, rel);
+#pragma unroll
+        for (int i = 0; i < 3; i++) al[i] = tal[i];
+        prefix3(al);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            alpar[i] = al[i] - tal[i];
+            const real dd = O[i] - row_shr<1>(O[i]);          // own origin - parent origin (the lane before a chain holds the base frame)
+            d[i] = valid ? dd : (real)0;
+        }
+        cross3(tvo, wpar, d);
+        cross3(t2, wpar, tvo);          // w_par x (w_par x d)
+        cross3(t1, alpar, d);
+#pragma unroll
+        for (int i = 0; i < 3; i++) { vo[i] = tvo[i]; tao[i] = t1[i] + t2[i]; }
+        prefix3(vo);
+        prefix3(tao);
+        if (valid) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) { s.kin[b][i] = w[i]; s.kin[b][3 + i] = al[i]; s.kin[b][6 + i] = v0[i] + vo[i]; s.kin[b][9 + i] = tao[i]; }
+        } else if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) { s.kin[0][i] = w0[i]; s.kin[0][3 + i] = 0; s.kin[0][6 + i] = v0[i]; s.kin[0][9 + i] = 0; }
         }
     }
-    const int depth = lane < NB ? c_depth[b] : -1;
-    const int par = lane < NB && b > 0 ? c_parent[b] : 0;
-    for (int level = 1; level <= 6; level++) {
-        WSYNC();
-        if (depth == level) {
-            real Rp[9], Op[3];
+    if (valid) {
+        const real cl[3] = {MDL(15), MDL(16), MDL(17)};
+        real e[3];
+        matvec3(e, R, cl);
 #pragma unroll
-            for (int i = 0; i < 9; i++) Rp[i] = s.RO[par][i];
+        for (int i = 0; i < 9; i++) s.RO[b][i] = R[i];
 #pragma unroll
-            for (int i = 0; i < 3; i++) Op[i] = s.RO[par][9 + i];
+        for (int i = 0; i < 3; i++) { s.RO[b][9 + i] = O[i]; s.CA[b][i] = O[i] + e[i]; s.CA[b][4 + i] = ax[i]; }
+    } else if (lane == 0) {            // the base body (model row 0: com; its "axis" entry is unused but kept as before)
+        const real cl[3] = {MDL(15), MDL(16), MDL(17)}, jax[3] = {MDL(12), MDL(13), MDL(14)};
+        real e[3], a0v[3];
+        matvec3(e, R0, cl);
+        matvec3(a0v, R0, jax);
 #pragma unroll
-            for (int i = 0; i < 3; i++)
+        for (int i = 0; i < 9; i++) s.RO[0][i] = R0[i];
 #pragma unroll
-                for (int j = 0; j < 3; j++) R[3 * i + j] = Rp[3 * i] * L[j] + Rp[3 * i + 1] * L[3 + j] + Rp[3 * i + 2] * L[6 + j];
-            real d[3];
-            const real jt[3] = {MDL(9), MDL(10), MDL(11)};
-            matvec3(d, Rp, jt);
-#pragma unroll
-            for (int i = 0; i < 3; i++) O[i] = Op[i] + d[i];
-#pragma unroll
-            for (int i = 0; i < 9; i++) s.RO[b][i] = R[i];
-#pragma unroll
-            for (int i = 0; i < 3; i++) s.RO[b][9 + i] = O[i];
-            if (with_vel) {
-                real wp[3], alp[3], vop[3], aop[3], ax[3], rel[3], t1[3], t2[3];
-#pragma unroll
-                for (int i = 0; i < 3; i++) { wp[i] = s.kin[par][i]; alp[i] = s.kin[par][3 + i]; vop[i] = s.kin[par][6 + i]; aop[i] = s.kin[par][9 + i]; }
-                const real jax[3] = {MDL(12), MDL(13), MDL(14)};
-                matvec3(ax, R, jax);
-#pragma unroll
-                for (int i = 0; i < 3; i++) { rel[i] = ax[i] * qd; w[i] = wp[i] + rel[i]; }
-                cross3(t1, wp, rel);
-#pragma unroll
-                for (int i = 0; i < 3; i++) al[i] = alp[i] + t1[i];
-                cross3(t1, wp, d);
-#pragma unroll
-                for (int i = 0; i < 3; i++) vo[i] = vop[i] + t1[i];
-                cross3(t2, wp, t1);           // wp x (wp x d)
-                cross3(t1, alp, d);
-#pragma unroll
-                for (int i = 0; i < 3; i++) ao[i] = aop[i] + t1[i] + t2[i];
-#pragma unroll
-                for (int i = 0; i < 3; i++) { s.kin[b][i] = w[i]; s.kin[b][3 + i] = al[i]; s.kin[b][6 + i] = vo[i]; s.kin[b][9 + i] = ao[i]; }
-            }
-        }
+        for (int i = 0; i < 3; i++) { s.RO[0][9 + i] = O0[i]; s.CA[0][i] = O0[i] + e[i]; s.CA[0][4 + i] = a0v[i]; }
     }
     WSYNC();
-    if (lane < NB) {
-        real e[3], ax[3];
-        const real cl[3] = {MDL(15), MDL(16), MDL(17)}, jax[3] = {MDL(12), MDL(13), MDL(14)};
-        matvec3(e, R, cl);
-        matvec3(ax, R, jax);
-#pragma unroll
-        for (int i = 0; i < 3; i++) { s.CA[b][i] = O[i] + e[i]; s.CA[b][4 + i] = ax[i]; }
-    }
 }
-
 #undef MDL
 
 // ---------------------------------------------------------------- per-body inertia + bias wrench, subtree sums
