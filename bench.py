@@ -133,10 +133,26 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     done_count += done.sum()
+    # for transparency: the same workload as ONE launch of all envs per step (untimed w.r.t. the contract, short)
+    single = None
+    if a.groups > 1:
+        env.close()
+        env1 = PlenVecEnvPipelined(n, groups=1, device=dev, dtype=dtype)
+        env1.reset()
+        for t in range(10):
+            env1.step_async(actions[t % ring])
+        torch.cuda.synchronize()
+        k1 = min(a.steps, 100)
+        t1 = time.perf_counter()
+        for t in range(k1):
+            env1.step_async(actions[(10 + t) % ring])
+        env1.sync(); torch.cuda.synchronize()
+        single = (time.perf_counter() - t1) / k1
+        env1.close()
     if world > 1:
-        tmax = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed, kernel_ms, single or 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(tmax[0]), float(tmax[1])
+        elapsed, kernel_ms, single = float(tmax[0]), float(tmax[1]), (float(tmax[2]) or None)
 
     if rank == 0:
         total_env_steps = world * n * a.steps
@@ -161,6 +177,7 @@ def main():
                        "sub_batches": "%d x %d envs per GPU on %d HIP streams: every env advances one control step per bench step, sub-batches are "
                                       "not synchronised with each other between steps (PlenVecEnvPipelined); --groups 1 = one launch per step" %
                                       (a.groups, n_launch, a.groups),
+                       "one_launch_per_step": None if single is None else {"ms_per_step": single * 1e3, "value": world * n / single},
                        "parallelism": "env-sharded, %d rank(s), no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "valu_issue": valu,
@@ -178,7 +195,8 @@ def main():
             except Exception as ex:     # the GPU number stands on its own
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
         print(json.dumps(out))
-    env.close()
+    if a.groups <= 1:
+        env.close()
     if world > 1:
         dist.destroy_process_group()
 
