@@ -10,6 +10,9 @@ OUT = os.path.join(CSRC, "libplenvec.so")
 DEPS = [SRC, os.path.join(CSRC, "plen_model_gen.h"), os.path.join(os.path.dirname(_HERE), "include", "plenvec.h")]
 
 
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared"]
+
+
 def hipcc_path():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
         if c and os.path.exists(c):
@@ -24,8 +27,17 @@ def build_extension(force=False, verbose=False):
     # -fno-slp-vectorize: the SLP vectoriser pairs the 3x3 kinematics products into v_pk_* ops but pays for it with more
     # v_mov shuffles than it saves (measured: -200 VALU instructions per substep, -3.6 % step time, 13 -> 5 spilled VGPRs);
     # the packed Delassus build uses explicit vector types and is unaffected.
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared", "-o", OUT, SRC]
+    cmd = [hipcc_path()] + FLAGS + ["-o", OUT, SRC]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd, cwd=CSRC)
     return OUT
+
+
+def build_variant(name, defines=()):
+    """Profiling / A-B builds (scripts/): csrc/variants/<name>.so with extra -D flags, rebuilt when the source is newer."""
+    out = os.path.join(CSRC, "variants", name + ".so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if not (os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in DEPS)):
+        subprocess.check_call([hipcc_path()] + FLAGS + list(defines) + ["-o", out, SRC], cwd=CSRC)
+    return out

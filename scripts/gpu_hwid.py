@@ -1,7 +1,9 @@
 """Profiling build (-DPGS_STAMPS -DPGS_HWID, variants/hwid.so): which (XCC, SE, CU, SIMD, slot) each block of a 4096-block launch ran on."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["PLENVEC_LIB"] = os.path.join(ROOT, "plen_ml_walk_amd", "csrc", "variants", "hwid.so")
+sys.path.insert(0, ROOT)
+from plen_ml_walk_amd.build import build_variant
+os.environ["PLENVEC_LIB"] = build_variant("hwid", ["-DPGS_STAMPS", "-DPGS_HWID"])
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from plen_ml_walk_amd.vec_env import PlenVecEnv

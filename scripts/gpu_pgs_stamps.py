@@ -3,7 +3,9 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
-os.environ.setdefault("PLENVEC_LIB", os.path.join(ROOT, "plen_ml_walk_amd", "csrc", "variants", "stamps.so"))
+sys.path.insert(0, ROOT)
+from plen_ml_walk_amd.build import build_variant
+os.environ["PLENVEC_LIB"] = build_variant("stamps", ["-DPGS_STAMPS"])
 from plen_ml_walk_amd.vec_env import PlenVecEnv
 names = ["motors(+limits)", "normals", "tors bounds", "spin rows", "roll rows", "cone pairs", "wave max"]
 for n in (64, 4096):

@@ -1,7 +1,9 @@
 """Profiling build (-DPGS_STAMPS, variants/stamps.so): distribution of wave lifetimes inside one 4096-env launch."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["PLENVEC_LIB"] = os.path.join(ROOT, "plen_ml_walk_amd", "csrc", "variants", "stamps.so")
+sys.path.insert(0, ROOT)
+from plen_ml_walk_amd.build import build_variant
+os.environ["PLENVEC_LIB"] = build_variant("stamps", ["-DPGS_STAMPS"])
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from plen_ml_walk_amd.vec_env import PlenVecEnv
