@@ -156,6 +156,29 @@ def test_gazebo_reward_head_f64():
     assert eo.max() <= 1e-5 and np.median(eo) <= 1e-11 and er.max() <= 1e-5     # obs includes the two force-threshold flags
 
 
+def test_recorded_policy_action_sequence_f64(golden_dir):
+    """The reference's own recorded policy commands (plen_bullet/trajectories/*_cmd.npy -> tests/golden/policy_cmd_sequence.npz),
+    near-saturated bang-bang actions, replayed open loop (the robot tumbles after ~30 steps).  Kernel = oracle to rounding until
+    contact events amplify the 1e-15 differences: 15 steps with rolling friction off, 4 in the reference configuration, whose
+    solver iteration is expanding; SURVEY 8c item 5."""
+    a = np.load(os.path.join(golden_dir, "policy_cmd_sequence.npz"))["actions"]        # [500, 18] float32
+    for rolling, exact_steps, loose_steps in ((0.0, 15, 22), (None, 4, 4)):
+        ov = {} if rolling is None else {"rolling_friction": rolling}
+        env = _env(1, torch.float64, cfg_overrides=ov); env.reset()
+        o = OracleEnv()
+        if rolling is not None:
+            o.set_friction(rolling=rolling)
+        o.reset()
+        errs = []
+        for t in range(loose_steps):
+            nobs, rew, done, _ = env.step(torch.tensor(a[t:t + 1]).cuda())
+            ob, r, d, _ = o.step(a[t].astype(np.float64))
+            errs.append(max(np.abs(ob - nobs[0].cpu().numpy()).max(), abs(r - float(rew[0])) / max(1.0, abs(r))))
+            assert bool(int(done[0]) & 1) == d
+        env.close()
+        assert max(errs[:exact_steps]) <= 1e-9 and max(errs) <= 1e-5, (rolling, errs)
+
+
 def test_rollout_well_conditioned_f32():
     g = torch.Generator().manual_seed(0)
     acts = ((torch.rand(10, 16, 18, generator=g) * 2 - 1) * 0.3).float()
