@@ -141,3 +141,26 @@ def test_time_limit_and_autoreset_in_rollout():
     if (flags & 1).sum() == 0:
         assert ends[0] == 499 and flags[499] == 2
     assert np.isfinite(obs).all() and np.isfinite(rew).all()
+
+
+def test_recorded_policy_action_sequence_on_the_oracle(golden_dir):
+    """The reference's recorded policy commands (trajectories/*_cmd.npy, fixture policy_cmd_sequence.npz) replayed open loop: the f64
+    and f32 builds of the oracle agree while the motion is regular and both end the episode by a fall (the sequence is a closed-loop
+    recording; open loop it cannot balance)."""
+    import os
+    a = np.load(os.path.join(golden_dir, "policy_cmd_sequence.npz"))["actions"]
+    assert a.shape == (500, 18) and a.dtype == np.float32
+    o64, o32 = OracleEnv(dtype="f64"), OracleEnv(dtype="f32")
+    o64.set_friction(rolling=0.0); o32.set_friction(rolling=0.0)
+    o64.reset(); o32.reset()
+    errs, ended = [], None
+    for t in range(60):
+        ob64, r64, d64, _ = o64.step(a[t].astype(np.float64))
+        if ended is None:
+            ob32, r32, d32, _ = o32.step(a[t].astype(np.float64))
+            errs.append(np.abs(ob64 - ob32).max())
+        if d64:
+            ended = t + 1
+            break
+    assert ended is not None and 20 <= ended <= 60
+    assert max(errs[:10]) <= 2e-4
