@@ -1639,19 +1639,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real)
 
 // ------------------------------------------------------------------------------------------------
 // Placement of envs on SIMDs.  One launch of N <= 4096 single-wave blocks is fully co-resident (16 waves per CU)
-// and the dispatcher puts blocks b, b+1024, b+2048, b+3072 on the same SIMD (measured with HW_ID, stable across
-// launches).  Waves differ in cost by 3x (airborne ... both feet planted) and the launch lasts as long as its
+// and the dispatcher puts blocks b, b+S, b+2S, b+3S on the same SIMD, S = number of SIMDs = 1024 (measured with HW_ID,
+// stable across launches).  Waves differ in cost by 3x (airborne ... both feet planted) and the launch lasts as long as its
 // slowest SIMD, so envs are dealt to blocks by descending cost estimate of their previous step in snake order:
 // every SIMD gets one env of each quartile.  Counting sort on 256 buckets, one block, LDS atomics.
 // Which block an env runs in does not change its result (tests assert bitwise equality with the identity placement).
 // ------------------------------------------------------------------------------------------------
 #define BAL_BUCKETS 256
-__global__ __launch_bounds__(1024) void plen_balance_kernel(int n, const int *aux, int *perm) {
+__global__ __launch_bounds__(1024) void plen_balance_kernel(int n, int groups, const int *aux, int *perm) {
     __shared__ int hist[BAL_BUCKETS], base[BAL_BUCKETS];
     const int t = threadIdx.x;
     if (t < BAL_BUCKETS) hist[t] = 0;
     __syncthreads();
-    const int groups = 1024;                                  // SIMDs of the chip
+    // groups = SIMDs of the device (4 x compute units: 1024 on a full MI355X)
     const int slots = (n + groups - 1) / groups;              // waves per SIMD of this launch
     for (int e = t; e < n; e += blockDim.x) {
         const int b = min(BAL_BUCKETS - 1, max(0, aux[(size_t)e * AUXN + 7]) / 448);      // 4 substeps x 50 iterations, both feet: ~110 k
@@ -1704,7 +1704,7 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 
 struct plenvec {
     PlenCfg cfg;
-    int n, device, dtype;
+    int n, device, dtype, simds;
     size_t rsz;
     void *P, *state, *reset_state, *reset_obs, *mass_scale, *mu_lat;
     int *aux, *reset_aux, *perm;
@@ -1751,7 +1751,7 @@ static int launch_env(plenvec *h, int mode, int nsub, const float *action, const
     a.dump = (real *)dump;
     a.perm = nullptr;
     if (mode == MODE_STEP && h->balance) {
-        hipLaunchKernelGGL(plen_balance_kernel, dim3(1), dim3(1024), 0, st, h->n, h->aux, h->perm);
+        hipLaunchKernelGGL(plen_balance_kernel, dim3(1), dim3(1024), 0, st, h->n, h->simds, h->aux, h->perm);
         a.perm = h->perm;
     }
     a.n = h->n; a.mode = mode; a.nsub = nsub; a.auto_reset = h->cfg.auto_reset;
@@ -1835,7 +1835,12 @@ int plenvec_create(const PlenCfg *cfg, int num_envs, int device, plenvec_t **out
     h->use_ms = h->use_mu = false; h->launches = 0; h->launches_mark = 0;
     h->fast = getenv("PLENVEC_NO_ASM") == nullptr;
     // SIMD load balancing pays once SIMDs hold more than one wave each (1024 SIMDs); PLENVEC_NO_BALANCE=1 keeps the identity placement
-    h->balance = num_envs > 1024 && getenv("PLENVEC_NO_BALANCE") == nullptr;
+    {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, device));
+        h->simds = 4 * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+    }
+    h->balance = num_envs > h->simds && getenv("PLENVEC_NO_BALANCE") == nullptr;
     int rcode = rebuild_reset_cache(h, 0);
     if (rcode != PLENVEC_OK) { plenvec_destroy(h); return rcode; }
     HIPCHK(hipStreamSynchronize(0));
