@@ -54,3 +54,12 @@ def test_merged_zero_pose_matches_raw_tree():
     for b in range(1, 19):
         link = M["moving_joints"][b - 1] + 1
         assert np.allclose(R[link], Rm[b], atol=1e-14) and np.allclose(O[link], Om[b], atol=1e-14)
+
+
+def test_sole_bbox_matches_the_reference_box_foot():
+    """SURVEY 8c weak pin (6): the reference's simplified model (plen_bullet/src/plen_new.urdf:1101,1262) replaces each foot by a
+    0.041 x 0.062867 m box; the sole polygon parsed from the STL hulls must have about that bounding box (axes aside)."""
+    for ft in M["feet"]:
+        dims = sorted(ft["sole_bbox"])
+        assert abs(dims[0] / 0.041 - 1) < 0.10 and abs(dims[1] / 0.062867 - 1) < 0.10, dims
+        assert ft["n_hull"] == 209 and ft["n_sole"] == 32          # SURVEY A2: 209 hull vertices, 32 coplanar sole vertices

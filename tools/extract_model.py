@@ -240,7 +240,7 @@ def main():
         best_area = 0.5 * abs(np.dot(q[:, 0], np.roll(q[:, 1], -1)) - np.dot(q[:, 1], np.roll(q[:, 0], -1)))
         feet.append(dict(side=side, link=k, n_hull=len(hv), n_sole=len(sole_idx),
                          sole_z_at_spawn=float(zmin + 0.158), quad_area=float(best_area),
-                         sole_polygon_area=float(ConvexHull(sole[:, :2]).volume),
+                         sole_polygon_area=float(ConvexHull(sole[:, :2]).volume), sole_bbox=(2 * hxy).tolist(),
                          points=pts_local.tolist(), margin=MARGIN, break_threshold=l["break_threshold"]))
 
     # ---- merged composite bodies (fixed joints folded) ----
