@@ -1213,11 +1213,14 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     for (it = 0; it < n_iter; it++) {
         res_i = 0;
         ISTAMP(0);
-        real resv = 0;           // per-lane |deltaVel| of the rows this lane hosted in this iteration (from the deferred deltas)
+        // Bullet's leastSquaresResidual test: does any row of this iteration move by more than sqrt(threshold)?  One compare per pass
+        // on the deferred deltas, the lane masks OR-ed on the scalar unit.
+        unsigned long long exceed = 0;
+#define OVER(x_) __ballot((float)abs_(x_) > thr_f)
         // -- non-contact rows: sorted order (motors, then limits) on odd iterations, reversed on even ones --
         if (it & 1) {
             pgs_motor_pass<FAST, false>(e, blo, bhi, dvec, Ar, lane);
-            blo -= dvec; bhi -= dvec; resv = max_(resv, abs_(dvec)); dvec = 0;
+            blo -= dvec; bhi -= dvec; exceed |= OVER(dvec); dvec = 0;
             if (lim_mask) {
                 static_for<ND>([&](auto ic) {
                     constexpr int PP = NC_ORDER[decltype(ic)::value];
@@ -1232,7 +1235,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                 });
             }
             pgs_motor_pass<FAST, true>(e, blo, bhi, dvec, Ar, lane);
-            blo -= dvec; bhi -= dvec; resv = max_(resv, abs_(dvec)); dvec = 0;
+            blo -= dvec; bhi -= dvec; exceed |= OVER(dvec); dvec = 0;
         }
         ISTAMP(1);
         if (act) {     // airborne: one branch skips every contact row
@@ -1244,7 +1247,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                 constexpr int PP = port_normal(4 * decltype(fc_)::value + decltype(kc)::value);
                 pgs_row2d<FAST, PP>(e, blo, bhi, dvec, Ar[PP], lane);
             });
-            blo -= dvec; resv = max_(resv, abs_(dvec)); dvec = 0;     // bhi of a normal row is 1e30 or 0: unchanged
+            blo -= dvec; exceed |= OVER(dvec); dvec = 0;     // bhi of a normal row is 1e30 or 0: unchanged
             ISTAMP(2);
             // -- torsional friction: spinning rows (all points), then rolling rows (all points) --
             // Bounds of a point's three torsional rows (spin lane, two roll lanes; each lane has its own
@@ -1280,7 +1283,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                     });
                 }
                 u0 += dv0; u1 += dv1; u2 += dv2; u3 += dv3;
-                resv = max_(resv, max_(max_(abs_(dv0), abs_(dv1)), max_(abs_(dv2), abs_(dv3))));
+                exceed |= OVER(max_(max_(abs_(dv0), abs_(dv1)), max_(abs_(dv2), abs_(dv3))));
             }
             ISTAMP(5);
             // -- lateral friction, cone-coupled pairs --
@@ -1295,13 +1298,14 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             }
             // Bullet's residual of a pair is |dA + dB|: after the pass every pair's deltas sit in its two lanes of dvec,
             // so one DPP add forms all the sums at once in the A lanes (instead of two VALU ops per pair)
-            resv = max_(resv, abs_(dvec + shift_down1(dvec)) * selA);
+            exceed |= OVER((dvec + shift_down1(dvec)) * selA);
             u0 += dvec; dvec = 0;
         }
         ISTAMP(6);
         ISTAMP(7);
-        // Bullet's leastSquaresResidual <= threshold: the rare scalar rows (limits) in res_i, every other row in resv
-        if ((res_i <= thr_i && __ballot((float)resv > thr_f) == 0) || it >= n_iter - 1) { it++; break; }
+        // (the rare scalar rows, joint limits, keep their max in res_i)
+        if ((res_i <= thr_i && exceed == 0) || it >= n_iter - 1) { it++; break; }
+#undef OVER
     }
     iters = it;
     // issue-slot estimate of this substep (setup + iterations x (motor pass + rows of the active contact points)), for the placement
