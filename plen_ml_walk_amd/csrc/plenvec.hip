@@ -54,7 +54,7 @@
 // device-side parameter block, converted to the kernel's real type on the host
 template <typename real>
 struct DevParams {
-    real dt, inv_dt, gz, erp, erp2, slop, res_thr, rest_thr, vmax;
+    real dt, inv_dt, gz, erp, erp2, slop, res_thr, res_thr_sqrt, rest_thr, vmax;
     real mu_lat, mu_spin, mu_roll, restitution, lin_damp, kp, kd, max_imp, spawn_z;
     real margin, brk[2];
     real pts[2][4][3];
@@ -1202,7 +1202,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     real e = -rv;                  // e = J_port * deltaV - rv
     real dvec = 0;                 // per-pass deltas of the rows hosted by this lane (deferred commit)
     unsigned res_i = 0;            // wave-uniform running max |deltaVel| of this iteration (IEEE bits, non-negative)
-    const float thr_f = (float)sqrt((double)P.res_thr);
+    const float thr_f = (float)P.res_thr_sqrt;               // Bullet compares the squared residual with the threshold
     const unsigned thr_i = __builtin_bit_cast(unsigned, thr_f);
 
     // loop-invariant parameters into registers (a reference into global memory would be re-read every iteration)
@@ -1721,7 +1721,7 @@ template <typename real>
 static void fill_params(const PlenCfg &c, DevParams<real> &p) {
     memset(&p, 0, sizeof p);
     p.dt = (real)c.dt; p.inv_dt = (real)(1.0 / c.dt); p.gz = (real)c.gravity_z; p.erp = (real)c.erp; p.erp2 = (real)c.erp2;
-    p.slop = (real)c.linear_slop; p.res_thr = (real)c.residual_threshold; p.rest_thr = (real)c.restitution_velocity_threshold;
+    p.slop = (real)c.linear_slop; p.res_thr = (real)c.residual_threshold; p.res_thr_sqrt = (real)sqrt(c.residual_threshold); p.rest_thr = (real)c.restitution_velocity_threshold;
     p.vmax = (real)c.max_coordinate_velocity; p.mu_lat = (real)c.lateral_friction; p.mu_spin = (real)c.spinning_friction;
     p.mu_roll = (real)c.rolling_friction; p.restitution = (real)c.restitution; p.lin_damp = (real)c.linear_damping;
     p.kp = (real)c.motor_kp; p.kd = (real)c.motor_kd; p.max_imp = (real)(c.motor_max_force * c.dt); p.spawn_z = (real)c.spawn_z;
