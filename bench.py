@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dr", action="store_true", help="BASELINE.json configs[4]: per-env link-mass scale U[0.8,1.2] and foot friction U[0.4,1.0], seed 1000+rank")
     ap.add_argument("--groups", type=int, default=2, help="independent sub-batches per GPU, one HIP stream each (1 = a single launch per step)")
     a = ap.parse_args()
 
@@ -104,6 +105,9 @@ def main():
     dtype = torch.float32 if a.dtype == "f32" else torch.float64
     # sub-batches on their own streams: the tail of one launch (its slowest waves) overlaps the body of the other's next step
     env = PlenVecEnvPipelined(n, groups=a.groups, device=dev, dtype=dtype)
+    if a.dr:
+        gd = torch.Generator(device=dev).manual_seed(1000 + rank)
+        env.set_params(mass_scale=0.8 + 0.4 * torch.rand(n, generator=gd, device=dev), lateral_friction=0.4 + 0.6 * torch.rand(n, generator=gd, device=dev))
     env.reset()
     g = torch.Generator(device=dev).manual_seed(rank)
     # a ring of pre-generated action batches resident in HBM (64 x 4096 x 18 f32 = 19 MB)
@@ -171,8 +175,8 @@ def main():
             "metric": "env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: %d vectorised PLEN envs per MI355X, random-action rollout, auto-reset "
-                                   "(done or 500-step limit), 4 x 240 Hz substeps per 60 Hz step" % n,
+            "config": {"workload": "BASELINE.json configs[%d]: %d vectorised PLEN envs per MI355X%s, random-action rollout, auto-reset "
+                                   "(done or 500-step limit), 4 x 240 Hz substeps per 60 Hz step" % (4 if a.dr else 1, n, ", per-env domain randomisation (mass x U[0.8,1.2], friction U[0.4,1.0])" if a.dr else ""),
                        "envs_per_gpu": n, "total_envs": world * n, "substeps": 4, "solver_iterations": 50,
                        "sub_batches": "%d x %d envs per GPU on %d HIP streams: every env advances one control step per bench step, sub-batches are "
                                       "not synchronised with each other between steps (PlenVecEnvPipelined); --groups 1 = one launch per step" %

@@ -212,6 +212,12 @@ class PlenVecEnvPipelined(object):
         """(next_obs, reward, done, info) of the last step; valid after sync()."""
         return self._next_obs, self._reward, self._done, StepInfo(self._done, self._cur_obs)
 
+    def set_params(self, mass_scale=None, lateral_friction=None):
+        """Per-env domain randomisation (BASELINE.json configs[4]); tensors of length num_envs."""
+        self.sync()
+        for e, s in zip(self.envs, self._slices):
+            e.set_params(None if mass_scale is None else mass_scale[s], None if lateral_friction is None else lateral_friction[s])
+
     def get_state(self):
         self.sync()
         return torch.cat([e.get_state() for e in self.envs], 0)
