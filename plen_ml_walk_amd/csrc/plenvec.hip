@@ -93,6 +93,11 @@ __device__ __constant__ double c_range_hi[ND] = {1.57, 1.5, 0.75, 0.3, 1.2, 0.4,
 #define NC_ORDER_LIST 6, 5, 8, 7, 4, 1, 0, 3, 2, 15, 14, 17, 16, 13, 10, 9, 12, 11
 
 // ---------------------------------------------------------------- math wrappers
+// f32: 1-ulp hardware reciprocal / reciprocal square root where a correctly rounded division is not part of the contract
+__device__ inline float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ inline double rcp_(double x) { return 1.0 / x; }
+__device__ inline float rsqrt_(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ inline double rsqrt_(double x) { return 1.0 / sqrt(x); }
 __device__ inline float sqrt_(float x) { return sqrtf(x); }
 __device__ inline double sqrt_(double x) { return sqrt(x); }
 // f32: the hardware sine/cosine (v_sin_f32 / v_cos_f32 on x / 2pi).  Arguments here are joint angles (|q| < pi) and half rotation
@@ -127,6 +132,12 @@ __device__ inline double max_(double a, double b) { return fmax(a, b); }
 __device__ inline float min_(float a, float b) { return fminf(a, b); }
 __device__ inline double min_(double a, double b) { return fmin(a, b); }
 
+// v if bit `b` of `mask` is set, else +0 (the bit sign-extended to a word mask and ANDed on: v_bfe_i32 + v_and_b32)
+__device__ __forceinline__ float keep_if(float v, unsigned mask, int b) {
+    const int m = __builtin_amdgcn_sbfe((int)mask, (unsigned)b, 1u);       // 0 or -1
+    return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & m);
+}
+__device__ __forceinline__ double keep_if(double v, unsigned mask, int b) { return ((mask >> b) & 1u) ? v : 0.0; }
 // wave-uniform broadcast of lane `l` (l must be wave-uniform)
 __device__ inline float bcast(float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); }
 __device__ inline double bcast(double x, int l) {
@@ -589,7 +600,7 @@ __device__ __forceinline__ void kinematics(Smem<real> &s, const DevParams<real> 
     real R0[9], O0[3] = {s.st[0], s.st[1], s.st[2]};
     {
         const real x = s.st[3], y = s.st[4], z = s.st[5], ww = s.st[6];
-        const real d = x * x + y * y + z * z + ww * ww, sc = (real)2 / d;
+        const real d = x * x + y * y + z * z + ww * ww, sc = (real)2 * rcp_(d);
         const real xs = x * sc, ys = y * sc, zs = z * sc;
         const real wx = ww * xs, wy = ww * ys, wz = ww * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
         R0[0] = 1 - (yy + zz); R0[1] = xy - wz; R0[2] = xz + wy;
@@ -861,15 +872,14 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         cross3(t1, &Sk[0], mc);
 #pragma unroll
         for (int i = 0; i < 3; i++) f[i] = cm * Sk[3 + i] + t1[i];
-        const unsigned anc = c_anc[k];
+        // lane k writes its whole column: M[r][k] for the supporting DoFs r <= k, zero elsewhere (so the lower triangle ends up
+        // zero: phase C factors the upper triangle in place, rows = lanes).  The keep/zero decision is a sign-extended bit of one
+        // per-lane mask ANDed onto the value: no compares, no predicated stores.
+        const unsigned keep = c_anc[k] & ((2u << k) - 1u);
 #pragma unroll
         for (int r = 0; r < NV; r++) {
-            real val = s.S[r][0] * n[0] + s.S[r][1] * n[1] + s.S[r][2] * n[2] + s.S[r][3] * f[0] + s.S[r][4] * f[1] + s.S[r][5] * f[2];
-            if (r <= k) {          // upper triangle only: phase C factors it in place, rows = lanes
-                if (!((anc >> r) & 1u)) val = 0;
-                s.M[r][k] = val;
-                if (r < k) s.M[k][r] = 0;
-            }
+            const real val = s.S[r][0] * n[0] + s.S[r][1] * n[1] + s.S[r][2] * n[2] + s.S[r][3] * f[0] + s.S[r][4] * f[1] + s.S[r][5] * f[2];
+            s.M[r][k] = keep_if(val, keep, r);
         }
         // generalized bias force (motors are constraints, so no joint torque here)
         real tau;
@@ -1123,7 +1133,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         }
     });
     const real EPS = sizeof(real) == 8 ? (real)2.220446049250313e-16 : (real)1.1920929e-07;
-    const real jdi = diag > EPS ? (real)1 / diag : (real)0;
+    const real jdi = diag > EPS ? rcp_(diag) : (real)0;
     if (dump) {
         if (lane < NPORT) {
 #pragma unroll
@@ -1352,12 +1362,13 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     // ---------------- I. integrate positions (btMultiBody::stepPositionsMultiDof) ----------------
     {
         const real w0 = s.v[0], w1 = s.v[1], w2 = s.v[2];
-        real fa = sqrt_(w0 * w0 + w1 * w1 + w2 * w2);
+        const real fa2 = w0 * w0 + w1 * w1 + w2 * w2;
+        real fa = fa2 > 0 ? fa2 * rsqrt_(fa2) : (real)0;
         const real HALF_PI = (real)1.5707963267948966;
-        if (fa * P.dt > (real)0.5 * HALF_PI) fa = (real)0.5 * HALF_PI / P.dt;
+        if (fa * P.dt > (real)0.5 * HALF_PI) fa = (real)0.5 * HALF_PI * P.inv_dt;
         real kk;
         if (fa < (real)0.001) kk = (real)0.5 * P.dt - (P.dt * P.dt * P.dt) * (real)0.020833333333 * fa * fa;
-        else kk = sin_((real)0.5 * fa * P.dt) / fa;
+        else kk = sin_((real)0.5 * fa * P.dt) * rcp_(fa);
         const real dq[4] = {w0 * kk, w1 * kk, w2 * kk, cos_(fa * P.dt * (real)0.5)};
         const real q0[4] = {s.st[3], s.st[4], s.st[5], s.st[6]};
         real rq[4];
@@ -1365,10 +1376,10 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         rq[0] = dq[3] * q0[0] + dq[0] * q0[3] + dq[1] * q0[2] - dq[2] * q0[1];
         rq[1] = dq[3] * q0[1] + dq[1] * q0[3] + dq[2] * q0[0] - dq[0] * q0[2];
         rq[2] = dq[3] * q0[2] + dq[2] * q0[3] + dq[0] * q0[1] - dq[1] * q0[0];
-        const real nrm = sqrt_(rq[0] * rq[0] + rq[1] * rq[1] + rq[2] * rq[2] + rq[3] * rq[3]);
+        const real inv_nrm = rsqrt_(rq[0] * rq[0] + rq[1] * rq[1] + rq[2] * rq[2] + rq[3] * rq[3]);
         WSYNC();
         if (lane < 3) { s.st[lane] += P.dt * s.v[3 + lane]; s.st[7 + lane] = s.v[lane]; s.st[10 + lane] = s.v[3 + lane]; }
-        if (lane < 4) s.st[3 + lane] = rq[lane] / nrm;
+        if (lane < 4) s.st[3 + lane] = rq[lane] * inv_nrm;
         if (lane >= 6 && lane < NV) { s.st[13 + lane - 6] += P.dt * s.v[lane]; s.st[31 + lane - 6] = s.v[lane]; }
     }
     WSYNC();    STAMP();
