@@ -202,8 +202,8 @@ class GraphedVecTD3Trainer(object):
         self.n = n
         torch.manual_seed(seed)
         # capturable Adam (step counters on device)
-        agent.actor_optimizer = torch.optim.Adam(agent.actor.parameters(), lr=3e-4, capturable=True)
-        agent.critic_optimizer = torch.optim.Adam(agent.critic.parameters(), lr=3e-4, capturable=True)
+        agent.actor_optimizer = torch.optim.Adam(agent.actor.parameters(), lr=3e-4, capturable=True, fused=True)
+        agent.critic_optimizer = torch.optim.Adam(agent.critic.parameters(), lr=3e-4, capturable=True, fused=True)
         self.state = env.reset().to(torch.float32).clone()
         self.total_t = torch.zeros((), dtype=torch.long, device=dev)        # transitions written so far
         self.arange_n = torch.arange(n, device=dev)
