@@ -205,6 +205,16 @@ __device__ __forceinline__ void for_foot_points(unsigned act, F &&row) {
 
 static constexpr int NC_ORDER[ND] = {NC_ORDER_LIST};
 __host__ __device__ constexpr int port_normal(int c) { return 18 + 15 * (c / 4) + 3 + 3 * (c % 4); }
+// Lanes of the ports.  Joint port d sits in lane d.  Contact point c (0..7) owns the quad of lanes 20+4c..23+4c (normal, t1, t2, unused),
+// so that its lateral pair exchanges values with DPP quad_perm and reads the normal row's limit with a quad broadcast.  The three
+// torsional ports of foot f sit in lanes 52+3f+{0,1,2}.  Lanes 18, 19, every fourth lane of a quad and 58..63 host no port.
+__host__ __device__ constexpr int lane_of_port(int p) {
+    if (p < 18) return p;
+    const int f = (p - 18) / 15, l = (p - 18) % 15;
+    if (l < 3) return 52 + 3 * f + l;
+    return 20 + 4 * (4 * f + (l - 3) / 3) + (l - 3) % 3;
+}
+#define LANE_NORMAL0 20          /* lane of the normal port of point 0; point c: + 4c */
 
 __device__ __forceinline__ unsigned absbits(float x) { return __builtin_bit_cast(unsigned, x) & 0x7fffffffu; }
 __device__ __forceinline__ unsigned absbits(double x) { return __builtin_bit_cast(unsigned, (float)x) & 0x7fffffffu; }
@@ -237,12 +247,12 @@ __device__ __forceinline__ void pgs_row2d(real &e, const real blo, const real bh
             "v_writelane_b32 %[dv], %[sd], %[pp]\n\t"
             "v_fmac_f32 %[e], %[sd], %[a]\n\t"
             : [d] "=&v"(d), [sd] "=&s"(sd), [dv] "+v"(dvec), [e] "+v"(e)
-            : [blo] "v"(blo), [bhi] "v"(bhi), [a] "v"(acol), [pp] "i"(PP));
+            : [blo] "v"(blo), [bhi] "v"(bhi), [a] "v"(acol), [pp] "i"(lane_of_port(PP)));
     } else {
 #pragma clang fp contract(off)
         const real d = min_(max_(-e, blo), bhi);
-        const real db = bcast(d, PP);
-        if (lane == PP) dvec = db;
+        const real db = bcast(d, lane_of_port(PP));
+        if (lane == lane_of_port(PP)) dvec = db;
         e = fma_(db, acol, e);
     }
 }
@@ -473,12 +483,12 @@ __device__ __forceinline__ void pgs_rowTd(real &e, const real nt1, const real t2
             "v_writelane_b32 %[dv], %[sd], %[pp]\n\t"
             "v_fmac_f32 %[e], %[sd], %[a]\n\t"
             : [d] "=&v"(d), [sd] "=&s"(sd), [dv] "+v"(dvec), [e] "+v"(e)
-            : [nt1] "v"(nt1), [t2] "v"(t2), [a] "v"(acol), [pp] "i"(PP));
+            : [nt1] "v"(nt1), [t2] "v"(t2), [a] "v"(acol), [pp] "i"(lane_of_port(PP)));
     } else {
 #pragma clang fp contract(off)
         const real d = min_(max_(-e, nt1), t2);
-        const real db = bcast(d, PP);
-        if (lane == PP) dvec = db;
+        const real db = bcast(d, lane_of_port(PP));
+        if (lane == lane_of_port(PP)) dvec = db;
         e = fma_(db, acol, e);
     }
 }
@@ -504,22 +514,34 @@ __device__ __forceinline__ void pgs_row_signed(real (&lim)[4][NV], real &e, cons
 //   u (lanes PA, PB) = lambda * diag of the two rows;  lmv (lanes PA, PB) = mu * lambda_n of their point
 // The candidate impulses are broadcast, the radial projection onto the friction circle is evaluated in
 // the two lanes themselves: new u = (u - e) * scale, scale = min(1, lm / |s|).
+// quad exchanges for the contact-point quads (normal, t1, t2, -): partner of the pair (lanes 1 <-> 2 of the quad) and lane 0 to all
+__device__ __forceinline__ float quad_swap12(float x) {
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, 0xD8 /* quad_perm:[0,2,1,3] */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double quad_swap12(double x) { const int l = threadIdx.x; const int q = l & 3; return __shfl(x, (q == 1 || q == 2) ? (l ^ 3) : l); }
+__device__ __forceinline__ float quad_bcast0(float x) {
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, 0x00 /* quad_perm:[0,0,0,0] */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double quad_bcast0(double x) { return __shfl(x, (int)threadIdx.x & ~3); }
+
 template <int PN, typename real>
 __device__ __forceinline__ void pgs_cone(real &e, const real u, real &dvec, const real lmv, const real jdi, const real aA, const real aB,
                                          const int lane) {
 #pragma clang fp contract(off)      // same roundings in every instantiation: fused ops are written out
-    constexpr int PA = PN + 1, PB = PN + 2;
+    constexpr int LA = lane_of_port(PN + 1), LB = lane_of_port(PN + 2);
     const real w = u - e;                           // candidate lambda * diag of this lane's row
     const real s = w * jdi;                         // candidate lambda
-    const real sA = bcast(s, PA), sB = bcast(s, PB);
-    const real len2 = fma_(sA, sA, sB * sB);
+    const real q = s * s;
+    const real len2 = q + quad_swap12(q);           // |s|^2 of the pair, in both of its lanes
     real scale;
     // Bullet clamps row A to |lim*sin(atan2(sA,sB))| and row B to |lim*cos(..)|: a radial projection onto the circle
     if constexpr (sizeof(real) == 4) scale = min_(1.0f, lmv * __builtin_amdgcn_rsqf(len2));   // 0*inf = NaN -> 1 (s == 0 then); 1 ulp, f32 path only
     else scale = len2 >= lmv * lmv ? (len2 > 0 ? lmv / sqrt_(len2) : (real)0) : (real)1;
     const real d = fma_(w, scale, -u);              // deltaVel of this lane's row
-    const real dA = bcast(d, PA), dB = bcast(d, PB);
-    dvec = wrlane<PA>(dvec, dA, lane); dvec = wrlane<PB>(dvec, dB, lane);     // u += dvec after the pass (no lane masks kept alive)
+    const real dA = bcast(d, LA), dB = bcast(d, LB);
+    dvec = wrlane<LA>(dvec, dA, lane); dvec = wrlane<LB>(dvec, dB, lane);     // u += dvec after the pass (no lane masks kept alive)
     e = fma_(dB, aB, fma_(dA, aA, e));
 }
 
@@ -969,24 +991,29 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     STAMP();
     FRESH_LANE();
     // ---------------- E. collision (feet vs ground) and port Jacobians ----------------
-    // port p: 0..17 joint d | 18+15f+{0,1,2} foot f torsional (n, dir1, dir2) | 18+15f+3+3k+{0,1,2} point k linear
+    // port p: 0..17 joint d | 18+15f+{0,1,2} foot f torsional (n, dir1, dir2) | 18+15f+3+3k+{0,1,2} point k linear; lanes: lane_of_port()
     // (not const: re-derived from the fresh lane id after phase F, so that none of them lives through it)
     int p, pf, pl, pk, pax;
-    bool is_joint, is_tors, is_lin;
+    bool is_joint, is_tors, is_lin, valid_port;
 #define LANE_ROLES() do { \
-        p = lane < NPORT ? lane : 0; is_joint = lane < ND; \
-        pf = (p - 18) / 15;                 /* foot (valid for p >= 18) */ \
-        pl = (p - 18) - 15 * pf;            /* 0..14 within foot */ \
-        is_tors = lane >= ND && lane < NPORT && pl < 3; \
-        is_lin = lane >= ND && lane < NPORT && pl >= 3; \
-        pk = is_lin ? (pl - 3) / 3 : 0;     /* contact point */ \
-        pax = is_lin ? (pl - 3) % 3 : pl;   /* 0 normal, 1 dir1 (0,-1,0), 2 dir2 (1,0,0) */ \
+        is_joint = lane < ND; \
+        const int ql_ = lane - LANE_NORMAL0;                        /* contact quads: lanes 20..51 */ \
+        const bool inq_ = ql_ >= 0 && ql_ < 32 && (ql_ & 3) < 3; \
+        const int tl_ = lane - 52;                                  /* torsional ports: lanes 52..57 */ \
+        is_tors = tl_ >= 0 && tl_ < 6; \
+        is_lin = inq_; \
+        pf = is_tors ? tl_ / 3 : (inq_ ? ql_ >> 4 : 0);             /* foot */ \
+        pk = inq_ ? (ql_ >> 2) & 3 : 0;                             /* contact point */ \
+        pax = inq_ ? (ql_ & 3) : (is_tors ? tl_ - 3 * pf : 0);      /* 0 normal, 1 dir1 (0,-1,0), 2 dir2 (1,0,0) */ \
+        pl = is_tors ? pax : 3 + 3 * pk + pax;                      /* 0..14 within foot */ \
+        valid_port = is_joint || is_tors || is_lin; \
+        p = is_joint ? lane : (valid_port ? 18 + 15 * pf + pl : 0); \
     } while (0)
     LANE_ROLES();
     const int fb = pf == 0 ? GEN_RFOOT_BODY : GEN_LFOOT_BODY;
     real dist = 0;
     real Pw[3] = {0, 0, 0};
-    if (lane >= ND && lane < NPORT) {
+    if (is_tors || is_lin) {
 #pragma unroll
         for (int j = 0; j < NV; j++) s.YT[j][p] = 0;
         real ax[3] = {pax == 2 ? (real)1 : (real)0, pax == 1 ? (real)-1 : (real)0, pax == 0 ? (real)1 : (real)0};
@@ -1021,7 +1048,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     // active-point mask in manifold order (right foot points 0..3, left foot 4..7)
     unsigned act = 0;
 #pragma unroll
-    for (int c = 0; c < 8; c++) act |= (unsigned)((act_ballot >> (18 + 15 * (c / 4) + 3 + 3 * (c % 4))) & 1ull) << c;
+    for (int c = 0; c < 8; c++) act |= (unsigned)((act_ballot >> (LANE_NORMAL0 + 4 * c)) & 1ull) << c;
     rc = (act & 0x0fu) != 0; lc = (act & 0xf0u) != 0;
     WSYNC();
     // own Jacobian row into registers, b = J v*, then Y = L^-T J^T by back substitution (A = J M^-1 J^T = Y^T Y)
@@ -1041,7 +1068,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         });
         Jr[I] = acc * s.col[I];
     });
-    if (lane < NPORT) {
+    if (valid_port) {
 #pragma unroll
         for (int j = 0; j < NV; j++) s.YT[j][p] = Jr[j];
     }
@@ -1049,7 +1076,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     WSYNC();
     STAMP();
     FRESH_LANE();
-    p = lane < NPORT ? lane : 0;
+    LANE_ROLES();
     // ---------------- F. port Delassus matrix, one row per lane in registers ----------------
     // A[p][q] = Y_p . Y_q.  Y inherits the tree sparsity: coordinate j of a port's column is nonzero only if
     // DoF j supports the port, so the base coordinates couple all 48 ports, a leg's coordinates only that
@@ -1135,17 +1162,17 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     const real EPS = sizeof(real) == 8 ? (real)2.220446049250313e-16 : (real)1.1920929e-07;
     const real jdi = diag > EPS ? rcp_(diag) : (real)0;
     if (dump) {
-        if (lane < NPORT) {
+        if (valid_port) {
 #pragma unroll
-            for (int q = 0; q < NPORT; q++) dump[1216 + lane * NPORT + q] = Ar2[q / 2][q % 2];
-            dump[3520 + lane] = s.park[0][lane];
-            dump[3568 + lane] = s.park[1][lane];
+            for (int q = 0; q < NPORT; q++) dump[1216 + p * NPORT + q] = Ar2[q / 2][q % 2];
+            dump[3520 + p] = s.park[0][lane];
+            dump[3568 + p] = s.park[1][lane];
         }
     }
     // The solver below works with velocity-scaled impulses u = lambda * diag (so a row's impulse
     // change IS Bullet's "deltaVel" residual) and the column-scaled matrix At[q][p] = A[q][p] / diag_p.
     WSYNC();
-    if (lane < NPORT) s.lamP[p] = jdi;
+    if (valid_port) s.lamP[p] = jdi;
     WSYNC();
     real Ar[NPORT];
 #pragma unroll
@@ -1191,7 +1218,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         if (distance > 0) vel_err -= distance * P.inv_dt; else pos_err = -distance * P.erp2 * P.inv_dt;
         rv = (pos_err + vel_err) * dis;
         bhi = cp_active_g ? (real)1e30 : (real)0;    // lambda_n in [0, 1e10] (never reached); a point out of range gets (0, 0): its row is a no-op
-    } else if (lane < NPORT) {
+    } else if (valid_port) {
         rv = (0 - bvel_g) * dis;
     }
     if (lane < NV) { s.lim[0][lane] = rv; s.lim[1][lane] = rv_lim; s.lim[2][lane] = sgn_lim; s.lim[3][lane] = 0; }
@@ -1206,7 +1233,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         fc0 = mu * s.lamP[pn0]; fc1 = mu * s.lamP[pn0 + 3]; fc2 = mu * s.lamP[pn0 + 6]; fc3 = mu * s.lamP[pn0 + 9];
     }
     const real selA = (is_lin && pax == 1) ? (real)1 : (real)0;     // 1 in the first lane of every lateral-friction pair
-    const int tors_src = 18 + 15 * pf + 3;                    // lane of the first normal port of this lane's foot
+    const int tors_src = LANE_NORMAL0 + 16 * pf;              // lane of the first normal port of this lane's foot (the next ones: + 4 each)
     const real nfcn = (is_lin && pax == 0) ? -mu_lat * jdi : (real)0;   // lane PN: mu_lat * lambda_n = nfcn * blo
 
     real e = -rv;                  // e = J_port * deltaV - rv
@@ -1266,8 +1293,8 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             // because u_n only changes in the normal pass and uk only at its own row.  Bullet skips the row
             // while the normal impulse is not positive: bounds (0, 0) leave e and uk untouched.
             if (has_spin || has_roll) {
-                const real nbv0 = gather_lane(blo, tors_src), nbv1 = gather_lane(blo, tors_src + 3);
-                const real nbv2 = gather_lane(blo, tors_src + 6), nbv3 = gather_lane(blo, tors_src + 9);     // -u_n of point k of this lane's foot
+                const real nbv0 = gather_lane(blo, tors_src), nbv1 = gather_lane(blo, tors_src + 4);
+                const real nbv2 = gather_lane(blo, tors_src + 8), nbv3 = gather_lane(blo, tors_src + 12);     // -u_n of point k of this lane's foot
                 const real lim0 = mul_rn_(fc0, nbv0), lim1 = mul_rn_(fc1, nbv1), lim2 = mul_rn_(fc2, nbv2), lim3 = mul_rn_(fc3, nbv3);
                 const real nt10 = nbv0 < 0 ? -(lim0 + u0) : (real)0, nt11 = nbv1 < 0 ? -(lim1 + u1) : (real)0;
                 const real nt12 = nbv2 < 0 ? -(lim2 + u2) : (real)0, nt13 = nbv3 < 0 ? -(lim3 + u3) : (real)0;
@@ -1298,9 +1325,8 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             ISTAMP(5);
             // -- lateral friction, cone-coupled pairs --
             {
-                // mu * lambda_n of each point, moved from its normal lane PN into the pair's lanes PN+1, PN+2
-                const real l1 = shift_up1(mul_rn_(nfcn, blo)), l2 = shift_up1(l1);
-                const real lmv = pax == 1 ? l1 : l2;
+                // mu * lambda_n of each point: from its normal lane (lane 0 of the point's quad) to the whole quad
+                const real lmv = quad_bcast0(mul_rn_(nfcn, blo));
                 for_foot_points(act, [&](auto fc_, auto kc) {
                     constexpr int PN = port_normal(4 * decltype(fc_)::value + decltype(kc)::value);
                     pgs_cone<PN>(e, u0, dvec, lmv, jdi, Ar[PN + 1], Ar[PN + 2], lane);
@@ -1334,7 +1360,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         const real inv_diag_r = lane < NV ? s.col[k] : (real)0;    // 1/L[k][k], parked in LDS since phase E
         const real vstar_r = lane < NV ? s.v[k] : (real)0;         // v* parked in LDS since phase D
         const real lamP = lam_sum;
-        if (lane < NPORT) s.lamP[p] = lamP;
+        if (valid_port) s.lamP[p] = lamP;
         WSYNC();
         real z = 0;
         if (lane < NV) {
@@ -1353,7 +1379,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         vn = min_(max_(vn, -P.vmax), P.vmax);
         WSYNC();
         if (lane < NV) s.v[k] = vn;
-        if (dump && lane < NPORT) dump[3616 + lane] = lamP;
+        if (dump && valid_port) dump[3616 + p] = lamP;
         if (dump && lane == 0) dump[3700] = (real)it;
     }
     WSYNC();
