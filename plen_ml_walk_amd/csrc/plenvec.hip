@@ -7,9 +7,10 @@
 //   * ONE WAVEFRONT (64 lanes) PER ENVIRONMENT, one launch per vector step, state resident in
 //     LDS/VGPRs across the 4 substeps.  At BASELINE.json's 4096 envs/GPU this gives 4096 waves =
 //     4 per SIMD on 256 CUs; "one env per lane" would give 64 waves = 6% of the chip.
-//   * lanes play three roles: body b (19 composite bodies), generalized DoF k (24), solver port p (48);
-//   * dynamics: world-axes composite-rigid-body mass matrix M (24x24) + classical recursive
-//     Newton-Euler bias, Cholesky M = L L^T held one row per lane;
+//   * lanes play three roles: body b (19 composite bodies), generalized DoF k (24), solver port p (48; lane_of_port());
+//   * dynamics: kinematics as DPP prefix scans along the four chains, world-axes composite-rigid-body mass
+//     matrix M (24x24) + classical recursive Newton-Euler bias, sparse factorization M = L^T L (no fill-in)
+//     held one column per lane;
 //   * constraints: Bullet's multibody PGS rows (18 position motors, joint limits, per contact point
 //     normal + spinning + 2 rolling + 2 cone-coupled lateral friction rows), solved in "port space":
 //     rows that share a Jacobian share a port, A = J M^-1 J^T (48x48) is held one row per lane in
@@ -17,7 +18,9 @@
 //     alternating sweep direction, limits, residual early-out follow btMultiBodyConstraintSolver.
 //   * integration: btMultiBody::stepPositionsMultiDof (exponential-map quaternion).
 //
-// No MFMA: there is no dense contraction worth a matrix core here (24..48-wide, latency bound).
+//   * plen_balance_kernel places envs on SIMDs by cost before every launch (placement never changes results).
+//
+// No MFMA: there is no dense contraction worth a matrix core here (24..48-wide); the kernel is VALU-issue bound.
 // The library never falls back to the CPU; the oracle under oracle/ is never linked or called.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -48,7 +51,7 @@
 //                           49-54 previous gait joint angles (joints 2,8,3,9,4,10; plen_env.py:825-849) |
 //                           55-63 running sums per L/R pair: dot, |L|^2, |R|^2 (plen_env.py:929-945)
 // aux record (int32[8]):    gait counter | double-support counter | episode step | history length |
-//                           right contact | left contact | solver iterations | reserved
+//                           right contact | left contact | solver iterations | cost estimate of the last step (placement)
 // ------------------------------------------------------------------------------------------------
 
 // device-side parameter block, converted to the kernel's real type on the host
