@@ -1,6 +1,6 @@
 """End-to-end demonstration: TD3 from scratch on 4096 vectorised envs (hipGraph-captured loop) for a fixed wall-clock budget,
 evaluating the deterministic actor every few thousand iterations.  Writes gpurun_out/train_curve.json.
-usage: python scripts/gpu_train_demo.py [seconds] [updates_per_step]"""
+usage: python scripts/gpu_train_demo.py [seconds] [updates_per_step] [init.npz]   (init.npz: actor./critic. arrays, e.g. tests/golden/policy_3229999.npz)"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,11 +12,15 @@ from plen_ml_walk_amd.walk_eval import evaluate
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 ups = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+init = sys.argv[3] if len(sys.argv) > 3 else None
 torch.manual_seed(0)
 env = PlenVecEnv(4096)
 agent = TD3Agent(26, 18, 1.0)
 replay = ReplayBuffer(1000000)
-tr = GraphedVecTD3Trainer(env, agent, replay, start_timesteps=100000, expl_noise=0.1, batch_size=4096, updates_per_step=ups, seed=0)
+if init:
+    agent.load_arrays(np.load(os.path.join(ROOT, init)))
+    agent.actor_target.load_state_dict(agent.actor.state_dict()); agent.critic_target.load_state_dict(agent.critic.state_dict())
+tr = GraphedVecTD3Trainer(env, agent, replay, start_timesteps=(4096 if init else 100000), expl_noise=0.1, batch_size=4096, updates_per_step=ups, seed=0)
 curve = []
 def ev(tag):
     torch.cuda.synchronize()
@@ -34,5 +38,5 @@ while time.time() - t0 < budget:
     it += 2000
     ev("it%d" % it)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(dict(envs=4096, batch=4096, updates_per_step=ups, start_timesteps=100000, budget_s=budget, curve=curve), open(os.path.join(ROOT, "gpurun_out", "train_curve.json"), "w"), indent=1)
+json.dump(dict(envs=4096, batch=4096, updates_per_step=ups, start_timesteps=(4096 if init else 100000), budget_s=budget, curve=curve), open(os.path.join(ROOT, "gpurun_out", ("train_curve_finetune.json" if init else "train_curve.json")), "w"), indent=1)
 env.close()
