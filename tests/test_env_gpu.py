@@ -269,6 +269,18 @@ def test_joint_act_generated_gait_f64():
     assert eo.max() <= 1e-7 and er.max() <= 1e-6
 
 
+def test_reference_walking_trajectory_joint_act_f64():
+    """The reference's own open-loop walking trajectory (trajectory_eval.py: 20 bend steps, then the assembled 18-joint gait, whose
+    arrays are pinned to the reference's committed trajectories/*.npy by the CPU suite) through joint_act=True: kernel = oracle."""
+    from plen_ml_walk_amd.trajectory_eval import assemble_joint_trajectories
+    walk, bend = assemble_joint_trajectories()
+    a = np.concatenate([np.tile(bend, (20, 1)), walk[:50]], 0)
+    acts = torch.tensor(np.repeat(a[:, None, :], 2, axis=1), dtype=torch.float32)
+    eo, er, mism, cmpd = _rollout_vs_oracle(torch.float64, 2, acts.shape[0], acts, joint_act=True)
+    assert cmpd >= 40 and mism == 0
+    assert np.median(eo) <= 1e-9 and eo.max() <= 1e-5 and er.max() <= 1e-5
+
+
 def test_asm_path_bitwise_equals_compiler_path(tmp_path):
     """The hand-scheduled f32 row update vs the compiler-generated one: same operations in the same
     order, so 20 steps x 256 envs must agree bit for bit (any pipeline hazard would show)."""

@@ -27,3 +27,14 @@ def test_ik_known_answers(golden_dir):
     assert np.abs(gen.IK(g["ik_points"], False) - g["ik_left"]).max() <= 1e-12
     acts = gen.walk_cycle_actions(cycles=2)
     assert acts.shape[1] == 18 and np.all(acts[:, 12:] == 0) and np.isfinite(acts).all()
+
+
+def test_trajectory_eval_assembly_matches_the_committed_trajectories(golden_dir):
+    """The reference commits what its trajectory_eval.py:180-271 assembles and saves (trajectories/<joint>_traj.npy, bend_traj.npy ->
+    tests/golden/traj_eval.npz): generator + assembly here reproduce those 18 x 800 joint targets and the bend pose."""
+    from plen_ml_walk_amd.trajectory_eval import assemble_joint_trajectories
+    g = np.load(os.path.join(golden_dir, "traj_eval.npz"))
+    walk, bend = assemble_joint_trajectories()
+    assert walk.shape == g["walk"].shape == (800, 18)
+    assert np.abs(walk - g["walk"]).max() <= 1e-12
+    assert np.abs(bend - g["bend"]).max() <= 1e-12
