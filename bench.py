@@ -180,7 +180,7 @@ def main():
             valu = {"insts_per_env_step": pmc["valu_insts_per_env_step"], "achieved": ginst, "peak": VALU_PEAK_GINST_S, "unit": "G wave-inst/s",
                     "frac": ginst / VALU_PEAK_GINST_S, "source": pmc_file}
         out = {
-            "metric": "env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "metric": "env-steps/sec @4096 envs", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[%d]: %d vectorised PLEN envs per MI355X%s, random-action rollout, auto-reset "
