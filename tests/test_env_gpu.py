@@ -13,6 +13,7 @@ Tolerances (written here, explained in DESIGN.md "Parity and conditioning"):
     median, on the fraction within north_star's 1e-4, and (f32) against the oracle's own sensitivity;
   * with rolling friction off the iteration is contractive and multi-step rollouts are asserted tightly.
 """
+import json
 import os
 import subprocess
 import sys
@@ -387,6 +388,33 @@ def test_facade_and_reference_shaped_driver(tmp_path):
     ev = plen_td3.main(max_timesteps=60, start_timesteps=30, eval_freq=50, out_dir=str(tmp_path / "run"), quiet=True)
     assert os.path.exists(str(tmp_path / "results" / "plen_walk_gazebo_.npy"))
     assert os.path.exists(str(tmp_path / "models" / "plen_walk_gazebo_49_actor"))
+
+
+def test_v0_facade_and_train_cli_resume(tmp_path):
+    """PlenWalkEnv-v0 (the Gazebo environment's contract on this simulator) through the gym-style facade, and the train_vec command line
+    stopping and continuing a run (checkpoint + counters + replay)."""
+    from plen_ml_walk_amd import plen_env as pe   # noqa: F401  (registers both ids)
+    from plen_ml_walk_amd import gym_compat as gym
+    from plen_ml_walk_amd import train_vec
+    env = gym.make("PlenWalkEnv-v0")
+    o = OracleEnv(reward_head=1)
+    assert np.abs(env.reset() - o.reset()).max() <= 1e-12
+    rng = np.random.default_rng(0)
+    a = (0.3 * rng.uniform(-1, 1, 18)).astype(np.float32)          # one step: in the reference configuration the solver amplifies the
+    ob, r, d, _ = env.step(a)                                      # 1e-15 differences ~100x per step (DESIGN.md section 5)
+    ob2, r2, d2, _ = o.step(a.astype(np.float64))
+    assert np.abs(ob - ob2).max() <= 1e-8 and abs(r - r2) <= 1e-8 and d == d2
+    assert isinstance(r, np.float64) and ob.shape == (26,) and abs(r - 0.2) < 5.0       # alive bonus 100/500 plus small shaping terms
+    env.close()
+    prefix, bp = str(tmp_path / "ck"), str(tmp_path / "replay")
+    train_vec.main(["--envs", "64", "--steps", "6", "--warmup", "2", "--batch", "64", "--start-timesteps", "128", "--replay", "4096", "--graphs", "1",
+                    "--save", prefix, "--save-replay", "1", "--buffer-path", bp])
+    assert all(os.path.exists(prefix + sfx) for sfx in ("_actor", "_critic", "_actor_optimizer", "_critic_optimizer", "_actor_target", "_critic_target", "_trainer.json"))
+    c1 = json.load(open(prefix + "_trainer.json"))
+    train_vec.main(["--envs", "64", "--steps", "4", "--warmup", "0", "--batch", "64", "--start-timesteps", "128", "--replay", "4096", "--graphs", "1",
+                    "--resume", prefix, "--load-replay", "1", "--buffer-path", bp, "--save", prefix + "2"])
+    c2 = json.load(open(prefix + "2_trainer.json"))
+    assert c2["env_steps"] > c1["env_steps"] and c2["grad_steps"] > c1["grad_steps"]
 
 
 def test_vector_td3_training_step(golden_dir):
