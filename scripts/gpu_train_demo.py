@@ -22,6 +22,7 @@ if init:
     agent.actor_target.load_state_dict(agent.actor.state_dict()); agent.critic_target.load_state_dict(agent.critic.state_dict())
 tr = GraphedVecTD3Trainer(env, agent, replay, start_timesteps=(4096 if init else 100000), expl_noise=0.1, batch_size=4096, updates_per_step=ups, seed=0)
 curve = []
+best = dict(mean=-1e9)
 def ev(tag):
     torch.cuda.synchronize()
     r = evaluate(agent, num_envs=128, episodes_per_env=1, action_noise=0.01, seed=1)
@@ -29,6 +30,9 @@ def ev(tag):
     row = dict(wall_s=round(time.time() - t0, 1), env_steps=int(tr.env_steps), grad_steps=int(tr.grad_steps), mean_return=float(ret.mean()),
                median_return=float(np.median(ret)), mean_length=float(ln.mean()), full_length_fraction=float((ln >= 500).mean()))
     curve.append(row); print(tag, json.dumps(row), flush=True)
+    if row["mean_return"] > best["mean"]:          # keep the best actor seen (TD3 with this schedule does not stay at its peak)
+        best.update(mean=row["mean_return"], row=row, actor={"actor." + k: v.detach().cpu().numpy().copy() for k, v in agent.actor.state_dict().items()},
+                    critic={"critic." + k: v.detach().cpu().numpy().copy() for k, v in agent.critic.state_dict().items()})
 t0 = time.time()
 ev("init")
 it = 0
@@ -39,4 +43,7 @@ while time.time() - t0 < budget:
     ev("it%d" % it)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(dict(envs=4096, batch=4096, updates_per_step=ups, start_timesteps=(4096 if init else 100000), budget_s=budget, curve=curve), open(os.path.join(ROOT, "gpurun_out", ("train_curve_finetune.json" if init else "train_curve.json")), "w"), indent=1)
+if best.get("actor"):
+    np.savez_compressed(os.path.join(ROOT, "gpurun_out", "best_policy.npz"), **best["actor"], **best["critic"])
+    print("best", json.dumps(best["row"]))
 env.close()
