@@ -1,78 +1,97 @@
 #!/usr/bin/env python
-"""Single-environment TD3 driver with the reference's control flow (plen_bullet/src/plen_td3.py:16-158):
-same hyper-parameters, warm-up, exploration noise, done_bool masking of the time limit, checkpoint
-cadence and file names.  It exists to show the surfaces are drop-in; train_vec.py is the fast path."""
+"""Single-environment TD3 training, drop-in for the reference's plen_bullet/src/plen_td3.py.
+
+Behaviour kept (reference line numbers): hyper-parameters and seeds (:19-48), optional pick-up of an existing policy / replay
+buffer (:57-69), uniform random actions during the first `start_timesteps` steps, then actor + N(0, 0.1) noise clipped to the
+action range (:96-104), the replay `done` flag masking the 500-step time limit (:109-110), one TD3 update per environment step
+once warmed up (:118-119), episode bookkeeping and reset (:122-133), `results/plen_walk_gazebo_.npy` and the four-file
+checkpoint `models/plen_walk_gazebo_<t>_*` every `eval_freq` steps (:136-155).  It exists to show that the surfaces are drop-in;
+`train_vec.py` is the fast path (thousands of environments per GPU)."""
 import os
 
 import numpy as np
 import torch
 
-from .td3 import ReplayBuffer, TD3Agent
-from . import plen_env  # noqa: F401  (registers PlenWalkEnv-v1)
 from . import gym_compat as gym
+from . import plen_env  # noqa: F401  (registers PlenWalkEnv-v1)
+from .td3 import ReplayBuffer, TD3Agent
+
+ENV_ID = "PlenWalkEnv-v1"
+RUN_NAME = "plen_walk_gazebo_"
+
+
+class _Run(object):
+    """Directories, environment, agent and buffer of one training run."""
+
+    def __init__(self, out_dir, seed, policy_num, buffer_number, quiet):
+        root = out_dir or os.path.abspath(os.path.dirname(__file__))
+        self.results_dir = os.path.join(root, "../results")
+        self.models_dir = os.path.join(root, "../models")
+        for d in (self.results_dir, self.models_dir):
+            os.makedirs(d, exist_ok=True)
+        self.quiet = quiet
+        self.env = gym.make(ENV_ID, render=False)
+        self.env.seed(seed)
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        self.n_obs = self.env.observation_space.shape[0]
+        self.n_act = self.env.action_space.shape[0]
+        self.act_limit = float(self.env.action_space.high[0])
+        self.agent = TD3Agent(self.n_obs, self.n_act, self.act_limit)
+        self.buffer = ReplayBuffer()
+        self._pick_up(policy_num, buffer_number)
+
+    def checkpoint_prefix(self, tag):
+        return self.models_dir + "/" + RUN_NAME + str(tag)
+
+    def _pick_up(self, policy_num, buffer_number):
+        if os.path.exists(self.checkpoint_prefix(policy_num) + "_critic"):
+            self.say("Loading Existing Policy")
+            self.agent.load(self.checkpoint_prefix(policy_num))
+        if os.path.exists(self.buffer.buffer_path + "/replay_buffer_" + str(buffer_number) + ".data"):
+            self.say("Loading Replay Buffer " + str(buffer_number))
+            self.buffer.load(buffer_number)
+
+    def say(self, msg):
+        if not self.quiet:
+            print(msg)
+
+    def behaviour_action(self, obs, exploring, noise_scale):
+        if exploring:
+            return self.env.action_space.sample()
+        greedy = self.agent.select_action(np.array(obs))
+        noisy = greedy + np.random.normal(0, self.act_limit * noise_scale, size=self.n_act)
+        return np.clip(noisy, -self.act_limit, self.act_limit)
 
 
 def main(max_timesteps=4e6, start_timesteps=1e4, eval_freq=1e4, out_dir=None, seed=0, expl_noise=0.1, batch_size=100,
          save_model=True, quiet=False, policy_num=0, buffer_number=0):
-    env_name = "PlenWalkEnv-v1"
-    file_name = "plen_walk_gazebo_"
-    my_path = out_dir or os.path.abspath(os.path.dirname(__file__))
-    results_path = os.path.join(my_path, "../results")
-    models_path = os.path.join(my_path, "../models")
-    for p in (results_path, models_path):
-        if not os.path.exists(p):
-            os.makedirs(p)
-    env = gym.make(env_name, render=False)
-    env.seed(seed)
-    torch.manual_seed(seed)
-    np.random.seed(seed)
-    state_dim = env.observation_space.shape[0]
-    action_dim = env.action_space.shape[0]
-    max_action = float(env.action_space.high[0])
-    policy = TD3Agent(state_dim, action_dim, max_action)
-    if os.path.exists(models_path + "/" + "plen_walk_gazebo_" + str(policy_num) + "_critic"):     # plen_td3.py:57-62
-        if not quiet:
-            print("Loading Existing Policy")
-        policy.load(models_path + "/" + "plen_walk_gazebo_" + str(policy_num))
-    replay_buffer = ReplayBuffer()
-    if os.path.exists(replay_buffer.buffer_path + "/" + "replay_buffer_" + str(buffer_number) + '.data'):   # plen_td3.py:64-69
-        if not quiet:
-            print("Loading Replay Buffer " + str(buffer_number))
-        replay_buffer.load(buffer_number)
-    evaluations = []
-    state = env.reset()
-    done = False
-    episode_reward = 0
-    episode_timesteps = 0
-    episode_num = 0
+    run = _Run(out_dir, seed, policy_num, buffer_number, quiet)
+    env, horizon = run.env, run.env._max_episode_steps
+    returns = []                       # one entry per finished episode: what the reference stores as "evaluations"
+    obs = env.reset()
+    ep_return, ep_len, ep_index = 0, 0, 0
     for t in range(int(max_timesteps)):
-        episode_timesteps += 1
-        if t < start_timesteps:
-            action = env.action_space.sample()
-        else:
-            action = np.clip((policy.select_action(np.array(state)) + np.random.normal(0, max_action * expl_noise, size=action_dim)),
-                             -max_action, max_action)
-        next_state, reward, done, _ = env.step(action)
-        done_bool = float(done) if episode_timesteps < env._max_episode_steps else 0
-        replay_buffer.add((state, action, next_state, reward, done_bool))
-        state = next_state
-        episode_reward += reward
+        ep_len += 1
+        action = run.behaviour_action(obs, exploring=t < start_timesteps, noise_scale=expl_noise)
+        obs_next, reward, done, _ = env.step(action)
+        terminal_for_replay = float(done) if ep_len < horizon else 0      # a time-limit ending is not a terminal state
+        run.buffer.add((obs, action, obs_next, reward, terminal_for_replay))
+        obs = obs_next
+        ep_return += reward
         if t >= start_timesteps:
-            policy.train(replay_buffer, batch_size)
+            run.agent.train(run.buffer, batch_size)
         if done:
-            state, done = env.reset(), False
-            evaluations.append(episode_reward)
-            if not quiet:
-                print("Total T: {} Episode Num: {} Episode T: {} Reward: {}".format(t + 1, episode_num, episode_timesteps, episode_reward))
-            episode_reward = 0
-            episode_timesteps = 0
-            episode_num += 1
+            returns.append(ep_return)
+            run.say("Total T: {} Episode Num: {} Episode T: {} Reward: {}".format(t + 1, ep_index, ep_len, ep_return))
+            obs = env.reset()
+            ep_return, ep_len, ep_index = 0, 0, ep_index + 1
         if (t + 1) % eval_freq == 0:
-            np.save(results_path + "/" + str(file_name), evaluations)
+            np.save(run.results_dir + "/" + RUN_NAME, returns)
             if save_model:
-                policy.save(models_path + "/" + str(file_name) + str(t))
+                run.agent.save(run.checkpoint_prefix(t))
     env.close()
-    return evaluations
+    return returns
 
 
 if __name__ == '__main__':
