@@ -5,8 +5,6 @@ The reference builds a whole PlenWalkEnv(joint_act=True) only to read `real_rang
 (trajectory_generator.py:52, :203-222); here the ranges come from plen_env.REAL_RANGES, so the generator
 needs no GPU and no physics.  Feed `foot_walk_rfwd` / `foot_walk_lfwd` / `bend` to a joint_act
 environment (PlenVecEnv(joint_act=True)) the way trajectory_eval.py:180-271 does."""
-import math
-
 import numpy as np
 
 from .plen_env import REAL_RANGES
@@ -31,70 +29,61 @@ class TrajectoryGenerator():
         self.env = _Ranges()
 
     def foot_path(self):
-        """Cartesian foot trajectories relative to the hips (trajectory_generator.py:54-152)."""
+        """Cartesian foot trajectories relative to the hips, as 3 x n arrays (x forward, y sideways, z up from the bent stance);
+        phases as in trajectory_generator.py:54-152: the stepping ("dominant") foot lifts and strides during single support and slides
+        back during double support, the support foot mirrors it with half the stride."""
         nD, nS = self.num_DoubleSupport, self.num_SingleSupport
-        DS_support_foot = np.zeros((3, 2 * nD)); SS_support_foot = np.zeros((3, nS))
-        DS_dominant_foot = np.zeros((3, 2 * nD)); SS_dominant_foot = np.zeros((3, nS))
-        for i in range(nS):                                   # dominant foot, single support: lift + stride
-            t = i / (nS - 1.0)
-            SS_dominant_foot[0][i] = t * self.stride_length
-            SS_dominant_foot[1][i] = np.sin(-np.pi * ((1 / 3.0) * (1 + t))) * self._body_sway
-            SS_dominant_foot[2][i] = np.sin(t * np.pi) * self.foot_lift_height + self._bend_distance
-        for i in range(2 * nD):                               # dominant foot, double support
-            t = i / (2 * nD - 1.0)
-            DS_dominant_foot[0][i] = -self.stride_length * (t / 2.0)
-            DS_dominant_foot[1][i] = np.sin(-np.pi * ((-1.0 / 3.0) + (2 / 3.0) * t)) * self._body_sway
-            DS_dominant_foot[2][i] = self._bend_distance
-        for i in range(nS):                                   # support foot, single support
-            t = i / (nS - 1.0)
-            SS_support_foot[0][i] = self.stride_length * ((1.0 / 2.0) - t) / 2.0
-            SS_support_foot[1][i] = np.sin(np.pi * ((1 / 3.0) * (1 + t))) * self._body_sway
-            SS_support_foot[2][i] = self._bend_distance
-        for i in range(2 * nD):                               # support foot, double support
-            t = i / (2.0 * nD - 1.0)
-            DS_support_foot[0][i] = self.stride_length * (1.0 - t) / 2.0
-            DS_support_foot[1][i] = np.sin(-np.pi * ((2.0 / 3.0) + (2 / 3.0) * t)) * self._body_sway
-            DS_support_foot[2][i] = self._bend_distance
+        ts = np.arange(nS) / (nS - 1.0)                  # phase in [0, 1] over single support
+        td = np.arange(2 * nD) / (2 * nD - 1.0)          # ... over double support
+        L, sway, bend = self.stride_length, self._body_sway, self._bend_distance
+        third = 1 / 3.0
+        ss_dom = np.stack([ts * L,
+                           np.sin(-np.pi * (third * (1 + ts))) * sway,
+                           np.sin(ts * np.pi) * self.foot_lift_height + bend])
+        ds_dom = np.stack([-L * (td / 2.0),
+                           np.sin(-np.pi * ((-1.0 / 3.0) + (2 / 3.0) * td)) * sway,
+                           np.full(2 * nD, bend)])
+        ss_sup = np.stack([L * ((1.0 / 2.0) - ts) / 2.0,
+                           np.sin(np.pi * (third * (1 + ts))) * sway,
+                           np.full(nS, bend)])
+        ds_sup = np.stack([L * (1.0 - td) / 2.0,
+                           np.sin(-np.pi * ((2.0 / 3.0) + (2 / 3.0) * td)) * sway,
+                           np.full(2 * nD, bend)])
         if self.fwd_bias != 0:
-            DS_support_foot[0] = DS_support_foot[0] - self.fwd_bias
-            SS_support_foot[0] = SS_support_foot[0] - self.fwd_bias
-            DS_dominant_foot[0] = DS_dominant_foot[0] - self.fwd_bias
-            SS_dominant_foot[0] = SS_dominant_foot[0] - self.fwd_bias
-        self.foot_walk_rfwd_r = np.column_stack([DS_dominant_foot[:, nD:], SS_dominant_foot, DS_support_foot[:, :nD]])
-        self.foot_walk_lfwd_r = np.column_stack([DS_support_foot[:, nD:], SS_support_foot, DS_dominant_foot[:, :nD]])
-        self.SS_dominant_foot, self.DS_dominant_foot = SS_dominant_foot, DS_dominant_foot
-        self.SS_support_foot, self.DS_support_foot = SS_support_foot, DS_support_foot
+            for path in (ds_sup, ss_sup, ds_dom, ss_dom):
+                path[0] -= self.fwd_bias
+        # one step = second half of double support, single support, first half of the next double support
+        self.foot_walk_rfwd_r = np.column_stack([ds_dom[:, nD:], ss_dom, ds_sup[:, :nD]])
+        self.foot_walk_lfwd_r = np.column_stack([ds_sup[:, nD:], ss_sup, ds_dom[:, :nD]])
+        self.SS_dominant_foot, self.DS_dominant_foot = ss_dom, ds_dom
+        self.SS_support_foot, self.DS_support_foot = ss_sup, ds_sup
 
     def assemble_trajectories(self):
         """The other foot does the mirrored (y negated) trajectory (trajectory_generator.py:154-167)."""
-        flip = np.array([[1], [-1], [1]])
-        self.foot_walk_lfwd_l = self.foot_walk_rfwd_r * flip
-        self.foot_walk_rfwd_l = self.foot_walk_lfwd_r * flip
+        mirror_y = np.array([[1], [-1], [1]])
+        self.foot_walk_lfwd_l = self.foot_walk_rfwd_r * mirror_y
+        self.foot_walk_rfwd_l = self.foot_walk_lfwd_r * mirror_y
 
     def IK(self, point, RightLeg):
-        """5-DoF leg inverse kinematics relative to the hip (trajectory_generator.py:169-233).
-        point: (3, n) array of foot positions; returns (n, 6) joint angles [0, th1..th5]."""
-        point = np.asarray(point, dtype=np.float64)
-        n = point[0].size
-        joint_angles = np.zeros((n, 6))
-        rr = self.env.real_ranges
-        for i in range(n):
-            lhip_knee, lknee_foot = self.l_hip_knee, self.l_knee_foot
-            Zx = point[0][i]; Zy = point[1][i]
-            Zz = self.l_hip_knee + self.l_knee_foot - point[2][i]
-            th1 = math.atan2(-Zy, Zz) if RightLeg else math.atan2(Zy, Zz)
-            th3 = math.acos((Zx ** 2 + Zy ** 2 + Zz ** 2 - lhip_knee ** 2 - lknee_foot ** 2) / (2.0 * lhip_knee * lknee_foot))
-            sqrtyz = np.sqrt(Zy ** 2 + Zz ** 2)
-            hok = lhip_knee / lknee_foot
-            th2 = -math.atan2((sqrtyz * np.sin(th3) + Zx * np.cos(th3) + Zx * hok),
-                              (sqrtyz * np.cos(th3) + sqrtyz * hok - Zx * np.sin(th3)))
-            knee, thigh = (3, 2) if RightLeg else (9, 8)      # caps from the real joint ranges
-            th3 = min(max(th3, rr[knee][0]), rr[knee][1])
-            th2 = min(max(th2, rr[thigh][0]), rr[thigh][1])
-            th4 = -(th2 + th3)
-            th5 = -th1 if RightLeg else th1
-            joint_angles[i] = np.array([0, th1, th2, th3, th4, th5])
-        return joint_angles
+        """Closed-form inverse kinematics of one leg relative to its hip (trajectory_generator.py:169-233), vectorised over the
+        n foot positions in `point` (3 x n, mm).  Returns (n, 6): [0, hip roll, thigh pitch, knee, ankle pitch, ankle roll]."""
+        pt = np.asarray(point, dtype=np.float64)
+        a, b = self.l_hip_knee, self.l_knee_foot
+        x, y = pt[0], pt[1]
+        z = a + b - pt[2]                                             # height of the hip above the foot
+        roll = np.arctan2(-y, z) if RightLeg else np.arctan2(y, z)
+        knee = np.arccos((x ** 2 + y ** 2 + z ** 2 - a ** 2 - b ** 2) / (2.0 * a * b))
+        ryz = np.sqrt(y ** 2 + z ** 2)
+        ratio = a / b
+        thigh = -np.arctan2(ryz * np.sin(knee) + x * np.cos(knee) + x * ratio,
+                            ryz * np.cos(knee) + ryz * ratio - x * np.sin(knee))
+        lim = self.env.real_ranges
+        k_idx, t_idx = (3, 2) if RightLeg else (9, 8)                 # knee / thigh rows of the real joint ranges cap the solution
+        knee = np.clip(knee, lim[k_idx][0], lim[k_idx][1])
+        thigh = np.clip(thigh, lim[t_idx][0], lim[t_idx][1])
+        ankle_pitch = -(thigh + knee)
+        ankle_roll = -roll if RightLeg else roll
+        return np.stack([np.zeros_like(roll), roll, thigh, knee, ankle_pitch, ankle_roll], axis=1)
 
     def joint_space_trajectories(self):
         """EE-space trajectories through the IK (trajectory_generator.py:235-270)."""
