@@ -108,3 +108,13 @@ def test_checkpoint_roundtrip_and_target_quirk(tmp_path):
         assert torch.equal(p, q)
     for p, q in zip(tgt_before, b.actor_target.parameters()):
         assert torch.equal(p, q)
+
+
+def test_reference_training_log_numbers_quoted_in_the_docs(golden_dir):
+    """DESIGN.md / the GPU tests quote the reference's own PyBullet training run (results/plen_walk_gazebo_.npy): 24 832 episodes, last
+    1000 averaging +50, best single episode +328.  Pinned here against a summary of that data file."""
+    import os
+    g = np.load(os.path.join(golden_dir, "ref_training_log_summary.npz"))
+    assert int(g["episodes"]) == 24832
+    assert abs(float(g["last1000_mean"]) - 50.43) < 0.01 and abs(float(g["max_return"]) - 328.04) < 0.01
+    assert float(g["first100_mean"]) < -150 and g["block_means_1000"].shape == (24,)
