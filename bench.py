@@ -1,18 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/s of the vectorised PLEN walking environment on MI355X.
 
-Workload = BASELINE.json configs[1]: 4096 vectorised PLEN envs per GPU, random-action rollout
-(actions U[-1,1] from torch.Generator(device).manual_seed(rank), pre-generated and resident in HBM
-before the timed region).  One "step" = one vector step of all 4096 envs of a rank = 4096 env-steps
-(action map, 4 x 1/240 s physics substeps, observation, termination, reward, auto-reset) in ONE
-kernel launch.  Envs shard one-GPU-per-rank with no data-path collective (weak scaling).
+Headline workload = BASELINE.json configs[1]: 4096 vectorised PLEN envs per GPU, random-action rollout
+(actions U[-1,1] from torch.Generator(device).manual_seed(rank), pre-generated and resident in HBM before the
+timed region).  One "step" = one vector step of all 4096 envs of a rank = 4096 env-steps (action map,
+4 x 1/240 s physics substeps, observation, termination, reward, auto-reset).  Envs shard one-GPU-per-rank with no
+data-path collective (weak scaling).
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; N>1 is launched by the driver through
-torch.distributed.run (one rank per GPU, RCCL); rank 0 prints ONE JSON line.
+The headline `value` is measured in the REFERENCE'S arithmetic, f64 (PyBullet is a double-precision build and
+plen_env.py computes in NumPy float64); the same JSON line carries two more legs measured by the same process:
+  legs.f32 : the f32 kernel (what an RL loop uses; agrees with the f64 oracle statistically)
+  legs.td3 : BASELINE.json configs[2]/[3]: 4096 envs per GPU + the full TD3 loop (actor/critic/replay in
+             PyTorch-ROCm on the same device, f32 env, hipGraph-captured; RCCL gradient all-reduce for N > 1):
+             env-steps/s AND gradient-steps/s, batch and update-to-data ratio stated.
+and `pybullet` records whether the reference's physics engine exists on this machine (it never has so far).
+
+Contract: `python bench.py --gpus N --steps K --warmup W`.  For N > 1 the driver launches it through
+torch.distributed.run (one rank per GPU, RCCL); started from a plain shell with --gpus N > 1 it spawns those ranks
+itself as CHILD processes (decided before anything touches the GPU) and relays rank 0's line.  Rank 0 prints ONE
+JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -21,57 +32,228 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 4096
-ALGO_BYTES_PER_ENV_STEP = 776          # fp32 state+aux+action in, state+aux+obs+reward+done out
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
-VALU_PEAK_GINST_S = 1024 * 2.4 / 4     # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles per SIMD, 2.4 GHz peak clock
+# Measured chip-wide wave64 vector-instruction issue rates (profiles/r02_valu_issue.json, scripts/ubench/valu_issue.hip, 8 waves per
+# SIMD on all 1024 SIMDs), in G wave-instructions/s.  The guide's nominal 2-cycle wave64 rate (1228.8 G/s at 2.4 GHz) is approached
+# only by the FMA class (0.73-0.76 of it); everything else the solver row is made of runs at about half that or less.
+VALU_CLASS_GINST_S = {"fma_mul_add": 900.0, "med3_dpp_writelane_pkfma_f64": 570.0, "readlane": 396.0, "transcendental": 285.0}
+VALU_ROW_MIX_GINST_S = {4: 610.0, 8: 665.0}      # the solver row itself (med3, readlane, writelane, fmac; dependent) at 4 / 8 waves per SIMD
+VALU_NOMINAL_GINST_S = 1024 * 2.4 / 2            # MI355X_MICROARCH.md: wave64 on SIMD-32 = 2 cycles
 
 
-def _pmc_summary():
+def algo_bytes_per_env_step(real_size):
+    """read state 49 + aux 25 reals + action 18 f32; write state 49 + aux 25 + obs 26 + reward 1 reals + done/trunc 4 B.
+    f32: 368 + 408 = 776 B (the survey's figure); f64: 664 + 812 = 1476 B."""
+    return (49 + 25) * real_size + 18 * 4 + (49 + 25 + 26 + 1) * real_size + 4
+
+
+def _pmc_summary(dtype):
     """HBM traffic and instruction counts per launch are PMC measurements (rocprofv3 --pmc, separate passes, gfx950 FETCH_SIZE
-    correction applied); bench.py cannot collect them itself, so it reports the newest committed summary under profiles/."""
+    correction applied); bench.py cannot collect them itself, so it reports the newest committed summary under profiles/ for the dtype."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary%s.json" % ("" if dtype == "f32" else "_" + dtype))))
     if not files:
         return None, None
     with open(files[-1]) as f:
         return json.load(f)["env_kernel_per_launch"], os.path.relpath(files[-1], ROOT)
 
 
-def _cpu_worker(args):
-    """One host core: the C oracle stepping one env with random actions (auto-reset) until the deadline."""
-    seed, budget_s = args
-    import numpy as np
-    from oracle.oracle import OracleEnv
-    rng = np.random.default_rng(seed)
-    env = OracleEnv()
-    env.reset()
-    steps, chunk = 0, 250
-    t0 = time.time()
-    while time.time() - t0 < budget_s:
-        env.rollout(rng.uniform(-1, 1, (chunk, 18)).astype(np.float32))
-        steps += chunk
-    return steps, time.time() - t0
-
-
-def cpu_baseline(budget_s=10.0):
-    """Oracle ("port" of the reference algorithm, f64, gcc -O2) on the host cores this process may use,
-    time-bounded: every worker steps its own env for `budget_s` seconds."""
-    import multiprocessing as mp
+# ------------------------------------------------------------------------------------------------ CPU baseline (rank 0, N = 1)
+def cpu_baseline(budget_s=12.0):
+    """The C oracle ("port" of the reference algorithm, f64) built on THIS machine with gcc -O3 -march=native -fopenmp and timed on the host
+    cores this process may use: (a) one thread stepping one env, (b) every core, 4096 envs partitioned across the threads -- each a bounded
+    sample (whole control steps until the time budget is spent)."""
     from oracle import oracle
-    oracle.build()
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    s1, t1 = _cpu_worker((0, 2.0))
-    ctx = mp.get_context("spawn")
-    with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(100 + i, budget_s) for i in range(cores)])
-    total = sum(r[0] for r in res)
-    wall = max(r[1] for r in res)
-    return {"value": total / wall, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d worker processes (one env each, C oracle f64, gcc -O2) stepping random actions for %.0f s: %d env-steps; "
-                      "one process alone: %.0f env-steps/s" % (cores, budget_s, total, s1 / t1)}
+    lib = oracle.native_lib()
+    one = oracle.native_throughput(lib, n_envs=1, threads=1, budget_s=min(3.0, budget_s / 4))
+    many = oracle.native_throughput(lib, n_envs=ENVS_PER_GPU, threads=cores, budget_s=budget_s)
+    return {"value": many["env_steps_per_s"], "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "C oracle f64 (gcc -O3 -march=native -fopenmp, built on this host): %d envs partitioned over %d threads, random actions, "
+                      "auto-reset, %d vector steps = %d env-steps in %.1f s; one thread alone on one env: %.0f env-steps/s (%d env-steps in %.1f s)"
+                      % (ENVS_PER_GPU, cores, many["vector_steps"], many["env_steps"], many["seconds"], one["env_steps_per_s"], one["env_steps"], one["seconds"]),
+            "one_thread": one["env_steps_per_s"]}
+
+
+def pybullet_status():
+    """The reference's physics is the third-party `pybullet` module (plen_env.py:6).  Probe for it here and now; when present the own
+    harness (tests/pybullet_harness.py, public pybullet API only) times PyBullet's step on one core and measures obs max-abs-err."""
+    try:
+        import pybullet  # noqa: F401
+    except Exception as ex:
+        return {"available": False, "error": "%s: %s" % (type(ex).__name__, ex),
+                "note": "no PyBullet step timing and no obs max-abs-err vs PyBullet can be measured on this machine; probes of the build container "
+                        "and of a GPU box are under profiles/r02_pybullet_probe_*.json (no module, no Bullet library on disk, no package index)"}
+    try:
+        from tests import pybullet_harness as H
+        return dict(H.bench_summary(), available=True)
+    except Exception as ex:      # pybullet importable but the harness failed: say so, never hide it
+        return {"available": True, "error": "harness failed: %r" % (ex,)}
+
+
+# ------------------------------------------------------------------------------------------------ multi-GPU self launch
+def spawn_ranks(argv, n):
+    """`python bench.py --gpus N` from a plain shell: start N ranks as child processes through torch.distributed.run (this parent never
+    initialises the GPU) and pass rank 0's JSON line through."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, env=env)
+    return p.returncode
+
+
+# ------------------------------------------------------------------------------------------------ legs
+def env_leg(a, dtype_name, dev, rank, world, dist, steps, warmup):
+    """Random-action rollout of a.envs_per_gpu envs on this rank; returns the timing dict (max over ranks)."""
+    import torch
+    from plen_ml_walk_amd import sharding
+    from plen_ml_walk_amd.vec_env import PlenVecEnvPipelined
+    n = a.envs_per_gpu
+    dtype = torch.float32 if dtype_name == "f32" else torch.float64
+    env = PlenVecEnvPipelined(n, groups=a.groups, device=dev, dtype=dtype)
+    if a.dr:
+        gd = torch.Generator(device=dev).manual_seed(1000 + rank)
+        env.set_params(mass_scale=0.8 + 0.4 * torch.rand(n, generator=gd, device=dev), lateral_friction=0.4 + 0.6 * torch.rand(n, generator=gd, device=dev))
+    env.reset()
+    g = torch.Generator(device=dev).manual_seed(rank)
+    ring = 64                   # pre-generated action batches resident in HBM (64 x 4096 x 18 f32 = 19 MB)
+    actions = torch.rand(ring, n, 18, generator=g, device=dev, dtype=torch.float32) * 2 - 1
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for t in range(warmup):
+        env.step_async(actions[t % ring])
+    env.sync()
+    barrier()
+    with torch.cuda.stream(env.streams[0]):          # HIP events on the stream the dominant kernel is launched on (sub-batch 0)
+        env.envs[0].timing_begin()
+    t0 = time.perf_counter()
+    for t in range(steps):
+        env.step_async(actions[(warmup + t) % ring])
+    with torch.cuda.stream(env.streams[0]):
+        kernel_ms, launches = env.envs[0].timing_end()
+    env.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    nonfinite = int(env.nonfinite_count())          # PLENVEC_DONE_NONFINITE events of this rank during warm-up + timed steps
+    env.close()
+    # the same workload as ONE launch of all envs per step: the mode in which the dominant kernel's own duration is well defined
+    # (with overlapping sub-batch launches only a period is)
+    single = kernel_ms1 = launches1 = None
+    if a.groups > 1:
+        env1 = PlenVecEnvPipelined(n, groups=1, device=dev, dtype=dtype)
+        env1.reset()
+        for t in range(10):
+            env1.step_async(actions[t % ring])
+        barrier()
+        k1 = min(steps, 100)
+        with torch.cuda.stream(env1.streams[0]):
+            env1.envs[0].timing_begin()
+        t1 = time.perf_counter()
+        for t in range(k1):
+            env1.step_async(actions[(10 + t) % ring])
+        with torch.cuda.stream(env1.streams[0]):
+            kernel_ms1, launches1 = env1.envs[0].timing_end()
+        env1.sync()
+        barrier()
+        single = (time.perf_counter() - t1) / k1
+        env1.close()
+    # the slowest rank defines every time (sharding.max_over_ranks is the identity for one rank)
+    elapsed = sharding.max_over_ranks(elapsed, dev)
+    slot_ms = sharding.max_over_ranks(kernel_ms / max(launches, 1), dev)
+    if single is not None:
+        single = sharding.max_over_ranks(single, dev)
+        launch1_ms = sharding.max_over_ranks(kernel_ms1 / max(launches1, 1), dev)
+    else:
+        launch1_ms = None
+    n_sub = n // a.groups
+    launch_ms, n_launch = (launch1_ms, n) if a.groups > 1 else (slot_ms, n)
+    real_size = 4 if dtype_name == "f32" else 8
+    ab = algo_bytes_per_env_step(real_size)
+    achieved = n_launch * ab / (launch_ms * 1e-3) / 1e9
+    value = world * n * steps / elapsed
+    pmc, pmc_file = _pmc_summary(dtype_name)
+    traffic = pmc["hbm_traffic_bytes"] * n_launch / ENVS_PER_GPU if (pmc and n == ENVS_PER_GPU) else None
+    valu = None
+    if pmc:
+        ginst = pmc["valu_insts_per_env_step"] * value / world / 1e9      # whole-GPU issue rate (all concurrent launches)
+        wps = 4 if dtype_name == "f32" else 2
+        valu = {"insts_per_env_step": pmc["valu_insts_per_env_step"], "achieved": ginst, "unit": "G wave-inst/s",
+                "peak_row_mix": VALU_ROW_MIX_GINST_S[4], "frac_row_mix": ginst / VALU_ROW_MIX_GINST_S[4],
+                "peak_fma_class": VALU_CLASS_GINST_S["fma_mul_add"], "frac_fma_class": ginst / VALU_CLASS_GINST_S["fma_mul_add"],
+                "peak_nominal_2cycle": VALU_NOMINAL_GINST_S, "frac_nominal_2cycle": ginst / VALU_NOMINAL_GINST_S,
+                "waves_per_simd": wps, "class_rates_measured": VALU_CLASS_GINST_S, "source": pmc_file, "rates_source": "profiles/r02_valu_issue.json"}
+    return {
+        "value": value, "unit": "env-steps/s", "dtype": dtype_name, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "sub_batches": "%d x %d envs per GPU on %d HIP streams: every env advances one control step per bench step, sub-batches are not "
+                       "synchronised with each other between steps (PlenVecEnvPipelined); --groups 1 = one launch per step" % (a.groups, n_sub, a.groups),
+        "one_launch_per_step": None if single is None else {"ms_per_step": single * 1e3, "value": world * n / single},
+        "kernel_ms_per_launch": launch_ms, "pipelined_ms_per_launch_slot": slot_ms,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_env_step": ab, "env_steps_per_launch": n_launch, "valu_issue": valu,
+                     "note": "achieved = algorithmic %d B/env-step (SURVEY 8d layout at %d-byte reals) x %d env-steps per launch / %.3f ms per launch (HIP events on "
+                             "the launch stream, launches of all envs back to back); traffic = PMC FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per "
+                             "launch from %s.  The contract's hbm/mfma bounds do not bind this kernel (a serial projected-Gauss-Seidel chain per env): "
+                             "valu_issue prices its measured instruction count against MEASURED issue rates (scripts/ubench/valu_issue.hip): the solver "
+                             "row's own instruction mix, the FMA class, and the guide's nominal 2-cycle rate" % (ab, real_size, n_launch, launch_ms, pmc_file)},
+        "nonfinite_resets": nonfinite,
+    }
+
+
+def td3_leg(a, dev, rank, world, dist, steps, warmup):
+    """BASELINE.json configs[2] (N = 1) / configs[3] (N > 1): envs + the full TD3 training loop on the same device(s)."""
+    import torch
+    from plen_ml_walk_amd import sharding
+    from plen_ml_walk_amd.vec_env import PlenVecEnv
+    from plen_ml_walk_amd.td3 import ReplayBuffer, TD3Agent
+    from plen_ml_walk_amd.train_vec import GraphedVecTD3Trainer
+    n = a.envs_per_gpu
+    torch.manual_seed(0)
+    env = PlenVecEnv(n, device=dev)
+    if a.dr:
+        gd = torch.Generator(device=dev).manual_seed(1000 + rank)
+        env.set_params(mass_scale=0.8 + 0.4 * torch.rand(n, generator=gd, device=dev), lateral_friction=0.4 + 0.6 * torch.rand(n, generator=gd, device=dev))
+    agent = TD3Agent(26, 18, 1.0, device=dev)
+    replay = ReplayBuffer(1000000, device=dev)
+    replay.seed(rank)
+    tr = GraphedVecTD3Trainer(env, agent, replay, start_timesteps=10000, expl_noise=0.1, batch_size=a.td3_batch, updates_per_step=a.td3_updates, seed=1000 + rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(warmup, 8)):          # past the random-action phase (3 vector steps at 4096 envs) and the graph captures
+        tr.step()
+    barrier()
+    e0, g0, t0 = tr.env_steps, tr.grad_steps, time.perf_counter()
+    for _ in range(steps):
+        tr.step()
+    barrier()
+    dt = sharding.max_over_ranks(time.perf_counter() - t0, dev)
+    out = {"value": world * (tr.env_steps - e0) / dt, "unit": "env-steps/s", "grad_steps_per_s": (tr.grad_steps - g0) / dt,
+           "env_dtype": "f32", "net_dtype": "f32", "steps": steps, "ms_per_step": dt / steps * 1e3,
+           "batch_per_rank": a.td3_batch, "updates_per_vector_step": a.td3_updates, "replay_capacity": 1000000, "start_timesteps": 10000,
+           "update_to_data": "%d gradient step(s) of batch %d per vector step of %d env-steps per rank (samples drawn per env-step: %.2f; the reference "
+                             "does 1 step of batch 100 per single env-step, plen_td3.py:119-120)" % (a.td3_updates, a.td3_batch, n, a.td3_updates * a.td3_batch / n),
+           "hip_graphs": True, "collective": ("RCCL all-reduce of the flat critic (155138 f32) and actor (77330 f32) gradient buckets per update, mode %s" % tr.allreduce_mode) if world > 1 else None,
+           "critic_loss": float(agent.last_critic_loss) if agent.last_critic_loss is not None else None,
+           "workload": "BASELINE.json configs[%d]: %d envs per GPU + TD3 (actor 26-256-256-18, twin critic 44-256-256-1, Adam 3e-4, policy_freq 2), exploration N(0, 0.1)" % (2 if world == 1 else 3, n)}
+    env.close()
+    return out
 
 
 def main():
@@ -80,126 +262,65 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--dtype", default="f64", choices=["f32", "f64"], help="arithmetic of the headline leg (f64 = the reference's)")
+    ap.add_argument("--legs", default="f64,f32,td3", help="comma list of legs to run besides the headline one (f64, f32, td3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dr", action="store_true", help="BASELINE.json configs[4]: per-env link-mass scale U[0.8,1.2] and foot friction U[0.4,1.0], seed 1000+rank")
     ap.add_argument("--groups", type=int, default=2, help="independent sub-batches per GPU, one HIP stream each (1 = a single launch per step)")
+    ap.add_argument("--td3-batch", type=int, default=4096)
+    ap.add_argument("--td3-updates", type=int, default=1)
+    ap.add_argument("--td3-steps", type=int, default=200)
     a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(sys.argv[1:], a.gpus))          # before any GPU call in this process
+    if a.gpus != world:
+        raise SystemExit("bench.py --gpus %d was started inside a %d-rank job" % (a.gpus, world))
 
     import torch
     import torch.distributed as dist
-    from plen_ml_walk_amd.vec_env import PlenVecEnvPipelined
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world != a.gpus:
-        raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+    from plen_ml_walk_amd import sharding
+    rank, world, local_rank = sharding.world_info()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    n = a.envs_per_gpu
-    dtype = torch.float32 if a.dtype == "f32" else torch.float64
-    # sub-batches on their own streams: the tail of one launch (its slowest waves) overlaps the body of the other's next step
-    env = PlenVecEnvPipelined(n, groups=a.groups, device=dev, dtype=dtype)
-    if a.dr:
-        gd = torch.Generator(device=dev).manual_seed(1000 + rank)
-        env.set_params(mass_scale=0.8 + 0.4 * torch.rand(n, generator=gd, device=dev), lateral_friction=0.4 + 0.6 * torch.rand(n, generator=gd, device=dev))
-    env.reset()
-    g = torch.Generator(device=dev).manual_seed(rank)
-    # a ring of pre-generated action batches resident in HBM (64 x 4096 x 18 f32 = 19 MB)
-    ring = 64
-    actions = torch.rand(ring, n, 18, generator=g, device=dev, dtype=torch.float32) * 2 - 1
-    done_count = torch.zeros((), dtype=torch.int64, device=dev)
-
-    for t in range(a.warmup):
-        env.step_async(actions[t % ring])
-    env.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    with torch.cuda.stream(env.streams[0]):          # HIP events on the stream the dominant kernel is launched on (sub-batch 0)
-        env.envs[0].timing_begin()
-    t0 = time.perf_counter()
-    for t in range(a.steps):
-        env.step_async(actions[(a.warmup + t) % ring])
-    with torch.cuda.stream(env.streams[0]):
-        kernel_ms, launches = env.envs[0].timing_end()
-    env.sync()
-    done = env.outputs()[2]
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    done_count += done.sum()
-    # for transparency: the same workload as ONE launch of all envs per step (untimed w.r.t. the contract, short)
-    single = None
-    if a.groups > 1:
-        env.close()
-        env1 = PlenVecEnvPipelined(n, groups=1, device=dev, dtype=dtype)
-        env1.reset()
-        for t in range(10):
-            env1.step_async(actions[t % ring])
-        torch.cuda.synchronize()
-        k1 = min(a.steps, 100)
-        with torch.cuda.stream(env1.streams[0]):
-            env1.envs[0].timing_begin()
-        t1 = time.perf_counter()
-        for t in range(k1):
-            env1.step_async(actions[(10 + t) % ring])
-        with torch.cuda.stream(env1.streams[0]):
-            kernel_ms1, launches1 = env1.envs[0].timing_end()
-        env1.sync(); torch.cuda.synchronize()
-        single = (time.perf_counter() - t1) / k1
-        env1.close()
-    if world > 1:
-        tmax = torch.tensor([elapsed, kernel_ms, single or 0.0, kernel_ms1 if single else 0.0], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms, single, kernel_ms1 = float(tmax[0]), float(tmax[1]), (float(tmax[2]) or None), float(tmax[3])
+    legs_wanted = [x for x in a.legs.split(",") if x]
+    head = env_leg(a, a.dtype, dev, rank, world, dist, a.steps, a.warmup)
+    legs = {}
+    for name in legs_wanted:
+        if name == a.dtype:
+            continue
+        try:
+            if name in ("f32", "f64"):
+                legs[name] = env_leg(a, name, dev, rank, world, dist, a.steps, a.warmup)
+            elif name == "td3":
+                legs[name] = td3_leg(a, dev, rank, world, dist, a.td3_steps, a.warmup)
+        except Exception as ex:                                  # the headline stands on its own; a failed leg is reported, not hidden
+            if world > 1:
+                raise
+            legs[name] = {"value": None, "error": repr(ex)}
 
     if rank == 0:
-        total_env_steps = world * n * a.steps
-        value = total_env_steps / elapsed
-        slot_s = kernel_ms * 1e-3 / max(launches, 1)          # period of sub-batch 0's launches (they overlap the other sub-batch's)
-        if a.groups > 1:
-            # the dominant kernel's own duration is measured where it is well defined: back-to-back launches of all envs on one stream
-            launch_s, n_launch = kernel_ms1 * 1e-3 / max(launches1, 1), n
-        else:
-            launch_s, n_launch = slot_s, n
-        achieved = n_launch * ALGO_BYTES_PER_ENV_STEP / launch_s / 1e9
-        pmc, pmc_file = _pmc_summary()
-        traffic = pmc["hbm_traffic_bytes"] * n_launch / ENVS_PER_GPU if (pmc and n == ENVS_PER_GPU and a.dtype == "f32") else None
-        valu = None
-        if pmc and a.dtype == "f32":
-            ginst = pmc["valu_insts_per_env_step"] * value / world / 1e9      # whole-GPU issue rate (all concurrent launches)
-            valu = {"insts_per_env_step": pmc["valu_insts_per_env_step"], "achieved": ginst, "peak": VALU_PEAK_GINST_S, "unit": "G wave-inst/s",
-                    "frac": ginst / VALU_PEAK_GINST_S, "source": pmc_file}
+        n = a.envs_per_gpu
         out = {
-            "metric": "env-steps/sec @4096 envs", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": "env-steps/sec @4096 envs", "value": head["value"], "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[%d]: %d vectorised PLEN envs per MI355X%s, random-action rollout, auto-reset "
-                                   "(done or 500-step limit), 4 x 240 Hz substeps per 60 Hz step" % (4 if a.dr else 1, n, ", per-env domain randomisation (mass x U[0.8,1.2], friction U[0.4,1.0])" if a.dr else ""),
-                       "envs_per_gpu": n, "total_envs": world * n, "substeps": 4, "solver_iterations": 50,
-                       "sub_batches": "%d x %d envs per GPU on %d HIP streams: every env advances one control step per bench step, sub-batches are "
-                                      "not synchronised with each other between steps (PlenVecEnvPipelined); --groups 1 = one launch per step" %
-                                      (a.groups, n_launch, a.groups),
-                       "one_launch_per_step": None if single is None else {"ms_per_step": single * 1e3, "value": world * n / single},
-                       "parallelism": "env-sharded, %d rank(s), no data-path collective" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "valu_issue": valu,
-                         "note": "algorithmic %d B/env-step x %d env-steps per launch / %.3f ms per launch (HIP events on the launch "
-                                 "stream, launches of all envs back to back: in the pipelined mode two launches overlap and only a period is defined); traffic = PMC FETCH_SIZE x2 (gfx950 correction, calibrated on the reset-copy kernel) + WRITE_SIZE "
-                                 "per launch from %s. The contract's hbm/mfma bounds do not bind this kernel: it is a serial "
-                                 "projected-Gauss-Seidel chain per env, bound by wave64 VALU issue (valu_issue: one instruction per 4 cycles "
-                                 "per SIMD) and by the 4-waves-per-SIMD occupancy the 128-VGPR working set allows; see DESIGN.md" %
-                                 (ALGO_BYTES_PER_ENV_STEP, n_launch, launch_s * 1e3, pmc_file)},
-            "kernel_ms_per_launch": launch_s * 1e3, "pipelined_ms_per_launch_slot": slot_s * 1e3,
+            "config": {"workload": "BASELINE.json configs[%d]: %d vectorised PLEN envs per MI355X%s, random-action rollout, auto-reset (done or 500-step limit), "
+                                   "4 x 240 Hz substeps per 60 Hz step, %s arithmetic" % (4 if a.dr else 1, n, ", per-env domain randomisation (mass x U[0.8,1.2], friction U[0.4,1.0])" if a.dr else "",
+                                                                                           "f64 (the reference's: PyBullet double precision + NumPy float64)" if a.dtype == "f64" else "f32"),
+                       "envs_per_gpu": n, "total_envs": world * n, "substeps": 4, "solver_iterations": 50, "sub_batches": head["sub_batches"],
+                       "one_launch_per_step": head["one_launch_per_step"],
+                       "parallelism": "env-sharded, %d rank(s), no data-path collective in the env step" % world},
+            "roofline": head["roofline"],
+            "kernel_ms_per_launch": head["kernel_ms_per_launch"], "pipelined_ms_per_launch_slot": head["pipelined_ms_per_launch_slot"],
+            "nonfinite_resets": head["nonfinite_resets"],
+            "legs": legs,
+            "pybullet": pybullet_status(),
         }
         if not a.no_cpu_baseline and world == 1:
             try:
@@ -207,8 +328,6 @@ def main():
             except Exception as ex:     # the GPU number stands on its own
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
         print(json.dumps(out))
-    if a.groups <= 1:
-        env.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -37,6 +37,10 @@ extern "C" {
 /* done flags written by plenvec_step */
 #define PLENVEC_DONE_TERMINAL 1   /* compute_done() fired (plen_env.py:1072-1093) */
 #define PLENVEC_DONE_TIMELIMIT 2  /* gym TimeLimit: episode step reached max_episode_steps (plen_env.py:15-19) */
+#define PLENVEC_DONE_NONFINITE 4  /* cfg.nonfinite_guard: the step produced a NaN/inf (state, observation or reward); the env was put back
+                                     into its reset state (even with auto_reset = 0), next_obs = the reset observation, reward = 0, and the
+                                     TIMELIMIT bit is set with it so that callers treat the transition as a truncation, never as a terminal.
+                                     The reference's only guard of this kind is robot_gazebo_env.py:182-185 (NaN reward -> shut down). */
 
 typedef struct plenvec plenvec_t;
 
@@ -68,6 +72,8 @@ typedef struct PlenCfg {
     double motor_kp, motor_kd;   /* 0.1, 1.0 (PyBullet POSITION_CONTROL defaults) */
     double motor_max_force;      /* 0.15, plen_env.py:753 */
     double spawn_z;              /* 0.158, plen_env.py:312 */
+    int32_t nonfinite_guard;     /* 1 (default): per-env NaN/inf guard in the step epilogue, see PLENVEC_DONE_NONFINITE; 0: NaNs propagate like in the reference */
+    int32_t reserved0;           /* keep zero */
 } PlenCfg;
 
 /* Fills *cfg with the reference configuration for the given joint_act mode. */
@@ -118,12 +124,20 @@ int plenvec_debug_substeps(plenvec_t *h, const void *targets, int nsub, void *du
 
 /* Domain randomisation (BASELINE.json configs[4]; not in the reference): per-env scale of every
  * link mass (inertia scales with it) and per-env foot/ground lateral friction coefficient.
- * real[num_envs] each; NULL leaves that parameter unchanged.  Takes effect at the next reset. */
+ * real[num_envs] each; NULL leaves that parameter unchanged.  The dynamics use the new values from the next
+ * plenvec_step on; the per-env reset record (the settled stance depends on mass and friction) is re-simulated on the
+ * given stream at the start of the next plenvec_step or plenvec_reset, WITHOUT touching the live state of any env, so
+ * auto-resets and masked resets after set_params always restore a state settled with the current parameters.
+ * (Call it outside hipGraph capture and run one step or reset before capturing.) */
 int plenvec_set_params(plenvec_t *h, const void *mass_scale, const void *lateral_friction, void *stream);
+
+/* Number of PLENVEC_DONE_NONFINITE events since create (all envs).  Host-synchronous on `stream` (diagnostic). */
+int plenvec_get_nonfinite_count(plenvec_t *h, int64_t *count_host, void *stream);
 
 /* Kernel timing hook for bench.py: HIP-event time of the step kernel launches on the stream the
  * kernel was launched on.  begin() records, end() records + synchronises and returns the elapsed
- * milliseconds and the number of step kernels launched in between. */
+ * milliseconds and the number of step kernels launched in between (`launches` counts host-side launch calls: under hipGraph
+ * replay it counts captures, not replays -- time graphs with your own events). */
 int plenvec_timing_begin(plenvec_t *h, void *stream);
 int plenvec_timing_end(plenvec_t *h, void *stream, double *elapsed_ms, int64_t *launches);
 

@@ -63,6 +63,23 @@ def _lib(dtype="f64"):
     return _LIBS[dtype]
 
 
+def native_lib():
+    """The CPU-baseline build (gcc -O3 -march=native -fopenmp), always recompiled on the machine that calls this: -march=native code
+    must not travel between hosts."""
+    subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libplen_oracle_native.so"])
+    lib = C.CDLL(os.path.join(_HERE, "libplen_oracle_native.so"))
+    lib.oracle_throughput.restype = C.c_longlong
+    lib.oracle_throughput.argtypes = [C.c_int, C.c_int, C.c_double, C.c_uint, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    return lib
+
+
+def native_throughput(lib, n_envs, threads, budget_s, seed=0):
+    """n_envs oracle environments, random actions, auto-reset, whole vector steps until budget_s has passed."""
+    sec, vs = C.c_double(0), C.c_int(0)
+    n = lib.oracle_throughput(int(n_envs), int(threads), float(budget_s), int(seed), C.byref(sec), C.byref(vs))
+    return {"env_steps": int(n), "seconds": sec.value, "vector_steps": vs.value, "env_steps_per_s": n / sec.value}
+
+
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 

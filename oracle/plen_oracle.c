@@ -34,7 +34,8 @@
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  *
- * Build:  make -C oracle     (gcc -O2 -fPIC -shared; -DORACLE_REAL=float for the f32 variant)
+ * Build:  make -C oracle     (gcc -O2 -fPIC -shared; -DORACLE_REAL=float for the f32 variant; `make native` =
+ *         -O3 -march=native -fopenmp on the machine that times it, bench.py's cpu_baseline)
  */
 #include <math.h>
 #include <stdlib.h>
@@ -923,6 +924,55 @@ API int oracle_rollout(Oracle *o, int nsteps, const float *actions, double *obs,
         if (done || trunc) oracle_reset(o, NULL);
     }
     return nsteps;
+}
+
+/* ---------------------------------------------------------------- CPU baseline (bench.py cpu_baseline leg)
+ * n_envs environments stepped with uniform random actions (xorshift per env, float32-valued like the Box) and the
+ * driver's auto-reset, whole vector steps until `budget_s` seconds have passed.  With OpenMP (the native build,
+ * gcc -O3 -march=native -fopenmp) the envs of a vector step are partitioned over `threads` threads. Returns env-steps. */
+#ifdef _OPENMP
+#include <omp.h>
+#else
+#include <time.h>
+#endif
+static double wall_now(void) {
+#ifdef _OPENMP
+    return omp_get_wtime();
+#else
+    struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec;
+#endif
+}
+API long long oracle_throughput(int n_envs, int threads, double budget_s, unsigned seed, double *seconds_out, int *vector_steps_out) {
+    Oracle **envs = (Oracle **)calloc((size_t)n_envs, sizeof(Oracle *));
+    uint64_t *rng = (uint64_t *)calloc((size_t)n_envs, sizeof(uint64_t));
+    for (int e = 0; e < n_envs; e++) { envs[e] = oracle_create(0); oracle_reset(envs[e], NULL); rng[e] = 0x9E3779B97F4A7C15ull * (uint64_t)(seed + 1 + e) | 1ull; }
+    int vsteps = 0;
+    (void)threads;
+    const double t0 = wall_now();
+    double t1 = t0;
+    do {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads)
+#endif
+        for (int e = 0; e < n_envs; e++) {
+            double a[ND], ob[26]; int done;
+            uint64_t x = rng[e];
+            for (int d = 0; d < ND; d++) {
+                x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+                a[d] = (double)(float)(((double)(x >> 11) * (1.0 / 9007199254740992.0)) * 2.0 - 1.0);
+            }
+            rng[e] = x;
+            oracle_step(envs[e], a, ob, &done);
+            if (done || envs[e]->episode_timestep >= 500) oracle_reset(envs[e], NULL);
+        }
+        vsteps++;
+        t1 = wall_now();
+    } while (t1 - t0 < budget_s);
+    for (int e = 0; e < n_envs; e++) oracle_destroy(envs[e]);
+    free(envs); free(rng);
+    if (seconds_out) *seconds_out = t1 - t0;
+    if (vector_steps_out) *vector_steps_out = vsteps;
+    return (long long)vsteps * n_envs;
 }
 
 API double oracle_last_residual(const Oracle *o) { return (double)o->last_residual; }

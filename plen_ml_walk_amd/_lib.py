@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("PLENVEC_LIB") or os.path.join(_HERE, "csrc", "libplen
 
 OBS, ACT, STATE, DUMP = 26, 18, 49, 4096
 DTYPE_F32, DTYPE_F64 = 0, 1
-DONE_TERMINAL, DONE_TIMELIMIT = 1, 2
+DONE_TERMINAL, DONE_TIMELIMIT, DONE_NONFINITE = 1, 2, 4
 
 
 class PlenCfg(C.Structure):
@@ -21,12 +21,13 @@ class PlenCfg(C.Structure):
                 ("linear_slop", C.c_double), ("residual_threshold", C.c_double), ("restitution_velocity_threshold", C.c_double),
                 ("max_coordinate_velocity", C.c_double), ("lateral_friction", C.c_double), ("spinning_friction", C.c_double),
                 ("rolling_friction", C.c_double), ("restitution", C.c_double), ("linear_damping", C.c_double),
-                ("motor_kp", C.c_double), ("motor_kd", C.c_double), ("motor_max_force", C.c_double), ("spawn_z", C.c_double)]
+                ("motor_kp", C.c_double), ("motor_kd", C.c_double), ("motor_max_force", C.c_double), ("spawn_z", C.c_double),
+                ("nonfinite_guard", C.c_int32), ("reserved0", C.c_int32)]
 
 
 EXPORTS = ["plenvec_default_cfg", "plenvec_create", "plenvec_destroy", "plenvec_num_envs", "plenvec_dtype", "plenvec_reset",
            "plenvec_step", "plenvec_get_state", "plenvec_set_state", "plenvec_get_aux", "plenvec_debug_substeps",
-           "plenvec_set_params", "plenvec_timing_begin", "plenvec_timing_end", "plenvec_last_error", "plenvec_version"]
+           "plenvec_set_params", "plenvec_get_nonfinite_count", "plenvec_timing_begin", "plenvec_timing_end", "plenvec_last_error", "plenvec_version"]
 
 _lib = None
 
@@ -57,6 +58,7 @@ def load():
     lib.plenvec_get_aux.argtypes = [vp, vp, vp]
     lib.plenvec_debug_substeps.argtypes = [vp, vp, i32, vp, vp]
     lib.plenvec_set_params.argtypes = [vp, vp, vp, vp]
+    lib.plenvec_get_nonfinite_count.argtypes = [vp, C.POINTER(C.c_int64), vp]
     lib.plenvec_timing_begin.argtypes = [vp, vp]
     lib.plenvec_timing_end.argtypes = [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.plenvec_last_error.restype = C.c_char_p

@@ -1433,7 +1433,8 @@ struct StepArgs {
     const real *mass_scale; const real *mu_lat;  // per-env domain randomisation or null
     real *dump;                                  // [N][PLENVEC_DUMP] or null
     const int *perm;                             // block -> env placement for SIMD load balance, or null (identity)
-    int n, mode, nsub, auto_reset;
+    unsigned long long *nonfinite;               // device counter of PLENVEC_DONE_NONFINITE events
+    int n, mode, nsub, auto_reset, guard;
 };
 
 // plen_env.py:694-714, evaluated in double so the +-0.001 clamps fire exactly where the reference's do
@@ -1567,6 +1568,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real)
 
     real reward = 0;
     int done_flag = 0;
+    bool nonfinite_hit = false;
     if (mode == MODE_STEP) {
         // compute_done (plen_env.py:1072-1093): one-sided on roll/pitch/y
         const real PI3 = (real)(3.14159265358979323846 / 3.0);
@@ -1631,6 +1633,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real)
         ep_step += 1; gait_cnt += 1;
         const bool trunc = ep_step >= P.max_episode_steps;
         done_flag = (dead ? PLENVEC_DONE_TERMINAL : 0) | ((trunc || gz_timeout) ? PLENVEC_DONE_TIMELIMIT : 0);
+        // Non-finite guard (the reference's only one is robot_gazebo_env.py:182-185): a NaN/inf anywhere in the
+        // state record, the observation or the reward (e.g. the unguarded 0/0 of the cosine similarity, plen_env.py:929-945) must not
+        // reach the caller's replay memory.  The env is put back into its reset state, the transition reported as a truncation to the
+        // reset observation with reward 0, and the event counted.
+        if (a->guard) {
+            const real chk = s.st[lane] * (real)0 + ob * (real)0 + reward * (real)0;      // 0 when everything is finite, NaN otherwise
+            if (__ballot(chk != (real)0 || chk != chk)) {
+                nonfinite_hit = true;
+                done_flag = PLENVEC_DONE_NONFINITE | PLENVEC_DONE_TIMELIMIT;
+                reward = 0;
+                ob = lane < PLENVEC_OBS ? a->reset_obs[(size_t)env * PLENVEC_OBS + lane] : (real)0;
+                if (lane == 0) atomicAdd(a->nonfinite, 1ull);
+            }
+        }
         if (lane < PLENVEC_OBS) a->next_obs[(size_t)env * PLENVEC_OBS + lane] = ob;
         if (lane == 0) { a->reward[env] = reward; a->done[env] = (uint8_t)done_flag; }
     } else {
@@ -1645,18 +1661,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real)
     if (lane < 9) s.st[55 + lane] = sums[lane];
     WSYNC();
 
-    if (mode == MODE_RESET_BUILD) {
-        a->state[(size_t)env * REC + lane] = s.st[lane];
+    if (mode == MODE_RESET_BUILD) {        // fills the per-env reset record only; live state is untouched (plenvec_reset copies from it)
         a->reset_state[(size_t)env * REC + lane] = s.st[lane];
         if (lane < PLENVEC_OBS) a->reset_obs[(size_t)env * PLENVEC_OBS + lane] = ob;
         if (lane < AUXN) {
             const int v = lane == 4 ? rc : (lane == 5 ? lc : (lane == 6 ? iters : (lane == 7 ? load : 0)));
-            a->aux[(size_t)env * AUXN + lane] = v; a->reset_aux[(size_t)env * AUXN + lane] = v;
+            a->reset_aux[(size_t)env * AUXN + lane] = v;
         }
         return;
     }
     // ---- MODE_STEP: store, auto-reset when the episode ended (TimeLimit + plen_td3.py:122-133) ----
-    const bool ended = done_flag != 0 && a->auto_reset;
+    const bool ended = (done_flag != 0 && a->auto_reset) || nonfinite_hit;
     if (ended) {
         a->state[(size_t)env * REC + lane] = a->reset_state[(size_t)env * REC + lane];
         if (lane < AUXN) a->aux[(size_t)env * AUXN + lane] = a->reset_aux[(size_t)env * AUXN + lane];
@@ -1752,6 +1767,7 @@ struct plenvec {
     size_t rsz;
     void *P, *state, *reset_state, *reset_obs, *mass_scale, *mu_lat;
     int *aux, *reset_aux, *perm;
+    unsigned long long *nonfinite;
     bool reset_dirty, use_ms, use_mu, fast, balance;
     hipEvent_t ev0, ev1;
     int64_t launches, launches_mark;
@@ -1798,7 +1814,8 @@ static int launch_env(plenvec *h, int mode, int nsub, const float *action, const
         hipLaunchKernelGGL(plen_balance_kernel, dim3(1), dim3(1024), 0, st, h->n, h->simds, h->aux, h->perm);
         a.perm = h->perm;
     }
-    a.n = h->n; a.mode = mode; a.nsub = nsub; a.auto_reset = h->cfg.auto_reset;
+    a.nonfinite = h->nonfinite;
+    a.n = h->n; a.mode = mode; a.nsub = nsub; a.auto_reset = h->cfg.auto_reset; a.guard = h->cfg.nonfinite_guard;
     if (h->fast) hipLaunchKernelGGL((plen_env_kernel<real, true>), dim3(h->n), dim3(64), 0, st, a);
     else hipLaunchKernelGGL((plen_env_kernel<real, false>), dim3(h->n), dim3(64), 0, st, a);
     HIPCHK(hipGetLastError());
@@ -1818,6 +1835,16 @@ static int rebuild_reset_cache(plenvec *h, hipStream_t st) {
     return rcode;
 }
 
+static int reset_copy(plenvec *h, const uint8_t *mask, void *obs, hipStream_t st) {
+    const int per = 4, blocks = (h->n + per - 1) / per;
+    if (h->dtype == PLENVEC_DTYPE_F64)
+        hipLaunchKernelGGL(plen_reset_copy_kernel<double>, dim3(blocks), dim3(64 * per), 0, st, h->n, mask, (const double *)h->reset_state, h->reset_aux, (const double *)h->reset_obs, (double *)h->state, h->aux, (double *)obs);
+    else
+        hipLaunchKernelGGL(plen_reset_copy_kernel<float>, dim3(blocks), dim3(64 * per), 0, st, h->n, mask, (const float *)h->reset_state, h->reset_aux, (const float *)h->reset_obs, (float *)h->state, h->aux, (float *)obs);
+    HIPCHK(hipGetLastError());
+    return PLENVEC_OK;
+}
+
 static int state_io(plenvec *h, void *ext, int set, hipStream_t st) {
     if (!ext) return fail(PLENVEC_E_INVAL, "state must be a device pointer");
     const int per = 4, blocks = (h->n + per - 1) / per;
@@ -1829,7 +1856,7 @@ static int state_io(plenvec *h, void *ext, int set, hipStream_t st) {
 extern "C" {
 
 const char *plenvec_last_error(void) { return g_err.c_str(); }
-const char *plenvec_version(void) { return "plenvec 0.1 (gfx950, wave-per-env)"; }
+const char *plenvec_version(void) { return "plenvec 0.2 (gfx950, wave-per-env)"; }
 
 int plenvec_default_cfg(PlenCfg *c, int joint_act) {
     if (!c) return fail(PLENVEC_E_INVAL, "cfg is NULL");
@@ -1841,6 +1868,7 @@ int plenvec_default_cfg(PlenCfg *c, int joint_act) {
     c->lateral_friction = 0.8 * 0.8; c->spinning_friction = 0.1 * 0.8; c->rolling_friction = (joint_act ? 0.01 : 0.1) * 0.8;
     c->restitution = 0.5 * 0.5; c->linear_damping = joint_act ? 0.1 : 0.0;
     c->motor_kp = 0.1; c->motor_kd = 1.0; c->motor_max_force = 0.15; c->spawn_z = 0.158;
+    c->nonfinite_guard = 1;
     return PLENVEC_OK;
 }
 
@@ -1853,41 +1881,48 @@ int plenvec_create(const PlenCfg *cfg, int num_envs, int device, plenvec_t **out
         return fail(PLENVEC_E_NODEV, "no HIP device visible: libplenvec has no CPU fallback");
     if (device < 0 || device >= ndev) return fail(PLENVEC_E_INVAL, "device index out of range");
     HIPCHK(hipSetDevice(device));
-    plenvec *h = new plenvec();
+    plenvec *h = new plenvec();          // value-initialised: every pointer null, so plenvec_destroy is safe on a half-built handle
+    // every failure below releases what was allocated so far
+#define HIPCHK_H(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { plenvec_destroy(h); return fail(PLENVEC_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
     if (cfg) h->cfg = *cfg; else plenvec_default_cfg(&h->cfg, 0);
-    if (h->cfg.dtype != PLENVEC_DTYPE_F32 && h->cfg.dtype != PLENVEC_DTYPE_F64) { delete h; return fail(PLENVEC_E_INVAL, "bad dtype"); }
-    if (h->cfg.substeps <= 0 || h->cfg.reset_substeps < 0 || h->cfg.num_iterations <= 0) { delete h; return fail(PLENVEC_E_INVAL, "bad substeps/iterations"); }
-    h->n = num_envs; h->device = device; h->dtype = h->cfg.dtype;
+    h->device = device;
+    if (h->cfg.dtype != PLENVEC_DTYPE_F32 && h->cfg.dtype != PLENVEC_DTYPE_F64) { plenvec_destroy(h); return fail(PLENVEC_E_INVAL, "bad dtype"); }
+    if (h->cfg.substeps <= 0 || h->cfg.reset_substeps < 0 || h->cfg.num_iterations <= 0) { plenvec_destroy(h); return fail(PLENVEC_E_INVAL, "bad substeps/iterations"); }
+    h->n = num_envs; h->dtype = h->cfg.dtype;
     h->rsz = h->dtype == PLENVEC_DTYPE_F64 ? 8 : 4;
     const size_t N = (size_t)num_envs;
-    HIPCHK(hipMalloc(&h->state, N * REC * h->rsz));
-    HIPCHK(hipMalloc(&h->reset_state, N * REC * h->rsz));
-    HIPCHK(hipMalloc(&h->reset_obs, N * PLENVEC_OBS * h->rsz));
-    HIPCHK(hipMalloc(&h->mass_scale, N * h->rsz));
-    HIPCHK(hipMalloc(&h->mu_lat, N * h->rsz));
-    HIPCHK(hipMalloc((void **)&h->aux, N * AUXN * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&h->reset_aux, N * AUXN * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&h->perm, N * sizeof(int)));
+    HIPCHK_H(hipMalloc(&h->state, N * REC * h->rsz));
+    HIPCHK_H(hipMalloc(&h->reset_state, N * REC * h->rsz));
+    HIPCHK_H(hipMalloc(&h->reset_obs, N * PLENVEC_OBS * h->rsz));
+    HIPCHK_H(hipMalloc(&h->mass_scale, N * h->rsz));
+    HIPCHK_H(hipMalloc(&h->mu_lat, N * h->rsz));
+    HIPCHK_H(hipMalloc((void **)&h->aux, N * AUXN * sizeof(int)));
+    HIPCHK_H(hipMalloc((void **)&h->reset_aux, N * AUXN * sizeof(int)));
+    HIPCHK_H(hipMalloc((void **)&h->perm, N * sizeof(int)));
+    HIPCHK_H(hipMalloc((void **)&h->nonfinite, sizeof(unsigned long long)));
+    HIPCHK_H(hipMemset(h->nonfinite, 0, sizeof(unsigned long long)));
     if (h->dtype == PLENVEC_DTYPE_F64) {
         DevParams<double> p; fill_params(h->cfg, p);
-        HIPCHK(hipMalloc(&h->P, sizeof p)); HIPCHK(hipMemcpy(h->P, &p, sizeof p, hipMemcpyHostToDevice));
+        HIPCHK_H(hipMalloc(&h->P, sizeof p)); HIPCHK_H(hipMemcpy(h->P, &p, sizeof p, hipMemcpyHostToDevice));
     } else {
         DevParams<float> p; fill_params(h->cfg, p);
-        HIPCHK(hipMalloc(&h->P, sizeof p)); HIPCHK(hipMemcpy(h->P, &p, sizeof p, hipMemcpyHostToDevice));
+        HIPCHK_H(hipMalloc(&h->P, sizeof p)); HIPCHK_H(hipMemcpy(h->P, &p, sizeof p, hipMemcpyHostToDevice));
     }
-    HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
+    HIPCHK_H(hipEventCreate(&h->ev0)); HIPCHK_H(hipEventCreate(&h->ev1));
     h->use_ms = h->use_mu = false; h->launches = 0; h->launches_mark = 0;
     h->fast = getenv("PLENVEC_NO_ASM") == nullptr;
     // SIMD load balancing pays once SIMDs hold more than one wave each (1024 SIMDs); PLENVEC_NO_BALANCE=1 keeps the identity placement
     {
         hipDeviceProp_t prop;
-        HIPCHK(hipGetDeviceProperties(&prop, device));
+        HIPCHK_H(hipGetDeviceProperties(&prop, device));
         h->simds = 4 * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
     }
     h->balance = num_envs > h->simds && getenv("PLENVEC_NO_BALANCE") == nullptr;
     int rcode = rebuild_reset_cache(h, 0);
+    if (rcode == PLENVEC_OK) rcode = reset_copy(h, nullptr, nullptr, 0);      // all envs start in the post-reset state
     if (rcode != PLENVEC_OK) { plenvec_destroy(h); return rcode; }
-    HIPCHK(hipStreamSynchronize(0));
+    HIPCHK_H(hipStreamSynchronize(0));
+#undef HIPCHK_H
     *out = h;
     return PLENVEC_OK;
 }
@@ -1896,7 +1931,7 @@ int plenvec_destroy(plenvec_t *h) {
     if (!h) return PLENVEC_OK;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
-    void *bufs[] = {h->state, h->reset_state, h->reset_obs, h->mass_scale, h->mu_lat, h->aux, h->reset_aux, h->perm, h->P};
+    void *bufs[] = {h->state, h->reset_state, h->reset_obs, h->mass_scale, h->mu_lat, h->aux, h->reset_aux, h->perm, h->nonfinite, h->P};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1911,22 +1946,20 @@ int plenvec_reset(plenvec_t *h, const uint8_t *mask, void *obs, void *stream) {
     if (!h) return fail(PLENVEC_E_INVAL, "handle is NULL");
     hipStream_t st = (hipStream_t)stream;
     if (h->reset_dirty) {
-        // parameters changed: the settle has to be re-simulated; this also puts EVERY env in its reset state
+        // parameters changed (plenvec_set_params): the settle is re-simulated into the reset records; live envs outside `mask` keep their state
         int rcode = rebuild_reset_cache(h, st);
         if (rcode != PLENVEC_OK) return rcode;
     }
-    const int per = 4, blocks = (h->n + per - 1) / per;
-    if (h->dtype == PLENVEC_DTYPE_F64)
-        hipLaunchKernelGGL(plen_reset_copy_kernel<double>, dim3(blocks), dim3(64 * per), 0, st, h->n, mask, (const double *)h->reset_state, h->reset_aux, (const double *)h->reset_obs, (double *)h->state, h->aux, (double *)obs);
-    else
-        hipLaunchKernelGGL(plen_reset_copy_kernel<float>, dim3(blocks), dim3(64 * per), 0, st, h->n, mask, (const float *)h->reset_state, h->reset_aux, (const float *)h->reset_obs, (float *)h->state, h->aux, (float *)obs);
-    HIPCHK(hipGetLastError());
-    return PLENVEC_OK;
+    return reset_copy(h, mask, obs, st);
 }
 
 int plenvec_step(plenvec_t *h, const float *action, void *next_obs, void *reward, uint8_t *done, void *cur_obs, void *stream) {
     if (!h) return fail(PLENVEC_E_INVAL, "handle is NULL");
     if (!action || !next_obs || !reward || !done) return fail(PLENVEC_E_INVAL, "action/next_obs/reward/done must be device pointers");
+    if (h->reset_dirty) {        // auto-resets inside this step must restore a stance settled with the CURRENT parameters
+        int rcode = rebuild_reset_cache(h, (hipStream_t)stream);
+        if (rcode != PLENVEC_OK) return rcode;
+    }
     return launch_env_any(h, MODE_STEP, h->cfg.substeps, action, nullptr, next_obs, reward, done, cur_obs, nullptr, (hipStream_t)stream);
 }
 
@@ -1951,6 +1984,15 @@ int plenvec_set_params(plenvec_t *h, const void *mass_scale, const void *lateral
     if (mass_scale) { HIPCHK(hipMemcpyAsync(h->mass_scale, mass_scale, (size_t)h->n * h->rsz, hipMemcpyDeviceToDevice, st)); h->use_ms = true; }
     if (lateral_friction) { HIPCHK(hipMemcpyAsync(h->mu_lat, lateral_friction, (size_t)h->n * h->rsz, hipMemcpyDeviceToDevice, st)); h->use_mu = true; }
     h->reset_dirty = true;
+    return PLENVEC_OK;
+}
+
+int plenvec_get_nonfinite_count(plenvec_t *h, int64_t *count_host, void *stream) {
+    if (!h || !count_host) return fail(PLENVEC_E_INVAL, "handle/count is NULL");
+    unsigned long long v = 0;
+    HIPCHK(hipMemcpyAsync(&v, h->nonfinite, sizeof v, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    *count_host = (int64_t)v;
     return PLENVEC_OK;
 }
 

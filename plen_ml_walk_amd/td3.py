@@ -220,6 +220,62 @@ class _FlatGrads(object):
             self.flat.div_(dist.get_world_size())
 
 
+def td3_critic_backward(agent, batch, noise=None):
+    """First half of a TD3 iteration (reference td3.py:274-323): target-policy smoothing, clipped double-Q target, critic loss,
+    gradients into the critic's flat bucket.  `noise` overrides the randn_like draw (golden tests feed the reference's)."""
+    state, action, next_state, reward, not_done = batch
+    with torch.no_grad():
+        if noise is None:
+            noise = torch.randn_like(action)
+        noise = (noise * agent.policy_noise).clamp(-agent.noise_clip, agent.noise_clip)
+        next_action = (agent.actor_target(next_state) + noise).clamp(-agent.max_action, agent.max_action)
+        target_Q1, target_Q2 = agent.critic_target(next_state, next_action)
+        target_Q = torch.min(target_Q1, target_Q2)
+        target_Q = reward + not_done * agent.discount * target_Q
+    current_Q1, current_Q2 = agent.critic(state, action)
+    critic_loss = F.mse_loss(current_Q1, target_Q) + F.mse_loss(current_Q2, target_Q)
+    agent._critic_grads.zero()
+    critic_loss.backward()
+    return critic_loss.detach()
+
+
+def td3_actor_backward(agent, batch):
+    """Delayed policy gradient (reference td3.py:334-341) into the actor's flat bucket."""
+    state = batch[0]
+    actor_loss = -agent.critic.Q1(state, agent.actor(state)).mean()
+    agent._actor_grads.zero()
+    actor_loss.backward()                          # also writes critic grads; they are zeroed before their next use
+    return actor_loss.detach()
+
+
+def td3_polyak(agent):
+    """tau*p + (1-tau)*t for critic then actor targets (reference td3.py:348-356)."""
+    with torch.no_grad():
+        for net, tgt in ((agent.critic, agent.critic_target), (agent.actor, agent.actor_target)):
+            ps, ts = list(net.parameters()), list(tgt.parameters())
+            torch._foreach_mul_(ts, 1 - agent.tau)
+            torch._foreach_add_(ts, ps, alpha=agent.tau)
+
+
+def td3_update(agent, batch, with_policy, noise=None, all_reduce=True):
+    """THE TD3 iteration (reference td3.py:259-356) on an explicit batch: the one implementation behind TD3Agent.train, the eager vector
+    trainer and the hipGraph-captured trainer (train_vec.py), so that one golden test covers them all.  With torch.distributed
+    initialised the two flat gradient buckets are averaged over ranks before their optimiser steps."""
+    loss = td3_critic_backward(agent, batch, noise)
+    if all_reduce:
+        agent._critic_grads.all_reduce_mean()
+    agent.critic_optimizer.step()
+    agent.last_critic_loss = loss
+    if with_policy:
+        aloss = td3_actor_backward(agent, batch)
+        if all_reduce:
+            agent._actor_grads.all_reduce_mean()
+        agent.actor_optimizer.step()
+        agent.last_actor_loss = aloss
+        td3_polyak(agent)
+    return loss
+
+
 class TD3Agent(object):
     """Twin Delayed DDPG agent with the reference's constructor and methods (td3.py:196-376)."""
 
@@ -268,32 +324,8 @@ class TD3Agent(object):
     def train(self, replay_buffer, batch_size=100):
         """One TD3 iteration, reference td3.py:259-356 (same order of operations and RNG call)."""
         self.total_it += 1
-        state, action, next_state, reward, not_done = replay_buffer.sample(batch_size)
-        with torch.no_grad():
-            noise = (torch.randn_like(action) * self.policy_noise).clamp(-self.noise_clip, self.noise_clip)
-            next_action = (self.actor_target(next_state) + noise).clamp(-self.max_action, self.max_action)
-            target_Q1, target_Q2 = self.critic_target(next_state, next_action)
-            target_Q = torch.min(target_Q1, target_Q2)
-            target_Q = reward + not_done * self.discount * target_Q
-        current_Q1, current_Q2 = self.critic(state, action)
-        critic_loss = F.mse_loss(current_Q1, target_Q) + F.mse_loss(current_Q2, target_Q)
-        self._critic_grads.zero()
-        critic_loss.backward()
-        self._critic_grads.all_reduce_mean()
-        self.critic_optimizer.step()
-        self.last_critic_loss = critic_loss.detach()
-        if self.total_it % self.policy_freq == 0:
-            actor_loss = -self.critic.Q1(state, self.actor(state)).mean()
-            self._actor_grads.zero()
-            actor_loss.backward()                          # also writes critic grads; they are zeroed before their next use
-            self._actor_grads.all_reduce_mean()
-            self.actor_optimizer.step()
-            self.last_actor_loss = actor_loss.detach()
-            with torch.no_grad():
-                for net, tgt in ((self.critic, self.critic_target), (self.actor, self.actor_target)):
-                    ps, ts = list(net.parameters()), list(tgt.parameters())
-                    torch._foreach_mul_(ts, 1 - self.tau)                 # tau*p + (1-tau)*t, td3.py:348-356
-                    torch._foreach_add_(ts, ps, alpha=self.tau)
+        batch = replay_buffer.sample(batch_size)
+        td3_update(self, batch, with_policy=self.total_it % self.policy_freq == 0)
 
     # ---- checkpoints: the reference's four files per checkpoint (td3.py:358-376) -----------------
     def save(self, filename):
@@ -305,16 +337,18 @@ class TD3Agent(object):
     def load(self, filename, load_optimizers=True):
         """Targets are NOT restored, exactly like the reference (td3.py:366-376).
         Files are read with weights_only=True; the reference's legacy optimizer pickles cannot be read
-        that way, so a missing/unreadable optimizer file is skipped with a warning instead of being
-        force-unpickled."""
+        that way, so a missing file or a legacy pickle is skipped with a warning instead of being
+        force-unpickled; a readable file whose contents do not fit raises."""
         self.critic.load_state_dict(torch.load(filename + "_critic", map_location=self.device, weights_only=True))
         self.actor.load_state_dict(torch.load(filename + "_actor", map_location=self.device, weights_only=True))
         if load_optimizers:
             for opt, suffix in ((self.critic_optimizer, "_critic_optimizer"), (self.actor_optimizer, "_actor_optimizer")):
                 try:
-                    opt.load_state_dict(torch.load(filename + suffix, map_location=self.device, weights_only=True))
-                except Exception as ex:       # noqa: BLE001 -- legacy pickle or absent file
+                    sd = torch.load(filename + suffix, map_location=self.device, weights_only=True)
+                except (FileNotFoundError, pickle.UnpicklingError) as ex:       # absent file, or the reference's legacy pickle that weights_only refuses
                     print("TD3Agent.load: optimizer state %s not loaded (%s)" % (suffix, type(ex).__name__))
+                    continue
+                opt.load_state_dict(sd)       # a readable but mismatched optimizer file is an error, not a fresh start
 
     def load_arrays(self, arrays):
         """Load actor./critic. arrays (e.g. tests/golden/policy_3229999.npz, the reference's shipped policy)."""

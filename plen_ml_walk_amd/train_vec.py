@@ -35,7 +35,8 @@ def setup_distributed():
             dist.init_process_group(backend, device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
         else:
             dist.init_process_group(backend)
-    return int(os.environ.get("RANK", "0")), world
+    from . import sharding
+    return sharding.world_info()[0], world
 
 
 def save_training(agent, trainer, prefix):
@@ -121,12 +122,13 @@ def main(argv=None):
     ap.add_argument("--replay", type=int, default=1000000)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--save", default=None, help="checkpoint prefix (reference 4-file layout)")
-    ap.add_argument("--graphs", type=int, default=1, help="capture collect/update in hipGraphs (single rank only)")
+    ap.add_argument("--graphs", type=int, default=1, help="capture collect/update in hipGraphs (any number of ranks)")
     ap.add_argument("--resume", default=None, help="checkpoint prefix to continue from (4-file layout + <prefix>_trainer.json; plen_td3.py:57-69)")
     ap.add_argument("--buffer-path", default=None, help="directory of replay_buffer_<n>.data files (td3.py:128-131)")
     ap.add_argument("--save-replay", type=int, default=None, help="write the rank-local replay buffer as replay_buffer_<n>.data at the end")
     ap.add_argument("--load-replay", type=int, default=None, help="read replay_buffer_<n>.data before training (with --resume)")
     a = ap.parse_args(argv)
+    from . import sharding
     from .vec_env import PlenVecEnv
     from .td3 import ReplayBuffer, TD3Agent
     import torch.distributed as dist
@@ -143,7 +145,8 @@ def main(argv=None):
     resumed = None
     if a.resume:
         resumed = resume_training(agent, replay, a.resume, a.load_replay)
-    if a.graphs and world == 1:
+    torch.manual_seed(a.seed + 7919 * (rank + 1))                # from here on the global generator (target-policy smoothing noise) differs per rank
+    if a.graphs:
         tr = GraphedVecTD3Trainer(env, agent, replay, a.start_timesteps, 0.1, a.batch, a.updates_per_step, seed=1000 + rank)
     else:
         tr = VecTD3Trainer(env, agent, replay, a.start_timesteps, 0.1, a.batch, a.updates_per_step, seed=1000 + rank)
@@ -160,15 +163,11 @@ def main(argv=None):
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt[0])
+    dt = sharding.max_over_ranks(time.perf_counter() - t0, dev)
     if rank == 0:
         print(json.dumps({"metric": "td3_env_steps_per_sec", "value": world * (tr.env_steps - e0) / dt, "unit": "env-steps/s",
                           "grad_steps_per_sec": (tr.grad_steps - g0) / dt, "n_gpus": world, "envs_per_gpu": a.envs, "batch": a.batch,
-                          "updates_per_step": a.updates_per_step, "hip_graphs": bool(a.graphs and world == 1), "steps": a.steps, "ms_per_step": dt / a.steps * 1e3,
+                          "updates_per_step": a.updates_per_step, "hip_graphs": bool(a.graphs), "allreduce_mode": getattr(tr, "allreduce_mode", None), "steps": a.steps, "ms_per_step": dt / a.steps * 1e3,
                           "critic_loss": float(agent.last_critic_loss) if agent.last_critic_loss is not None else None}))
         if a.save:
             save_training(agent, tr, a.save)
@@ -181,18 +180,28 @@ def main(argv=None):
 
 
 class GraphedVecTD3Trainer(object):
-    """The same loop as VecTD3Trainer with the launch-bound parts captured in hipGraphs (single rank):
+    """The same loop as VecTD3Trainer with the launch-bound parts captured in hipGraphs:
       collect graph : actor forward (+ exploration noise) or uniform random actions -> libplenvec step kernel
                       (launched on the capturing stream through the C ABI) -> ring write into the replay tensors
                       -> next state;
-      update graphs : replay sampling on device -> TD3 critic update (-> actor + target update every
-                      `policy_freq`-th call), Adam with capturable state.
+      update graphs : replay sampling on device -> td3.td3_update (the one TD3 iteration shared with TD3Agent.train),
+                      Adam with capturable state.
     Write position / fill level of the ring live in device scalars that the graphs advance; the host mirrors the
-    same arithmetic, so nothing synchronises.  Gradients are not all-reduced here: use VecTD3Trainer (eager
-    updates) when world_size > 1."""
+    same arithmetic, so nothing synchronises.
+
+    world_size > 1 (one rank per GPU): the update is cut at its two collectives into graph segments
+        [sample + targets + critic backward] -> all-reduce(critic bucket) -> [critic Adam (+ actor backward)]
+        -> all-reduce(actor bucket) -> [actor Adam + Polyak]
+    with the RCCL all-reduces issued eagerly between the graph replays (`allreduce_mode` "eager-between-graphs"); set
+    PLEN_TD3_CAPTURE_ALLREDUCE=1 to capture the collectives inside one graph instead ("captured").
+
+    Every graph key is executed eagerly (on a side stream) the first two times it is needed and captured on the third: those
+    eager runs ARE the loop's real iterations, so the collect/update cadence and policy_freq alternation are exactly the eager
+    trainer's from the first step on."""
 
     def __init__(self, env, agent, replay, start_timesteps=10000, expl_noise=0.1, batch_size=4096, updates_per_step=1, seed=0):
-        import torch.nn.functional as F
+        import torch.distributed as dist
+        from . import td3 as T
         assert agent.device.type == "cuda"
         self.env, self.agent, self.replay = env, agent, replay
         self.start_timesteps, self.expl_noise = start_timesteps, expl_noise
@@ -200,10 +209,13 @@ class GraphedVecTD3Trainer(object):
         dev = agent.device
         n = env.num_envs
         self.n = n
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.allreduce_mode = None if self.world == 1 else ("captured" if os.environ.get("PLEN_TD3_CAPTURE_ALLREDUCE") == "1" else "eager-between-graphs")
         torch.manual_seed(seed)
-        # capturable Adam (step counters on device)
-        agent.actor_optimizer = torch.optim.Adam(agent.actor.parameters(), lr=3e-4, capturable=True, fused=True)
-        agent.critic_optimizer = torch.optim.Adam(agent.critic.parameters(), lr=3e-4, capturable=True, fused=True)
+        # capturable Adam (step counters on device) that CONTINUES the agent's optimisers: same lr/betas/eps, moments and step counts
+        # carried over (a resumed run must not restart Adam)
+        agent.actor_optimizer = self._capturable_adam(agent.actor_optimizer, agent.actor)
+        agent.critic_optimizer = self._capturable_adam(agent.critic_optimizer, agent.critic)
         self.state = env.reset().to(torch.float32).clone()
         self.total_t = torch.zeros((), dtype=torch.long, device=dev)        # transitions written so far
         self.arange_n = torch.arange(n, device=dev)
@@ -211,7 +223,10 @@ class GraphedVecTD3Trainer(object):
         self.grad_steps = 0
         self.host_total = 0
         self._graphs = {}
-        self._warm_side_stream = torch.cuda.Stream(device=dev)
+        self._eager_runs = {}
+        self._side = torch.cuda.Stream(device=dev)
+        self._critic_loss = torch.zeros((), device=dev)
+        self._batch = None          # the sampled batch of the update in flight (static tensors once captured)
 
         def collect(random_actions):
             if random_actions:
@@ -231,36 +246,47 @@ class GraphedVecTD3Trainer(object):
             self.total_t += n
             self.state.copy_(info["obs"])
 
-        def update(with_policy):
+        def sample():
             size_t = torch.clamp(self.total_t, max=replay.max_size)
             ind = (torch.rand(batch_size, device=dev) * size_t).long().clamp_(max=replay.max_size - 1)
             ind = torch.minimum(ind, size_t - 1)
-            state, action, next_state = replay.state[ind], replay.action[ind], replay.next_state[ind]
-            reward, not_done = replay.reward[ind], replay.not_done[ind]
-            with torch.no_grad():
-                noise = (torch.randn_like(action) * agent.policy_noise).clamp(-agent.noise_clip, agent.noise_clip)
-                next_action = (agent.actor_target(next_state) + noise).clamp(-agent.max_action, agent.max_action)
-                q1, q2 = agent.critic_target(next_state, next_action)
-                target_q = reward + not_done * agent.discount * torch.min(q1, q2)
-            cq1, cq2 = agent.critic(state, action)
-            critic_loss = F.mse_loss(cq1, target_q) + F.mse_loss(cq2, target_q)
-            agent._critic_grads.zero()
-            critic_loss.backward()
-            agent.critic_optimizer.step()
-            self._critic_loss.copy_(critic_loss.detach())
-            if with_policy:
-                actor_loss = -agent.critic.Q1(state, agent.actor(state)).mean()
-                agent._actor_grads.zero()
-                actor_loss.backward()
-                agent.actor_optimizer.step()
-                with torch.no_grad():
-                    for net, tgt in ((agent.critic, agent.critic_target), (agent.actor, agent.actor_target)):
-                        ps, ts = list(net.parameters()), list(tgt.parameters())
-                        torch._foreach_mul_(ts, 1 - agent.tau)
-                        torch._foreach_add_(ts, ps, alpha=agent.tau)
+            return (replay.state[ind], replay.action[ind], replay.next_state[ind], replay.reward[ind], replay.not_done[ind])
 
-        self._critic_loss = torch.zeros((), device=dev)
+        def update(with_policy):                       # one rank, or collectives captured: the whole iteration in one graph
+            loss = T.td3_update(agent, sample(), with_policy, all_reduce=self.world > 1)
+            self._critic_loss.copy_(loss)
+
+        # --- segments for eager collectives between graph replays (world > 1) ---
+        def seg_critic_backward():
+            self._batch = sample()
+            self._critic_loss.copy_(T.td3_critic_backward(agent, self._batch))
+
+        def seg_critic_step(with_policy):
+            agent.critic_optimizer.step()
+            if with_policy:
+                T.td3_actor_backward(agent, self._batch)
+
+        def seg_actor_step():
+            agent.actor_optimizer.step()
+            T.td3_polyak(agent)
+
         self._collect_fn, self._update_fn = collect, update
+        self._segs = (seg_critic_backward, seg_critic_step, seg_actor_step)
+
+    @staticmethod
+    def _capturable_adam(old, module):
+        g = old.param_groups[0]
+        new = torch.optim.Adam(module.parameters(), lr=g["lr"], betas=g["betas"], eps=g["eps"], weight_decay=g["weight_decay"],
+                               capturable=True, fused=True)
+        sd = old.state_dict()
+        if sd["state"]:
+            for st in sd["state"].values():           # capturable Adam keeps `step` as a float32 tensor on the parameter's device
+                st["step"] = torch.as_tensor(float(st["step"]), dtype=torch.float32)
+            for k in ("capturable", "fused"):
+                for pg in sd["param_groups"]:
+                    pg[k] = True
+            new.load_state_dict(sd)
+        return new
 
     def restore_counters(self, c):
         """Continue a run: the ring position comes from the (loaded) replay buffer, the update cadence from the counters."""
@@ -269,37 +295,49 @@ class GraphedVecTD3Trainer(object):
         self.total_t.fill_(self.host_total)
         self.env_steps, self.grad_steps = int(c["env_steps"]), int(c["grad_steps"])
 
-    def _graph(self, key, fn, *args):
+    def _run(self, key, fn, *args):
+        """Execute `fn(*args)` once: eagerly on the side stream the first two times this key is seen (allocator / lazy-init warm-up,
+        and real work), from then on as a replay of its captured graph."""
         g = self._graphs.get(key)
-        if g is None:
-            # warm up on a side stream (allocations, lazy init), then capture
-            s = self._warm_side_stream
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                for _ in range(2):
-                    fn(*args)
-                    if key[0] == "collect":
-                        self.host_total += self.n; self.env_steps += self.n
-                    else:
-                        self.grad_steps += 1
-            torch.cuda.current_stream().wait_stream(s)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+        if g is not None:
+            g.replay()
+            return
+        cur = torch.cuda.current_stream()
+        runs = self._eager_runs.get(key, 0)
+        if runs < 2:
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
                 fn(*args)
-            self._graphs[key] = g
-            # the capture itself does not execute: no counters to advance
-            return g
-        return g
+            cur.wait_stream(self._side)
+            self._eager_runs[key] = runs + 1
+            return
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn(*args)
+        self._graphs[key] = g
+        g.replay()                                   # the capture itself does not execute
+
+    def _update(self, with_policy):
+        if self.world == 1 or self.allreduce_mode == "captured":
+            self._run(("update", with_policy), self._update_fn, with_policy)
+            return
+        a, b, c = self._segs
+        self._run(("critic_backward",), a)
+        self.agent._critic_grads.all_reduce_mean()
+        self._run(("critic_step", with_policy), b, with_policy)
+        if with_policy:
+            self.agent._actor_grads.all_reduce_mean()
+            self._run(("actor_step",), c)
 
     def step(self):
         warm = self.host_total < self.start_timesteps
-        self._graph(("collect", warm), self._collect_fn, warm).replay()
+        self._run(("collect", warm), self._collect_fn, warm)
         self.host_total += self.n
         self.env_steps += self.n
         if self.host_total >= self.start_timesteps:
             for _ in range(self.updates_per_step):
                 with_policy = (self.grad_steps + 1) % self.agent.policy_freq == 0
-                self._graph(("update", with_policy), self._update_fn, with_policy).replay()
+                self._update(with_policy)
                 self.grad_steps += 1
                 self.agent.total_it = self.grad_steps
         self.replay.size = min(self.host_total, self.replay.max_size)

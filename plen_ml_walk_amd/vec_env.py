@@ -24,6 +24,8 @@ class StepInfo(dict):
             v = (f & L.DONE_TIMELIMIT) != 0
         elif key == "terminal":          # compute_done() fired and the time limit did not: plen_td3.py:109-110 done_bool
             v = ((f & L.DONE_TERMINAL) != 0) & ((f & L.DONE_TIMELIMIT) == 0)
+        elif key == "nonfinite":         # the non-finite guard reset this env (reported as a truncation, never as a terminal)
+            v = (f & L.DONE_NONFINITE) != 0
         else:
             raise KeyError(key)
         self[key] = v
@@ -133,6 +135,12 @@ class PlenVecEnv(object):
         mu = lateral_friction.to(device=self.device, dtype=self.dtype).contiguous() if lateral_friction is not None else None
         L.check(self.lib.plenvec_set_params(self.h, _ptr(ms), _ptr(mu), self._stream()))
 
+    def nonfinite_count(self):
+        """PLENVEC_DONE_NONFINITE events since construction (host-synchronous, diagnostic)."""
+        c = C.c_int64(0)
+        L.check(self.lib.plenvec_get_nonfinite_count(self.h, C.byref(c), self._stream()))
+        return c.value
+
     def timing_begin(self):
         L.check(self.lib.plenvec_timing_begin(self.h, self._stream()))
 
@@ -217,6 +225,10 @@ class PlenVecEnvPipelined(object):
         self.sync()
         for e, s in zip(self.envs, self._slices):
             e.set_params(None if mass_scale is None else mass_scale[s], None if lateral_friction is None else lateral_friction[s])
+
+    def nonfinite_count(self):
+        self.sync()
+        return sum(e.nonfinite_count() for e in self.envs)
 
     def get_state(self):
         self.sync()

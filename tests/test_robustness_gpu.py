@@ -1,0 +1,228 @@
+"""GPU tests of the C-ABI semantics added in round 2: the per-env non-finite guard, parameter changes vs the reset cache, masked
+resets, and the TD3 update on the device (eager and hipGraph-captured) against the reference's golden vectors."""
+import os
+import numpy as np
+import pytest
+import torch
+
+from oracle.oracle import OracleEnv
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env(n, dtype=torch.float32, **kw):
+    from plen_ml_walk_amd.vec_env import PlenVecEnv
+    return PlenVecEnv(n, dtype=dtype, **kw)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("auto_reset", [True, False])
+def test_nonfinite_guard_resets_and_counts(dtype, auto_reset):
+    """A NaN / inf in an env's state must not reach the caller: that env is reset (even with auto_reset off), reported as a truncation
+    to the reset observation with reward 0 and PLENVEC_DONE_NONFINITE set, and counted; its neighbours are untouched."""
+    from plen_ml_walk_amd import _lib as L
+    n = 8
+    env = _env(n, dtype, auto_reset=auto_reset)
+    ref = _env(n, dtype, auto_reset=auto_reset)
+    obs0 = env.reset().clone(); ref.reset()
+    s = env.get_state()
+    s[2, 15] = float("nan")            # a joint angle
+    s[5, 10] = float("inf")            # base velocity
+    env.set_state(s)
+    s_ok = ref.get_state(); ref.set_state(s_ok)           # same bookkeeping reset as env.set_state, finite everywhere
+    act = torch.full((n, 18), 0.1, device="cuda")
+    o, r, d, info = env.step(act)
+    o2, r2, d2, info2 = ref.step(act)
+    bad = torch.tensor([2, 5], device="cuda")
+    good = torch.tensor([0, 1, 3, 4, 6, 7], device="cuda")
+    assert torch.isfinite(o).all() and torch.isfinite(r).all() and torch.isfinite(info["obs"]).all()
+    assert (d[bad] == (L.DONE_NONFINITE | L.DONE_TIMELIMIT)).all() and (r[bad] == 0).all()
+    assert torch.equal(o[bad], obs0[bad]) and torch.equal(info["obs"][bad], obs0[bad])
+    assert info["nonfinite"][bad].all() and not info["nonfinite"][good].any() and not info["terminal"][bad].any()
+    assert torch.equal(o[good], o2[good]) and torch.equal(r[good], r2[good]) and torch.equal(d[good], d2[good])
+    assert env.nonfinite_count() == 2 and ref.nonfinite_count() == 0
+    st = env.get_state()
+    assert torch.isfinite(st).all()
+    fresh = _env(n, dtype); fresh.reset()
+    assert torch.equal(st[bad], fresh.get_state()[bad])    # back in the reset state
+    # the next step is an ordinary first step of an episode
+    o3, r3, d3, _ = env.step(act)
+    f3, fr3, fd3, _ = fresh.step(act)
+    assert torch.equal(o3[bad], f3[bad]) and torch.equal(r3[bad], fr3[bad]) and env.nonfinite_count() == 2
+    for e in (env, ref, fresh):
+        e.close()
+
+
+def test_nonfinite_guard_can_be_switched_off():
+    """cfg.nonfinite_guard = 0 keeps the reference's behaviour: NaNs propagate (plen_env.py has no guard)."""
+    env = _env(4, torch.float32, cfg_overrides=dict(nonfinite_guard=0))
+    env.reset()
+    s = env.get_state(); s[1, 20] = float("nan"); env.set_state(s)
+    o, r, d, _ = env.step(torch.zeros(4, 18, device="cuda"))
+    assert not torch.isfinite(o[1]).all() and torch.isfinite(o[[0, 2, 3]]).all() and env.nonfinite_count() == 0
+    env.close()
+
+
+def test_set_params_reset_cache_and_masked_reset():
+    """plenvec_set_params: the dynamics use the new parameters at once; auto-resets after it restore a stance settled with the NEW
+    parameters (the reset records are re-simulated at the next step without touching live envs); a masked reset resets only its mask."""
+    n = 16
+    g = torch.Generator(device="cuda").manual_seed(0)
+    ms = 0.8 + 0.4 * torch.rand(n, generator=g, device="cuda")
+    mu = 0.4 + 0.6 * torch.rand(n, generator=g, device="cuda")
+    env = _env(n, torch.float64)
+    env.reset()
+    acts = (torch.rand(3, n, 18, generator=g, device="cuda") * 2 - 1) * 0.3
+    for t in range(3):
+        env.step(acts[t])
+    live = env.get_state().clone()
+    env.set_params(mass_scale=ms.double(), lateral_friction=mu.double())
+    # (1) masked reset right after set_params: only the masked envs move, and they get the NEW settled stance
+    mask = torch.zeros(n, dtype=torch.uint8, device="cuda"); mask[[1, 4, 9]] = 1
+    env.reset(mask)
+    st = env.get_state()
+    keep = mask == 0
+    assert torch.equal(st[keep], live[keep])
+    want = []
+    for i in (1, 4, 9):
+        o = OracleEnv(); o.set_params(float(ms[i]), float(mu[i])); o.reset(); want.append(o.get_state())
+    assert np.abs(st[[1, 4, 9]].cpu().numpy() - np.array(want)).max() <= 1e-9
+    # (2) set_params followed directly by step(): envs that end their episode inside that step are restored from records built with the new parameters
+    env2 = _env(n, torch.float64); env2.reset()
+    s = env2.get_state(); s[:, 2] = 0.3                               # in the air, rolled by 1.2 rad > pi/3: every env terminates at once
+    s[:, 3] = float(np.sin(0.6)); s[:, 4] = 0; s[:, 5] = 0; s[:, 6] = float(np.cos(0.6)); env2.set_state(s)
+    env2.set_params(mass_scale=ms.double(), lateral_friction=mu.double())
+    o, r, d, info = env2.step(torch.zeros(n, 18, device="cuda"))
+    assert (d & 1).bool().all()
+    st2 = env2.get_state().cpu().numpy()
+    for i in (0, 7, 15):
+        o_ = OracleEnv(); o_.set_params(float(ms[i]), float(mu[i])); ob = o_.reset()
+        assert np.abs(st2[i] - o_.get_state()).max() <= 1e-9 and np.abs(info["obs"][i].cpu().numpy() - ob).max() <= 1e-9
+    env.close(); env2.close()
+
+
+# ------------------------------------------------------------------------------------------------ TD3 on the device
+def _golden_agent(golden_dir, device):
+    from plen_ml_walk_amd import td3 as T
+    g = np.load(os.path.join(golden_dir, "td3_train.npz"))
+    a = T.TD3Agent(26, 18, 1.0, device=device, data_parallel=False)
+    a.load_arrays({k[len("init."):]: g[k] for k in g.files if k.startswith("init.")})
+    a.actor_target.load_state_dict(a.actor.state_dict()); a.critic_target.load_state_dict(a.critic.state_dict())
+    buf = T.ReplayBuffer(1000, device=device)
+    buf.add_batch(torch.as_tensor(g["S"]), torch.as_tensor(g["A"]), torch.as_tensor(g["S2"]), torch.as_tensor(g["R"]), torch.as_tensor(g["D"]))
+    return g, a, buf
+
+
+def _check_against_golden(g, a, k, tol=2e-5):
+    for net, prefix in ((a.actor, "actor."), (a.critic, "critic."), (a.actor_target, "actor_target."), (a.critic_target, "critic_target.")):
+        for name, v in net.state_dict().items():
+            ref_sum = g["it%d.sum.%s%s" % (k + 1, prefix, name)]
+            got = v.detach().cpu().numpy().astype(np.float64)
+            assert abs(got.sum() - ref_sum[0]) <= tol * max(1.0, ref_sum[1]), (k, prefix + name)
+            key = "it%d.%s%s" % (k + 1, prefix, name)
+            if key in g.files:
+                assert np.abs(v.detach().cpu().numpy() - g[key]).max() <= tol, key
+
+
+def test_td3_two_iterations_on_gpu_eager(golden_dir, monkeypatch):
+    """TD3Agent.train x2 ON THE GPU from the reference's initial parameters with the reference's sampled indices and smoothing noise:
+    parameters and targets afterwards match the reference's (td3.py:259-356) to 2e-5."""
+    g, a, buf = _golden_agent(golden_dir, "cuda")
+    noise = [torch.as_tensor(n).cuda() for n in g["noise"]]
+    real_sample = buf.sample
+    for k in range(2):
+        monkeypatch.setattr(torch, "randn_like", lambda x, *a_, _k=k, **k_: noise[_k])
+        monkeypatch.setattr(buf, "sample", lambda bs, _k=k: real_sample(bs, ind=g["idx"][_k]))
+        a.train(buf, int(g["batch"]))
+        _check_against_golden(g, a, k)
+    assert a.total_it == 2
+
+
+def test_td3_two_iterations_on_gpu_in_hip_graphs(golden_dir):
+    """The same two iterations through what GraphedVecTD3Trainer captures: td3.td3_update inside a hipGraph with the capturable fused
+    Adam the trainer installs (critic-only graph for iteration 1, critic+actor+targets graph for iteration 2), batch and noise fed through
+    static tensors.  Same golden vectors, same tolerance."""
+    from plen_ml_walk_amd import td3 as T
+    from plen_ml_walk_amd.train_vec import GraphedVecTD3Trainer
+    g, a, buf = _golden_agent(golden_dir, "cuda")
+    a.actor_optimizer = GraphedVecTD3Trainer._capturable_adam(a.actor_optimizer, a.actor)
+    a.critic_optimizer = GraphedVecTD3Trainer._capturable_adam(a.critic_optimizer, a.critic)
+    B = int(g["batch"])
+    idx = torch.zeros(B, dtype=torch.long, device="cuda")
+    nz = torch.zeros(B, 18, device="cuda")
+    loss = torch.zeros((), device="cuda")
+
+    def it(with_policy):
+        loss.copy_(T.td3_update(a, buf.sample(B, ind=idx), with_policy, noise=nz, all_reduce=False))
+
+    # snapshot: warm-up runs (allocator, lazy init) must not count as iterations
+    snap = [p.detach().clone() for net in (a.actor, a.critic, a.actor_target, a.critic_target) for p in net.parameters()]
+    osnap = [a.actor_optimizer.state_dict(), a.critic_optimizer.state_dict()]
+    import copy
+    osnap = copy.deepcopy(osnap)
+    graphs = {}
+    side = torch.cuda.Stream()
+    for wp in (False, True):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            it(wp)
+        torch.cuda.current_stream().wait_stream(side)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            it(wp)
+        graphs[wp] = gr
+    with torch.no_grad():
+        i = 0
+        for net in (a.actor, a.critic, a.actor_target, a.critic_target):
+            for p in net.parameters():
+                p.copy_(snap[i]); i += 1
+    # Adam state after the warm-ups: back to "never stepped" (in place: the graphs hold these tensors)
+    for opt in (a.actor_optimizer, a.critic_optimizer):
+        for st in opt.state.values():
+            st["step"].zero_(); st["exp_avg"].zero_(); st["exp_avg_sq"].zero_()
+    for k in range(2):
+        idx.copy_(torch.as_tensor(g["idx"][k]).cuda()); nz.copy_(torch.as_tensor(g["noise"][k]).cuda())
+        graphs[(k + 1) % 2 == 0].replay()
+        torch.cuda.synchronize()
+        _check_against_golden(g, a, k)
+    assert torch.isfinite(loss)
+
+
+def test_graphed_trainer_cadence_and_resumed_optimizer_state(tmp_path):
+    """(a) The graph trainer's warm-up runs are the loop's real iterations: after k steps it has done exactly k collects and the same
+    number of updates, with the same policy_freq alternation, as the eager trainer.  (b) Building it on a resumed agent keeps Adam's
+    moments, step counts and learning rate (they used to be replaced by fresh optimisers)."""
+    from plen_ml_walk_amd.td3 import ReplayBuffer, TD3Agent
+    from plen_ml_walk_amd.train_vec import GraphedVecTD3Trainer, VecTD3Trainer
+    n = 64
+    env = _env(n); agent = TD3Agent(26, 18, 1.0, lr=1e-4); replay = ReplayBuffer(4000)
+    tr = VecTD3Trainer(env, agent, replay, start_timesteps=128, batch_size=64, updates_per_step=1, seed=0)
+    for _ in range(7):
+        tr.step()
+    assert tr.grad_steps == 6 and agent.total_it == 6
+    before = {k: {kk: vv.clone() if torch.is_tensor(vv) else vv for kk, vv in st.items()} for k, st in agent.critic_optimizer.state_dict()["state"].items()}
+    a_before = {k: {kk: vv.clone() if torch.is_tensor(vv) else vv for kk, vv in st.items()} for k, st in agent.actor_optimizer.state_dict()["state"].items()}
+    env.close()
+    env2 = _env(n)
+    tr2 = GraphedVecTD3Trainer(env2, agent, replay, start_timesteps=128, batch_size=64, updates_per_step=1, seed=1)
+    tr2.restore_counters({"env_steps": tr.env_steps, "grad_steps": tr.grad_steps})
+    for opt, ref in ((agent.critic_optimizer, before), (agent.actor_optimizer, a_before)):
+        assert opt.param_groups[0]["lr"] == 1e-4 and opt.param_groups[0]["capturable"]
+        sd = opt.state_dict()["state"]
+        assert len(sd) == len(ref) > 0
+        for k in ref:
+            assert torch.equal(sd[k]["exp_avg"], ref[k]["exp_avg"]) and torch.equal(sd[k]["exp_avg_sq"], ref[k]["exp_avg_sq"])
+            assert float(sd[k]["step"]) == float(ref[k]["step"]) and sd[k]["step"].is_cuda
+    assert float(next(iter(agent.critic_optimizer.state_dict()["state"].values()))["step"]) == 6.0
+    assert float(next(iter(agent.actor_optimizer.state_dict()["state"].values()))["step"]) == 3.0
+    for k in range(9):
+        tr2.step()
+        assert tr2.env_steps == tr.env_steps + (k + 1) * n and tr2.grad_steps == tr.grad_steps + k + 1
+    torch.cuda.synchronize()
+    assert int(tr2.total_t) == tr2.host_total == replay.size == 16 * n
+    # 9 more critic steps, and actor steps on the even iterations 8, 10, 12, 14 only
+    assert float(next(iter(agent.critic_optimizer.state_dict()["state"].values()))["step"]) == 15.0
+    assert float(next(iter(agent.actor_optimizer.state_dict()["state"].values()))["step"]) == 7.0
+    assert torch.isfinite(agent.last_critic_loss)
+    env2.close()
