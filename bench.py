@@ -61,21 +61,22 @@ def _pmc_summary(dtype):
 # ------------------------------------------------------------------------------------------------ CPU baseline (rank 0, N = 1)
 def cpu_baseline(budget_s=12.0):
     """The C oracle ("port" of the reference algorithm, f64) built on THIS machine with gcc -O3 -march=native -fopenmp and timed on the host
-    cores this process may use: (a) one thread stepping one env, (b) every core, 4096 envs partitioned across the threads -- each a bounded
-    sample (whole control steps until the time budget is spent)."""
-    from oracle import oracle
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    lib = oracle.native_lib()
-    one = oracle.native_throughput(lib, n_envs=1, threads=1, budget_s=min(3.0, budget_s / 4))
-    many = oracle.native_throughput(lib, n_envs=ENVS_PER_GPU, threads=cores, budget_s=budget_s)
-    return {"value": many["env_steps_per_s"], "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "C oracle f64 (gcc -O3 -march=native -fopenmp, built on this host): %d envs partitioned over %d threads, random actions, "
-                      "auto-reset, %d vector steps = %d env-steps in %.1f s; one thread alone on one env: %.0f env-steps/s (%d env-steps in %.1f s)"
-                      % (ENVS_PER_GPU, cores, many["vector_steps"], many["env_steps"], many["seconds"], one["env_steps_per_s"], one["env_steps"], one["seconds"]),
-            "one_thread": one["env_steps_per_s"]}
+    cores this process may use, in a child process (own OpenMP runtime): (a) one thread stepping one env, (b) 4096 envs partitioned across T
+    threads, T taken from a short sweep up to every visible core (the boxes expose more hardware threads than their CPU quota sustains) --
+    each a bounded sample (whole vector steps until the time budget is spent)."""
+    env = dict(os.environ, OMP_WAIT_POLICY="PASSIVE", OMP_PROC_BIND="false")
+    out = subprocess.run([sys.executable, "-m", "oracle.oracle", "baseline", str(budget_s)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    if out.returncode != 0:
+        raise RuntimeError("oracle baseline failed: " + out.stderr[-500:])
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    one, many = r["one"], r["many"]
+    return {"value": many["env_steps_per_s"], "unit": "env-steps/s", "cores": r["threads"], "kind": "port",
+            "sample": "C oracle f64 (gcc -O3 -march=native -fopenmp, built on this host): %d envs partitioned over %d threads (fastest of the sweep %s env-steps/s "
+                      "per thread count; %d hardware threads visible), random actions, auto-reset, %d vector steps = %d env-steps in %.1f s; one thread alone "
+                      "on one env: %.0f env-steps/s (%d env-steps in %.1f s)"
+                      % (ENVS_PER_GPU, r["threads"], json.dumps({k: round(v) for k, v in r["sweep"].items()}), r["cores_visible"], many["vector_steps"],
+                         many["env_steps"], many["seconds"], one["env_steps_per_s"], one["env_steps"], one["seconds"]),
+            "one_thread": one["env_steps_per_s"], "cores_visible": r["cores_visible"]}
 
 
 def pybullet_status():

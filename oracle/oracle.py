@@ -40,6 +40,8 @@ def _lib(dtype="f64"):
         lib.oracle_set_targets.argtypes = [C.c_void_p, dp]
         lib.oracle_substep.argtypes = [C.c_void_p]
         lib.oracle_contacts.argtypes = [C.c_void_p, ip]
+        lib.oracle_contact_slots.argtypes = [C.c_void_p, C.c_int, ip, dp]
+        lib.oracle_set_body_contacts.argtypes = [C.c_void_p, C.c_int]
         lib.oracle_forward_dynamics.argtypes = [C.c_void_p, dp]
         lib.oracle_minv_times.argtypes = [C.c_void_p, dp, dp]
         lib.oracle_link_frames.argtypes = [C.c_void_p, dp, dp, dp]
@@ -175,6 +177,16 @@ class OracleEnv(object):
         self.lib.oracle_contacts(self.h, a)
         return dict(right=a[0], left=a[1], ncp=a[2], iterations=a[3])
 
+    def contact_slots(self, run_collide=False):
+        """The 8 contact-point slots of the last collision pass: owner (-2 empty, -1 foot point, >= 0 box index) and point positions."""
+        box = (C.c_int * 8)(); pos = np.zeros(24)
+        self.lib.oracle_contact_slots(self.h, int(run_collide), box, _dp(pos))
+        return np.array(list(box)), pos.reshape(8, 3)
+
+    def set_body_contacts(self, on=True):
+        """False: only the feet collide with the ground (the round-1 contact model)."""
+        self.lib.oracle_set_body_contacts(self.h, int(bool(on)))
+
     def forward_dynamics(self):
         qdd = np.zeros(24)
         self.lib.oracle_forward_dynamics(self.h, _dp(qdd))
@@ -205,3 +217,32 @@ class OracleEnv(object):
 
 def agent_to_env(joint, a, dtype="f64"):
     return _lib(dtype).oracle_agent_to_env(int(joint), float(a))
+
+
+def cpu_baseline_main(budget_s=12.0, n_envs=4096):
+    """`python -m oracle.oracle baseline [budget_s]`: the CPU-baseline measurement of bench.py, run in its own process (own OpenMP runtime,
+    passive waiting).  (a) one thread, one env; (b) n_envs envs partitioned over T threads for T in a short sweep up to the cores this process
+    may use -- GPU boxes expose many more hardware threads than their CPU quota sustains, so the fastest T is kept and reported."""
+    import json
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    lib = native_lib()
+    one = native_throughput(lib, 1, 1, min(3.0, budget_s / 4))
+    sweep, t = [], 4
+    while t < cores:
+        sweep.append(t); t *= 2
+    sweep.append(cores)
+    probe = {}
+    for t in sweep:
+        probe[t] = native_throughput(lib, n_envs, t, 1.5)["env_steps_per_s"]
+    best = max(probe, key=probe.get)
+    many = native_throughput(lib, n_envs, best, budget_s)
+    print(json.dumps({"one": one, "many": many, "threads": best, "cores_visible": cores, "sweep": {str(k): v for k, v in probe.items()}}))
+
+
+if __name__ == "__main__":
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "baseline":
+        cpu_baseline_main(float(sys.argv[2]) if len(sys.argv) > 2 else 12.0)

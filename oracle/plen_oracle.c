@@ -29,8 +29,14 @@
  * with a persistent 4-point manifold whose point positions depend on solver history; that is not
  * reproducible without Bullet itself.  Here each foot has 4 fixed candidate points (corner-most
  * sole-hull vertices, 1 mm spherical margin) tested against the half-space z<=0; a candidate is a
- * manifold point while its distance is below the foot's contact-breaking threshold.  Only the two
- * feet collide with the ground (self-collision is off in the reference).
+ * manifold point while its distance is below the foot's contact-breaking threshold.
+ * The 31 box colliders of the other links (plen.urdf:504-1274) collide with the ground too (Bullet:
+ * btBoxBoxDetector against plane.urdf's box -> the penetrating corners of the face turned to the
+ * ground): a box corner is a contact point while its height is below the link's breaking threshold.
+ * The solver has 8 contact-point slots (the HIP kernel's port layout): a foot point always sits in
+ * its home slot; box corners, deepest first, take the slots whose foot point is inactive; corners
+ * beyond that are dropped (both feet flat AND other links on the ground: see DESIGN.md).
+ * Self-collision is off in the reference.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  *
@@ -51,7 +57,8 @@ typedef ORACLE_REAL real;
 #define NL RAW_NLINKS          /* 32 non-base links                               */
 #define ND RAW_NDOF            /* 18 joint DoF                                    */
 #define NV (6 + ND)            /* generalized velocity: base omega(3), v(3), qd   */
-#define MAXCP 8                /* 2 feet x 4 candidate points                     */
+#define MAXCP 8                /* contact-point slots: 2 feet x 4 home points; a slot whose foot point is inactive may be lent to a box corner */
+#define MAXNEAR 8              /* at most this many near boxes (box index order) are enumerated per collision pass */
 #define MAXROWS (36 + MAXCP * 6)
 #define HIST 1024
 
@@ -190,6 +197,8 @@ typedef struct {
     real restitution_velocity_threshold; /* 0.2 */
     real max_coordinate_velocity;        /* btMultiBody m_maxCoordinateVelocity 100 */
     real lateral_friction;   /* foot 0.8 x plane 0.8 (plen_env.py:309,444) */
+    real box_lateral_friction; /* other links: Bullet's URDF default 0.5 x plane 0.8 */
+    int body_contacts;       /* 1: the box colliders of the non-foot links collide with the ground (reference behaviour); 0: feet only */
     real spinning_friction;  /* foot 0.1 x plane lateral 0.8 */
     real rolling_friction;   /* foot 0.1 (0.01 joint_act) x 0.8 (plen_env.py:439-442) */
     real restitution;        /* 0.5 x 0.5 (plen_env.py:309,481) */
@@ -214,6 +223,8 @@ typedef struct {
     real IA[NL + 1][36], U[NL + 1][6], Dinv[NL + 1], S[NL + 1][6];
     /* ---- contact state of the last collision pass ---- */
     int ncp; int cp_foot[MAXCP]; real cp_pos[MAXCP][3]; real cp_dist[MAXCP];
+    int cp_slot[MAXCP], cp_link[MAXCP], cp_box[MAXCP];      /* slot of contact c; link it is on; box index or -1 for a foot point */
+    real cp_mu[MAXCP], cp_rest[MAXCP];                      /* combined lateral friction and restitution of contact c */
     int reward_head;                 /* 0: PlenWalkEnv-v1 (plen_env.py), 1: PlenWalkEnv-v0 contract (plen_walk.py:346-396, 597-650) */
     real foot_force[2][3];           /* contact force on each foot over the last substep (impulses / dt), right then left */
     int right_contact, left_contact;
@@ -238,6 +249,7 @@ static void world_defaults(World *w, int joint_act) {
     w->linear_slop = (real)0.00001; w->residual_threshold = (real)1e-7;
     w->restitution_velocity_threshold = (real)0.2; w->max_coordinate_velocity = 100;
     w->lateral_friction = (real)(0.8 * 0.8);
+    w->box_lateral_friction = (real)(0.5 * 0.8); w->body_contacts = 1;
     w->spinning_friction = (real)(0.1 * 0.8);
     w->rolling_friction = (real)((joint_act ? 0.01 : 0.1) * 0.8);
     w->restitution = (real)(0.5 * 0.5);
@@ -466,9 +478,15 @@ static real resolve_cone(Row *cA, Row *cB, real *dv) {
     return dA / cA->jac_diag_inv + dB / cB->jac_diag_inv;
 }
 
-/* ---------------------------------------------------------------- collision: feet vs ground */
+/* ---------------------------------------------------------------- collision: feet and link boxes vs ground */
+typedef struct { real dist; int id, box, link; real pos[3]; } BoxCand;
+static int cand_less(const BoxCand *a, const BoxCand *b) { return a->dist < b->dist || (a->dist == b->dist && a->id < b->id); }
+
 static void collide(Oracle *o) {
     o->ncp = 0; o->right_contact = 0; o->left_contact = 0;
+    int slot_used[MAXCP] = {0};
+    struct { int used, foot, link, box; real pos[3], dist, mu, rest; } slot[MAXCP];
+    memset(slot, 0, sizeof slot);
     for (int f = 0; f < 2; f++) {
         int link = f == 0 ? RAW_RFOOT_LINK : RAW_LFOOT_LINK, b = link + 1;
         real thr = (real)(f == 0 ? RAW_RFOOT_BREAK : RAW_LFOOT_BREAK);
@@ -478,12 +496,56 @@ static void collide(Oracle *o) {
             m3mulv(wpt, o->Rw[b], l); v3add(wpt, wpt, o->Ow[b]);
             real dist = wpt[2] - (real)RAW_MARGIN;
             if (dist <= thr) {
-                int c = o->ncp++;
-                o->cp_foot[c] = f; o->cp_dist[c] = dist;
-                v3set(o->cp_pos[c], wpt[0], wpt[1], dist);   /* position on the robot (sphere-swept vertex) */
+                int c = 4 * f + k;
+                slot[c].used = 1; slot[c].foot = f; slot[c].link = link; slot[c].box = -1; slot[c].dist = dist;
+                v3set(slot[c].pos, wpt[0], wpt[1], dist);   /* position on the robot (sphere-swept vertex) */
+                slot[c].mu = o->w.lateral_friction; slot[c].rest = o->w.restitution;
+                slot_used[c] = 1;
                 if (f == 0) o->right_contact = 1; else o->left_contact = 1;
             }
         }
+    }
+    if (o->w.body_contacts) {
+        /* near boxes in box order (lowest point of the box within its breaking threshold), then their corners */
+        BoxCand cand[MAXNEAR * 8]; int ncand = 0, nnear = 0;
+        for (int x = 0; x < RAW_NBOX && nnear < MAXNEAR; x++) {
+            int b = RAW_BOX_LINK[x] + 1;
+            const real *Rw = o->Rw[b];
+            real Rb[9], t[3], h[3], c[3], ax[9];
+            for (int i = 0; i < 9; i++) Rb[i] = (real)RAW_BOX_R[x][i];
+            for (int i = 0; i < 3; i++) { t[i] = (real)RAW_BOX_T[x][i]; h[i] = (real)RAW_BOX_H[x][i]; }
+            m3mulv(c, Rw, t); v3add(c, c, o->Ow[b]);
+            m3mul(ax, Rw, Rb);                         /* columns = box axes in world */
+            real zmin = c[2] - (h[0] * (real)fabs((double)ax[6]) + h[1] * (real)fabs((double)ax[7]) + h[2] * (real)fabs((double)ax[8]));
+            real thr = (real)RAW_BOX_BREAK[x];
+            if (!(zmin <= thr)) continue;
+            int r = nnear++;
+            for (int cn = 0; cn < 8; cn++) {
+                real sg[3] = {(cn & 1) ? h[0] : -h[0], (cn & 2) ? h[1] : -h[1], (cn & 4) ? h[2] : -h[2]}, w[3];
+                m3mulv(w, ax, sg); v3add(w, w, c);
+                if (w[2] <= thr) {
+                    BoxCand *q = &cand[ncand++];
+                    q->dist = w[2]; q->id = 8 * r + cn; q->box = x; q->link = RAW_BOX_LINK[x]; v3cpy(q->pos, w);
+                }
+            }
+        }
+        /* deepest first (ties: candidate id) into the free slots in slot order */
+        for (int i = 1; i < ncand; i++) { BoxCand k = cand[i]; int j = i - 1; while (j >= 0 && cand_less(&k, &cand[j])) { cand[j + 1] = cand[j]; j--; } cand[j + 1] = k; }
+        int next = 0;
+        for (int c = 0; c < MAXCP && next < ncand; c++) {
+            if (slot_used[c]) continue;
+            const BoxCand *q = &cand[next++];
+            slot[c].used = 1; slot[c].foot = -1; slot[c].link = q->link; slot[c].box = q->box; slot[c].dist = q->dist;
+            v3cpy(slot[c].pos, q->pos);
+            slot[c].mu = o->w.box_lateral_friction;
+            slot[c].rest = (real)RAW_BOX_LINK_RESTITUTION[q->box] * (real)0.5;      /* x plane restitution 0.5 (plen_env.py:309) */
+        }
+    }
+    for (int c = 0; c < MAXCP; c++) {
+        if (!slot[c].used) continue;
+        int n = o->ncp++;
+        o->cp_slot[n] = c; o->cp_foot[n] = slot[c].foot; o->cp_link[n] = slot[c].link; o->cp_box[n] = slot[c].box;
+        o->cp_dist[n] = slot[c].dist; v3cpy(o->cp_pos[n], slot[c].pos); o->cp_mu[n] = slot[c].mu; o->cp_rest[n] = slot[c].rest;
     }
 }
 
@@ -542,28 +604,28 @@ static void substep(Oracle *o) {
     const real nrmW[3] = {0, 0, 1};
     const real dir1[3] = {0, -1, 0}, dir2[3] = {1, 0, 0};          /* btPlaneSpace1((0,0,1)) */
     for (int c = 0; c < o->ncp; c++) {
-        int link = o->cp_foot[c] == 0 ? RAW_RFOOT_LINK : RAW_LFOOT_LINK;
+        const int link = o->cp_link[c], is_foot = o->cp_foot[c] >= 0;
         const real *P = o->cp_pos[c];
         Row *r = &nrm[n_n];
         fill_jacobian(o, link, P, Z3, nrmW, r->jac);
         real cfm = w->global_cfm / dt;
         real rel = row_finish(o, r, cfm);
         real distance = o->cp_dist[c] + w->linear_slop;
-        real rest = restitution_curve(rel, w->restitution, w->restitution_velocity_threshold);
+        real rest = restitution_curve(rel, o->cp_rest[c], w->restitution_velocity_threshold);
         if (rest <= 0) rest = 0;
         real pos_err = 0, vel_err = rest - rel;
         if (distance > 0) vel_err -= distance / dt; else pos_err = -distance * w->erp2 / dt;
         r->rhs = pos_err * r->jac_diag_inv + vel_err * r->jac_diag_inv;
-        r->cfm = cfm * r->jac_diag_inv; r->lo = 0; r->hi = (real)1e10; r->friction = w->lateral_friction;
+        r->cfm = cfm * r->jac_diag_inv; r->lo = 0; r->hi = (real)1e10; r->friction = o->cp_mu[c];
         r->friction_index = n_n;
-        if (w->spinning_friction > 0) {
+        if (is_foot && w->spinning_friction > 0) {      /* spinning / rolling friction is set on the two foot links only (plen_env.py:439-467) */
             Row *t = &spin[n_spin++];
             fill_jacobian(o, link, P, nrmW, Z3, t->jac);
             real rv = row_finish(o, t, 0);
             t->rhs = (0 - rv) * t->jac_diag_inv; t->cfm = 0; t->friction = w->spinning_friction; t->friction_index = n_n;
             t->lo = -t->friction; t->hi = t->friction;
         }
-        if (w->rolling_friction > 0) {
+        if (is_foot && w->rolling_friction > 0) {
             for (int a = 0; a < 2; a++) {
                 Row *t = &roll[n_roll++];
                 fill_jacobian(o, link, P, a == 0 ? dir1 : dir2, Z3, t->jac);
@@ -576,7 +638,7 @@ static void substep(Oracle *o) {
             Row *t = &fric[n_fric++];
             fill_jacobian(o, link, P, Z3, a == 0 ? dir1 : dir2, t->jac);
             real rv = row_finish(o, t, 0);         /* frictionCFM = 0; friction positional error = 0 */
-            t->rhs = (0 - rv) * t->jac_diag_inv; t->cfm = 0; t->friction = w->lateral_friction; t->friction_index = n_n;
+            t->rhs = (0 - rv) * t->jac_diag_inv; t->cfm = 0; t->friction = o->cp_mu[c]; t->friction_index = n_n;
             t->lo = -t->friction; t->hi = t->friction;
         }
         n_n++;
@@ -614,6 +676,7 @@ static void substep(Oracle *o) {
     /* contact force per foot (what a Gazebo bumper reports): normal + lateral impulses of its points / dt */
     memset(o->foot_force, 0, sizeof o->foot_force);
     for (int c = 0; c < o->ncp; c++) {
+        if (o->cp_foot[c] < 0) continue;
         real *F = o->foot_force[o->cp_foot[c]];
         v3axpy(F, nrm[c].applied / dt, nrmW); v3axpy(F, fric[2 * c].applied / dt, dir1); v3axpy(F, fric[2 * c + 1].applied / dt, dir2);
     }
@@ -834,6 +897,13 @@ API void oracle_get_aux(const Oracle *o, int *a) {
 API void oracle_set_targets(Oracle *o, const double *t) { for (int d = 0; d < ND; d++) o->target[d] = (real)t[d]; }
 API void oracle_substep(Oracle *o) { substep(o); }
 API void oracle_contacts(const Oracle *o, int *flags) { flags[0] = o->right_contact; flags[1] = o->left_contact; flags[2] = o->ncp; flags[3] = o->last_iterations; }
+/* contact slots of the last collision pass: box[8] = -2 empty, -1 foot point, else box index; pos[8][3]; also runs a collision pass on demand */
+API void oracle_contact_slots(Oracle *o, int run_collide, int *box8, double *pos24) {
+    if (run_collide) { fk(o); collide(o); }
+    for (int c = 0; c < MAXCP; c++) { box8[c] = -2; for (int k = 0; k < 3; k++) pos24[3 * c + k] = 0; }
+    for (int n = 0; n < o->ncp; n++) { int c = o->cp_slot[n]; box8[c] = o->cp_box[n]; for (int k = 0; k < 3; k++) pos24[3 * c + k] = o->cp_pos[n][k]; }
+}
+API void oracle_set_body_contacts(Oracle *o, int on) { o->w.body_contacts = on; }
 
 /* low-level hooks for cross-checks in tests */
 API void oracle_forward_dynamics(Oracle *o, double *qdd) {   /* accelerations at the current state, no constraints */
@@ -945,6 +1015,9 @@ static double wall_now(void) {
 API long long oracle_throughput(int n_envs, int threads, double budget_s, unsigned seed, double *seconds_out, int *vector_steps_out) {
     Oracle **envs = (Oracle **)calloc((size_t)n_envs, sizeof(Oracle *));
     uint64_t *rng = (uint64_t *)calloc((size_t)n_envs, sizeof(uint64_t));
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads)
+#endif
     for (int e = 0; e < n_envs; e++) { envs[e] = oracle_create(0); oracle_reset(envs[e], NULL); rng[e] = 0x9E3779B97F4A7C15ull * (uint64_t)(seed + 1 + e) | 1ull; }
     int vsteps = 0;
     (void)threads;

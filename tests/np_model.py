@@ -73,6 +73,8 @@ FOOT_BODY = [6, 12]   # right, left (DoF order: right leg 1..6, left leg 7..12)
 FOOT_POINTS = [np.array(MODEL["feet"][0]["points"]), np.array(MODEL["feet"][1]["points"])]
 FOOT_BREAK = [MODEL["feet"][0]["break_threshold"], MODEL["feet"][1]["break_threshold"]]
 MARGIN = MODEL["margin"]
+BOXES = MODEL["boxes"]          # box colliders of the non-foot links, pose in their composite body's frame
+MAXNEAR = 8
 
 
 def ancestors(b):
@@ -175,11 +177,36 @@ def mass_matrix_and_bias(pos, quat, omega, vel, q, qd, lin_damp=0.0):
     return M, tau, kin
 
 
-def port_jacobians(kin, pos):
+def box_candidates(kin):
+    """Corners of the near boxes (at most MAXNEAR, box order) within their link's breaking threshold: (dist, id, box, body, P), deepest first."""
+    R, O = kin["R"], kin["O"]
+    out, near = [], 0
+    for x in BOXES:
+        if near >= MAXNEAR:
+            break
+        b = x["body"]
+        ax = R[b] @ np.array(x["R_body"])              # columns: box axes in world
+        c = O[b] + R[b] @ np.array(x["t_body"])
+        h = np.array(x["half"])
+        zmin = c[2] - (h[0] * abs(ax[2, 0]) + h[1] * abs(ax[2, 1]) + h[2] * abs(ax[2, 2]))
+        if not zmin <= x["break_threshold"]:
+            continue
+        r = near; near += 1
+        for cn in range(8):
+            sg = np.array([h[0] if cn & 1 else -h[0], h[1] if cn & 2 else -h[1], h[2] if cn & 4 else -h[2]])
+            w = c + ax @ sg
+            if w[2] <= x["break_threshold"]:
+                out.append((w[2], 8 * r + cn, x["box"], b, w))
+    out.sort(key=lambda t: (t[0], t[1]))
+    return out
+
+
+def port_jacobians(kin, pos, body_contacts=True):
     """48 x 24 port Jacobian + bookkeeping.  Port layout:
        0..17   joint d
        18+15f + {0,1,2}            foot f torsional about (n, dir1, dir2)
-       18+15f + 3 + 3k + {0,1,2}   foot f point k linear along (n, dir1, dir2)"""
+       18+15f + 3 + 3k + {0,1,2}   contact slot 4f+k linear along (n, dir1, dir2): foot f's point k while that is in range, else lent to
+                                   a box corner of another link (deepest first), else unused"""
     R, O, A = kin["R"], kin["O"], kin["A"]
     O0 = O[0]
     J = np.zeros((NPORT, NV))
@@ -205,7 +232,24 @@ def port_jacobians(kin, pos):
                 J[row, 3:6] = ax
                 for b in anc:
                     J[row, 5 + b] = A[b] @ np.cross(P - O[b], ax)
-    return J, pts, dist
+    # slots whose foot point is out of range are lent to box corners, deepest first
+    slots = [dict(kind="foot", f=c // 4, k=c % 4) if dist[c // 4, c % 4] <= FOOT_BREAK[c // 4] else None for c in range(8)]
+    if body_contacts:
+        cands = box_candidates(kin)
+        for c in range(8):
+            if slots[c] is None and cands:
+                d_, _, box, b, P = cands.pop(0)
+                slots[c] = dict(kind="box", box=box, body=b, P=P, dist=d_)
+                f, k = c // 4, c % 4
+                pts[f, k] = P; dist[f, k] = d_
+                for a_i, ax in enumerate((N_W, DIR1, DIR2)):
+                    row = 18 + 15 * f + 3 + 3 * k + a_i
+                    J[row, :] = 0
+                    J[row, 0:3] = np.cross(P - O0, ax)
+                    J[row, 3:6] = ax
+                    for bb in ancestors(b):
+                        J[row, 5 + bb] = A[bb] @ np.cross(P - O[bb], ax)
+    return J, pts, dist, slots
 
 
 class World(object):
@@ -214,6 +258,7 @@ class World(object):
         self.erp = 0.2; self.erp2 = 0.08
         self.linear_slop = 1e-5; self.residual_threshold = 1e-7
         self.restitution_velocity_threshold = 0.2; self.max_coordinate_velocity = 100.0
+        self.box_lateral_friction = 0.5 * 0.8; self.body_contacts = True
         self.lateral_friction = 0.8 * 0.8; self.spinning_friction = 0.1 * 0.8
         self.rolling_friction = (0.01 if joint_act else 0.1) * 0.8
         self.restitution = 0.25
@@ -236,7 +281,7 @@ def substep(state, target, w=None, info=None):
     v = np.concatenate([omega, vel, qd])
     acc = np.linalg.solve(L, np.linalg.solve(L.T, tau))
     v = np.clip(v + DT * acc, -w.max_coordinate_velocity, w.max_coordinate_velocity)
-    J, pts, dist = port_jacobians(kin, pos)
+    J, pts, dist, slots = port_jacobians(kin, pos, w.body_contacts)
     Y = np.linalg.solve(L.T, J.T)          # 24 x 48,  A = J M^-1 J^T = Y^T Y
     A = Y.T @ Y                            # port Delassus
     b = J @ v                              # port relative velocities
@@ -245,7 +290,7 @@ def substep(state, target, w=None, info=None):
     # ---- rows ----
     lam = {}    # row id -> applied impulse
     r = np.zeros(NPORT)                    # J * deltaV per port
-    active = [(f, k) for f in range(2) for k in range(4) if dist[f, k] <= FOOT_BREAK[f]]
+    active = [(c // 4, c % 4) for c in range(8) if slots[c] is not None]
     # non-contact rows in solver order
     nc_rows = []
     for kind, d in NC_ORDER:
@@ -260,11 +305,15 @@ def substep(state, target, w=None, info=None):
                 nc_rows.append(dict(port=d, sign=sign, rhs=(pos_err - sign * b[d]) * jdi[d], lo=0.0, hi=100.0, lam=0.0))
     nrm, spin, roll, fric = [], [], [], []
     for (f, k) in active:
+        sl = slots[4 * f + k]
+        is_foot = sl["kind"] == "foot"
+        mu_lat = w.lateral_friction if is_foot else w.box_lateral_friction
+        restitution = w.restitution if is_foot else BOXES[sl["box"]]["link_restitution"] * 0.5
         base = 18 + 15 * f
         pn = base + 3 + 3 * k
         rel = b[pn]
         distance = dist[f, k] + w.linear_slop
-        rest = 0.0 if abs(rel) < w.restitution_velocity_threshold else w.restitution * -rel
+        rest = 0.0 if abs(rel) < w.restitution_velocity_threshold else restitution * -rel
         rest = max(rest, 0.0)
         pos_err, vel_err = 0.0, rest - rel
         if distance > 0:
@@ -273,13 +322,13 @@ def substep(state, target, w=None, info=None):
             pos_err = -distance * w.erp2 / DT
         ni = len(nrm)
         nrm.append(dict(port=pn, sign=1.0, rhs=(pos_err + vel_err) * jdi[pn], lo=0.0, hi=1e10, lam=0.0))
-        if w.spinning_friction > 0:
+        if is_foot and w.spinning_friction > 0:
             spin.append(dict(port=base, sign=1.0, rhs=-b[base] * jdi[base], mu=w.spinning_friction, n=ni, lam=0.0))
-        if w.rolling_friction > 0:
+        if is_foot and w.rolling_friction > 0:
             for a_i in (1, 2):
                 roll.append(dict(port=base + a_i, sign=1.0, rhs=-b[base + a_i] * jdi[base + a_i], mu=w.rolling_friction, n=ni, lam=0.0))
         for a_i in (1, 2):
-            fric.append(dict(port=pn + a_i, sign=1.0, rhs=-b[pn + a_i] * jdi[pn + a_i], mu=w.lateral_friction, n=ni, lam=0.0))
+            fric.append(dict(port=pn + a_i, sign=1.0, rhs=-b[pn + a_i] * jdi[pn + a_i], mu=mu_lat, n=ni, lam=0.0))
 
     def resolve(row):
         p = row["port"]
@@ -361,6 +410,7 @@ def substep(state, target, w=None, info=None):
     nq /= np.linalg.norm(nq)
     q = q + DT * qd
     if info is not None:
-        info.update(M=M, tau=tau, L=L, A=A, b=b, J=J, dist=dist, iterations=its, active=active,
-                    right=any(f == 0 for f, _ in active), left=any(f == 1 for f, _ in active))
+        info.update(M=M, tau=tau, L=L, A=A, b=b, J=J, dist=dist, iterations=its, active=active, slots=slots,
+                    right=any(sl is not None and sl["kind"] == "foot" and sl["f"] == 0 for sl in slots),
+                    left=any(sl is not None and sl["kind"] == "foot" and sl["f"] == 1 for sl in slots))
     return np.concatenate([pos, nq, omega, vel, q, qd])

@@ -28,7 +28,7 @@ def test_nonfinite_guard_resets_and_counts(dtype, auto_reset):
     obs0 = env.reset().clone(); ref.reset()
     s = env.get_state()
     s[2, 15] = float("nan")            # a joint angle
-    s[5, 10] = float("inf")            # base velocity
+    s[5, 0] = float("inf")             # base position (an infinite VELOCITY would be clamped to +-100 by the engine and stay finite)
     env.set_state(s)
     s_ok = ref.get_state(); ref.set_state(s_ok)           # same bookkeeping reset as env.set_state, finite everywhere
     act = torch.full((n, 18), 0.1, device="cuda")

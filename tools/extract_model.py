@@ -289,6 +289,21 @@ def main():
         bodies.append(bd)
     assert abs(sum(b["mass"] for b in bodies) - total_mass) < 1e-12
 
+    # ---- ground-contact boxes of the non-foot links (plen.urdf:504-1274: 31 box colliders; the plane is loaded at plen_env.py:306-309) ----
+    # box 0 = the base link (torso), then the non-foot links in link order.  Pose in the LINK frame for the oracle and in the composite BODY
+    # frame for the HIP library.  Link restitution: 0.5 for links 0..31 (changeDynamics loop plen_env.py:472-481), the base keeps Bullet's
+    # default 0; lateral friction: Bullet's URDF default 0.5 (only the feet are changed, :439-467); no spinning/rolling friction.
+    boxes = []
+    for idx, x in [(-1, base)] + [(l["index"], l) for l in links]:
+        c = x["collider"]
+        if c["type"] != "box":
+            continue
+        cR, ct = np.array(c["R"]), np.array(c["t"])
+        boxes.append(dict(box=len(boxes), link=idx, name=x["name"], body=body_of_link[idx], half=c["half"], R_link=cR.tolist(), t_link=ct.tolist(),
+                          R_body=(Rb[idx] @ cR).tolist(), t_body=(tb[idx] + Rb[idx] @ ct).tolist(), break_threshold=x["break_threshold"],
+                          link_restitution=0.0 if idx < 0 else 0.5, link_lateral_friction=0.5))
+    assert len(boxes) == 31
+
     # ---- non-contact constraint visiting order ----
     # world array: 18 limit constraints (DoF order) then 18 motors (DoF order); ids 0..17 limit, 18..35 motor
     perm = bullet_quicksort_equal_keys(36)
@@ -298,7 +313,7 @@ def main():
         source=dict(urdf="plen_bullet/src/plen.urdf", meshes=["plen_ros/meshes_bin/rfoot.stl", "plen_ros/meshes_bin/lfoot.stl"],
                     note="generated by tools/extract_model.py; do not edit"),
         total_mass=total_mass, zero_pose_com_at_spawn=(com + np.array([0, 0, 0.158])).tolist(),
-        moving_joints=moving, base=base, links=links, feet=feet, bodies=bodies,
+        moving_joints=moving, base=base, links=links, feet=feet, bodies=bodies, boxes=boxes,
         noncontact_order=noncontact_order, margin=MARGIN)
 
     out_json = os.path.join(ROOT, "plen_ml_walk_amd/model/plen_model.json")
@@ -356,6 +371,15 @@ def write_raw_header(m, path):
             f.write("static const double RAW_%s_POINTS[4][3] = {\n%s};\n" % (tag, carr([x for v in ft["points"] for x in v], nested=3)))
             f.write("static const double RAW_%s_BREAK = %r;\n" % (tag, ft["break_threshold"]))
         f.write("static const double RAW_MARGIN = %r;\n" % m["margin"])
+        X = m["boxes"]
+        f.write("/* box colliders of the non-foot links (pose in the LINK frame; link -1 = base); half extents already include Bullet's margin */\n")
+        f.write("#define RAW_NBOX %d\n" % len(X))
+        f.write("static const int RAW_BOX_LINK[%d] = {%s};\n" % (len(X), ", ".join(str(b["link"]) for b in X)))
+        f.write("static const double RAW_BOX_R[%d][9] = {\n%s};\n" % (len(X), carr([v for b in X for r in b["R_link"] for v in r], nested=9)))
+        f.write("static const double RAW_BOX_T[%d][3] = {\n%s};\n" % (len(X), carr([v for b in X for v in b["t_link"]], nested=3)))
+        f.write("static const double RAW_BOX_H[%d][3] = {\n%s};\n" % (len(X), carr([v for b in X for v in b["half"]], nested=3)))
+        f.write("static const double RAW_BOX_BREAK[%d] = {\n%s};\n" % (len(X), carr([b["break_threshold"] for b in X])))
+        f.write("static const double RAW_BOX_LINK_RESTITUTION[%d] = {\n%s};\n" % (len(X), carr([b["link_restitution"] for b in X])))
         f.write("/* solver visiting order of the 36 non-contact constraints: kind 0=limit 1=motor, dof */\n")
         f.write("static const int RAW_NC_KIND[36] = {%s};\n" % ", ".join("0" if o["kind"] == "limit" else "1" for o in m["noncontact_order"]))
         f.write("static const int RAW_NC_DOF[36] = {%s};\n" % ", ".join(str(o["dof"]) for o in m["noncontact_order"]))
@@ -391,6 +415,16 @@ def write_merged_header(m, path):
         f.write("static const double GEN_MEMB_MASS[19][%d] = {\n%s};\n" % (nmax, carr([x for b in B for x in (b["member_mass"] + [0.0] * nmax)[:nmax]], nested=nmax)))
         f.write("static const double GEN_MEMB_COM[19][%d] = {\n%s};\n" % (nmax * 3, carr([x for b in B for v in (b["member_com"] + [[0.0, 0.0, 0.0]] * nmax)[:nmax] for x in v], nested=nmax * 3)))
         f.write("static const double GEN_MARGIN = %r;\n" % m["margin"])
+        X = m["boxes"]
+        f.write("/* box colliders of the non-foot links: composite body, pose in that BODY's frame (row-major R), half extents (margin included),\n"
+                " * contact breaking threshold, link restitution (0.5; base 0) */\n")
+        f.write("#define GEN_NBOX %d\n" % len(X))
+        f.write("static const int GEN_BOX_BODY[%d] = {%s};\n" % (len(X), ", ".join(str(b["body"]) for b in X)))
+        f.write("static const double GEN_BOX_R[%d][9] = {\n%s};\n" % (len(X), carr([v for b in X for r in b["R_body"] for v in r], nested=9)))
+        f.write("static const double GEN_BOX_T[%d][3] = {\n%s};\n" % (len(X), carr([v for b in X for v in b["t_body"]], nested=3)))
+        f.write("static const double GEN_BOX_H[%d][3] = {\n%s};\n" % (len(X), carr([v for b in X for v in b["half"]], nested=3)))
+        f.write("static const double GEN_BOX_BREAK[%d] = {\n%s};\n" % (len(X), carr([b["break_threshold"] for b in X])))
+        f.write("static const double GEN_BOX_LINK_RESTITUTION[%d] = {\n%s};\n" % (len(X), carr([b["link_restitution"] for b in X])))
         lows = set(l["lower"] for l in m["links"] if l["jtype"] == 1); ups = set(l["upper"] for l in m["links"] if l["jtype"] == 1)
         assert len(lows) == 1 and len(ups) == 1, "the HIP path assumes one common joint limit"
         f.write("#define GEN_LOWER_LIMIT %r\n#define GEN_UPPER_LIMIT %r\n" % (lows.pop(), ups.pop()))
