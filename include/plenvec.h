@@ -72,8 +72,11 @@ typedef struct PlenCfg {
     double motor_kp, motor_kd;   /* 0.1, 1.0 (PyBullet POSITION_CONTROL defaults) */
     double motor_max_force;      /* 0.15, plen_env.py:753 */
     double spawn_z;              /* 0.158, plen_env.py:312 */
+    double box_lateral_friction; /* 0.5*0.8: links other than the feet keep Bullet's URDF default friction 0.5 (only links 11, 19 are changed, plen_env.py:439-467) */
     int32_t nonfinite_guard;     /* 1 (default): per-env NaN/inf guard in the step epilogue, see PLENVEC_DONE_NONFINITE; 0: NaNs propagate like in the reference */
-    int32_t reserved0;           /* keep zero */
+    int32_t body_contacts;       /* 1 (default): the box colliders of the 31 non-foot links (plen.urdf:504-1274) collide with the ground like in the
+                                    reference (plen_env.py:306-315): a box corner near the ground takes a contact slot whose foot point is out of range;
+                                    0: only the feet collide */
 } PlenCfg;
 
 /* Fills *cfg with the reference configuration for the given joint_act mode. */
@@ -118,7 +121,9 @@ int plenvec_get_aux(plenvec_t *h, int32_t *aux, void *stream);
 
 /* Test hook: run `nsub` raw physics substeps (p.stepSimulation(), plen_env.py:667) with the given
  * motor targets (real[num_envs][18], radians, i.e. AFTER agent_to_env), no observation/reward
- * bookkeeping.  dump: optional real[num_envs][PLENVEC_DUMP] of solver intermediates of the LAST substep. */
+ * bookkeeping.  dump: optional real[num_envs][PLENVEC_DUMP] of solver intermediates of the LAST substep.  Afterwards aux[4..6] hold
+ * the contact flags and iteration count of the last substep and aux[7] its contact-slot masks (bits 0-7: slots lent to box corners of
+ * non-foot links, bits 8-15: occupied slots). */
 #define PLENVEC_DUMP 4096
 int plenvec_debug_substeps(plenvec_t *h, const void *targets, int nsub, void *dump, void *stream);
 

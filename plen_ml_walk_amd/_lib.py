@@ -22,7 +22,7 @@ class PlenCfg(C.Structure):
                 ("max_coordinate_velocity", C.c_double), ("lateral_friction", C.c_double), ("spinning_friction", C.c_double),
                 ("rolling_friction", C.c_double), ("restitution", C.c_double), ("linear_damping", C.c_double),
                 ("motor_kp", C.c_double), ("motor_kd", C.c_double), ("motor_max_force", C.c_double), ("spawn_z", C.c_double),
-                ("nonfinite_guard", C.c_int32), ("reserved0", C.c_int32)]
+                ("box_lateral_friction", C.c_double), ("nonfinite_guard", C.c_int32), ("body_contacts", C.c_int32)]
 
 
 EXPORTS = ["plenvec_default_cfg", "plenvec_create", "plenvec_destroy", "plenvec_num_envs", "plenvec_dtype", "plenvec_reset",

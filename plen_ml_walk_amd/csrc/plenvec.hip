@@ -64,6 +64,10 @@ struct DevParams {
     real mdl[NB][28];   // JR9 | JT3 | axis3 | com3 | inertia xx yy zz xy xz yz | mass | pad3
     real memb[NB][GEN_MAXMEMB][4];   // member links of each composite body: COM (body frame) | mass  (per-link linear damping)
     int nmemb[NB];
+    real box[GEN_NBOX][20];          // box colliders of the non-foot links: R9 | T3 (pose in the body frame) | H3 | break threshold | combined restitution | pad3
+    int box_body[GEN_NBOX];
+    real mu_box;                     // combined lateral friction of a box contact (URDF default 0.5 x plane 0.8)
+    int body_contacts;
     int num_iterations, max_episode_steps, joint_act, reward_head;
 };
 
@@ -568,7 +572,7 @@ struct Smem {
             real RO[NB][12];    // world rotation (9, row major) + frame origin (3)
             real CA[NB][8];     // COM world (3) | pad | joint axis world (3) | pad
         };
-        real park[2][64];       // phase F only (frames are dead after the collision pass): per-lane values parked out of registers
+        real park[4][64];       // phases F, G (frames are dead after the collision pass): per-lane values parked out of registers (port velocity, distance, restitution, friction)
     };
     alignas(16) real M[NV][NV]; // mass matrix, later its Cholesky factor L (lower); rows read as broadcast b128
     real v[NV];         // generalized velocity after the unconstrained update
@@ -843,11 +847,86 @@ __device__ __forceinline__ void euler_from_quat(const real *q, real *rpy) {   //
     }
 }
 
+// ---------------------------------------------------------------- ground contact of the non-foot links (rare path of phase E)
+// `near`: boxes (bit = box index) whose lowest point is within the link's contact breaking threshold of the ground.  Candidates are the
+// corners of the first 8 such boxes, one per lane: lane = 8 * (rank of the box among the near ones) + corner.  The valid ones (height <=
+// threshold) are ranked by (height, lane) and the deepest take the free contact slots (foot point out of range) in slot order; what does
+// not fit is dropped.  The three port lanes of a lent slot then get the corner's position, parameters and Jacobian (base + the chain of
+// joints that moves the box's body).  Same rule, same order as oracle/plen_oracle.c collide().
+template <typename real>
+__device__ __forceinline__ void box_contacts(Smem<real> &s, const DevParams<real> &P, const int lane, const unsigned near, unsigned &act, unsigned &lent,
+                                             const bool is_lin, const int pf, const int pk, const int pax, const int p, const real (&O0)[3],
+                                             real &dist, real (&Pw)[3], real &rest_l, real &mu_l) {
+    const real BIG = (real)1e30;
+    int xb = -1;
+    {
+        unsigned m = near;
+        for (int r = 0; r < 8 && m; r++) { const int x = __builtin_ctz(m); m &= m - 1u; if ((lane >> 3) == r) xb = x; }
+    }
+    real cw[3] = {0, 0, 0}, cd = BIG, crest = 0;
+    int cbody = 0;
+    if (xb >= 0) {
+        const real *bx = &P.box[0][0] + (unsigned)xb * 20u;
+        cbody = P.box_body[xb];
+        const real *RB = s.RO[cbody];
+        const real sg[3] = {(lane & 1) ? bx[12] : -bx[12], (lane & 2) ? bx[13] : -bx[13], (lane & 4) ? bx[14] : -bx[14]};
+        real lp[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) lp[i] = bx[9 + i] + bx[3 * i] * sg[0] + bx[3 * i + 1] * sg[1] + bx[3 * i + 2] * sg[2];    // corner in the body frame
+#pragma unroll
+        for (int i = 0; i < 3; i++) cw[i] = RB[9 + i] + RB[3 * i] * lp[0] + RB[3 * i + 1] * lp[1] + RB[3 * i + 2] * lp[2];
+        if (cw[2] <= bx[15]) cd = cw[2];
+        crest = bx[16];
+    }
+    const bool valid = cd < BIG;
+    int rank = 0;
+    for (int j = 0; j < 64; j++) {
+        const real dj = bcast(cd, j);
+        rank += (dj < cd || (dj == cd && j < lane)) ? 1 : 0;
+    }
+    const unsigned freem = ~act & 0xffu;
+    const bool take = valid && rank < __builtin_popcount(freem);
+    int myslot = -1;
+    if (take) {
+        unsigned m = freem;
+        for (int r = 0; r < rank; r++) m &= m - 1u;
+        myslot = __builtin_ctz(m);
+    }
+    real *desc = &s.lim[0][0];                 // free until phase G fills it
+    if (take) {
+        desc[8 * myslot + 0] = cw[0]; desc[8 * myslot + 1] = cw[1]; desc[8 * myslot + 2] = cd;
+        desc[8 * myslot + 3] = (real)cbody; desc[8 * myslot + 4] = crest;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; c++) if (__ballot(take && myslot == c)) lent |= 1u << c;
+    WSYNC();
+    const int slot = 4 * pf + pk;
+    if (is_lin && ((lent >> slot) & 1u)) {
+        const real *d = desc + 8 * slot;
+        Pw[0] = d[0]; Pw[1] = d[1]; Pw[2] = d[2]; dist = d[2];
+        rest_l = d[4]; mu_l = P.mu_box;
+        const real ax[3] = {pax == 2 ? (real)1 : (real)0, pax == 1 ? (real)-1 : (real)0, pax == 0 ? (real)1 : (real)0};
+#pragma unroll
+        for (int j = 0; j < NV; j++) s.YT[j][p] = 0;
+        real r[3] = {Pw[0] - O0[0], Pw[1] - O0[1], Pw[2] - O0[2]}, t1[3];
+        cross3(t1, r, ax);
+#pragma unroll
+        for (int i = 0; i < 3; i++) { s.YT[i][p] = t1[i]; s.YT[3 + i][p] = ax[i]; }
+        for (int bb = (int)d[3]; bb > 0; bb = c_parent[bb]) {          // the joints that move the box's body
+            const real a[3] = {s.CA[bb][4], s.CA[bb][5], s.CA[bb][6]};
+            const real rr[3] = {Pw[0] - s.RO[bb][9], Pw[1] - s.RO[bb][10], Pw[2] - s.RO[bb][11]};
+            cross3(t1, rr, ax);
+            s.YT[5 + bb][p] = dot3(a, t1);
+        }
+    }
+    act |= lent;
+}
+
 // ---------------------------------------------------------------- one 1/240 s physics substep
 // Contact flags of this substep's collision pass are returned in rc/lc, solver iterations in iters.
 template <bool FAST, typename real>
 __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P, const int lane_in, const real mass_scale, const real mu_lat,
-                               int &rc, int &lc, int &iters, int &load, real *dump) {
+                               int &rc, int &lc, int &iters, int &load, unsigned &lent_out, real *dump) {
     // `lane` is re-laundered through an empty asm at phase boundaries: otherwise the compiler CSEs the
     // `lane == j` masks of every unrolled phase (48 SGPR pairs), keeps them alive across the whole substep
     // and spills them
@@ -1052,7 +1131,30 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     unsigned act = 0;
 #pragma unroll
     for (int c = 0; c < 8; c++) act |= (unsigned)((act_ballot >> (LANE_NORMAL0 + 4 * c)) & 1ull) << c;
-    rc = (act & 0x0fu) != 0; lc = (act & 0xf0u) != 0;
+    rc = (act & 0x0fu) != 0; lc = (act & 0xf0u) != 0;        // getContactPoints(robot, plane, link 11 | 19): foot points only
+    // per-lane contact parameters of this lane's slot (foot point: the reference's foot values; a lent slot gets its box's below)
+    real rest_l = P.restitution, mu_l = mu_lat;
+    // ---- ground contact of the other links' boxes (plen.urdf:504-1274; rare) ----
+    // Every link has a box collider and the plane collides with all of them.  A box corner within its link's breaking threshold of
+    // the ground becomes a contact point in a slot whose foot point is out of range ("lent" slot), deepest corners first; the slot's
+    // three ports then carry that point's Jacobian.  The common case costs one box-height evaluation per lane and a ballot.
+    unsigned lent = 0;
+    if (P.body_contacts) {
+        bool near_l = false;
+        if (lane < GEN_NBOX) {
+            const real *bx = &P.box[0][0] + (unsigned)lane * 20u;
+            const real *RB = s.RO[P.box_body[lane]];
+            // heights of the box centre and of its three half axes:  row z of R_body times the box pose
+            const real cz = RB[11] + RB[6] * bx[9] + RB[7] * bx[10] + RB[8] * bx[11];
+            const real a0 = RB[6] * bx[0] + RB[7] * bx[3] + RB[8] * bx[6], a1 = RB[6] * bx[1] + RB[7] * bx[4] + RB[8] * bx[7],
+                       a2 = RB[6] * bx[2] + RB[7] * bx[5] + RB[8] * bx[8];
+            const real zmin = cz - (bx[12] * abs_(a0) + bx[13] * abs_(a1) + bx[14] * abs_(a2));
+            near_l = zmin <= bx[15];
+        }
+        const unsigned near = (unsigned)__ballot(near_l);           // boxes 0..30
+        if (near != 0u && act != 0xffu) box_contacts(s, P, lane, near, act, lent, is_lin, pf, pk, pax, p, O0, dist, Pw, rest_l, mu_l);
+    }
+    lent_out = lent | (act << 8);          // bits 0-7: slots lent to box corners, bits 8-15: slots holding a contact point
     WSYNC();
     // own Jacobian row into registers, b = J v*, then Y = L^-T J^T by back substitution (A = J M^-1 J^T = Y^T Y)
     real Jr[NV];
@@ -1076,6 +1178,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         for (int j = 0; j < NV; j++) s.YT[j][p] = Jr[j];
     }
     s.park[0][lane] = bvel; s.park[1][lane] = dist;      // needed again in phase G; phase F needs every register
+    s.park[2][lane] = rest_l; s.park[3][lane] = mu_l;
     WSYNC();
     STAMP();
     FRESH_LANE();
@@ -1109,11 +1212,13 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             for (int i = 0; i < 6; i++) Ar2[6 * decltype(cc)::value + i] += y2 * b[i];
         };
         integral_constant<int, 0> c0; integral_constant<int, 1> c1; integral_constant<int, 2> c2; integral_constant<int, 3> c3;
+        // a lent slot's port is supported by ITS body's chain, not by the leg it sits in: then every coordinate couples every pair (dense build, rare)
+        const int jend = lent ? NV : 6;
         ld(bufA, 0, c0);
         real yj = s.YT[0][p];
 #pragma unroll 1
-        for (int j = 0; j < 6; j++) {
-            const int jn = j < 5 ? j + 1 : 5;                 // (the last prefetch re-reads row 5: harmless, keeps the loop uniform)
+        for (int j = 0; j < jend; j++) {
+            const int jn = j < jend - 1 ? j + 1 : jend - 1;   // (the last prefetch re-reads the last row: harmless, keeps the loop uniform)
             const vec2 y2 = {yj, yj};
             diag += yj * yj;
             ld(bufB, j, c1); mac(bufA, y2, c0);
@@ -1123,6 +1228,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             ld(bufA, jn, c0); mac(bufB, y2, c3);
         }
     }
+    if (!lent) {
     static_for<2>([&](auto fc_) {        // leg f: DoFs 6+6f..11+6f, joint ports 6f..6f+5 (pairs 3f..3f+2), foot ports 18+15f..32+15f (pairs 9+7f..16+7f; pair 16 = ports 32|33 is shared)
         constexpr int f = decltype(fc_)::value, J0 = 6 + 6 * f, PJ = 3 * f, PC = 9 + 7 * f;
         vec2 bufA[6], bufB[5];           // A: the 3 joint pairs + the first 3 foot pairs, B: the other 5 foot pairs
@@ -1162,6 +1268,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             Ar2[6 + a] += y2 * r[6 + a]; Ar2[7 + a] += y2 * r[7 + a];
         }
     });
+    }
     const real EPS = sizeof(real) == 8 ? (real)2.220446049250313e-16 : (real)1.1920929e-07;
     const real jdi = diag > EPS ? rcp_(diag) : (real)0;
     if (dump) {
@@ -1188,8 +1295,8 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     FRESH_LANE();
     // ---------------- G. rows ----------------
     LANE_ROLES();
-    const real bvel_g = s.park[0][lane], dist_g = s.park[1][lane];
-    const bool cp_active_g = is_lin && dist_g <= P.brk[pf];
+    const real bvel_g = s.park[0][lane], dist_g = s.park[1][lane], rest_g = s.park[2][lane], mu_g = s.park[3][lane];
+    const bool cp_active_g = is_lin && ((act >> (4 * pf + pk)) & 1u);          // the slot holds a contact point (its foot point in range, or lent to a box corner)
     // joint lanes: motor row (+ a limit row when violated); contact lanes: one row per port, except the
     // torsional ports which carry one row per active contact point of their foot (same Jacobian).
     real rv = 0;                                   // velocity-level right-hand side of this lane's port
@@ -1215,7 +1322,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         }
     } else if (is_lin && pax == 0) {
         const real distance = dist_g + P.slop;
-        real rest = abs_(bvel_g) < P.rest_thr ? (real)0 : P.restitution * -bvel_g;
+        real rest = abs_(bvel_g) < P.rest_thr ? (real)0 : rest_g * -bvel_g;
         rest = max_(rest, (real)0);
         real pos_err = 0, vel_err = rest - bvel_g;
         if (distance > 0) vel_err -= distance * P.inv_dt; else pos_err = -distance * P.erp2 * P.inv_dt;
@@ -1234,10 +1341,17 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         const real mu = -(pl == 0 ? P.mu_spin : P.mu_roll) * diag;
         const int pn0 = 18 + 15 * pf + 3;
         fc0 = mu * s.lamP[pn0]; fc1 = mu * s.lamP[pn0 + 3]; fc2 = mu * s.lamP[pn0 + 6]; fc3 = mu * s.lamP[pn0 + 9];
+        if (lent) {          // spinning / rolling friction belongs to the FOOT's points (plen_env.py:439-467): a slot lent to another link's box has none
+            const unsigned l4 = (lent >> (4 * pf)) & 0xfu;
+            if (l4 & 1u) fc0 = 0;
+            if (l4 & 2u) fc1 = 0;
+            if (l4 & 4u) fc2 = 0;
+            if (l4 & 8u) fc3 = 0;
+        }
     }
     const real selA = (is_lin && pax == 1) ? (real)1 : (real)0;     // 1 in the first lane of every lateral-friction pair
     const int tors_src = LANE_NORMAL0 + 16 * pf;              // lane of the first normal port of this lane's foot (the next ones: + 4 each)
-    const real nfcn = (is_lin && pax == 0) ? -mu_lat * jdi : (real)0;   // lane PN: mu_lat * lambda_n = nfcn * blo
+    const real nfcn = (is_lin && pax == 0) ? -mu_g * jdi : (real)0;     // lane PN: mu * lambda_n = nfcn * blo
 
     real e = -rv;                  // e = J_port * deltaV - rv
     real dvec = 0;                 // per-pass deltas of the rows hosted by this lane (deferred commit)
@@ -1492,12 +1606,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real)
     WSYNC();
 
     int rc = 0, lc = 0, iters = 0, load = 0;
+    unsigned lent = 0;                                // last substep: bits 0-7 = contact slots lent to box corners of other links, bits 8-15 = occupied slots
     for (int sub = 0; sub < nsub; sub++) {
         // keep loop-invariant parameter/model loads INSIDE the substep: hoisted out of this loop they would
         // stay live across everything and be spilled to scratch
         int ln;                                       // ... and so would every lane-dependent constant (one-hots, masks, addresses)
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln) : : "memory");
-        substep<FAST>(s, P, ln, mass_scale, mu_lat, rc, lc, iters, load, (sub == nsub - 1) ? dump : nullptr);
+        substep<FAST>(s, P, ln, mass_scale, mu_lat, rc, lc, iters, load, lent, (sub == nsub - 1) ? dump : nullptr);
     }
 
     // the lane id again (one wave per block): the copy from threadIdx.x would otherwise be spilled across the substeps
@@ -1506,7 +1621,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real)
     load = load * 4 / max(nsub, 1);          // per 4-substep control step, whatever this launch ran (reset build: 8)
     if (mode == MODE_DEBUG) {
         a->state[(size_t)env * REC + lane] = s.st[lane];
-        if (lane == 0) { int *ax = a->aux + (size_t)env * AUXN; ax[4] = rc; ax[5] = lc; ax[6] = iters; }
+        if (lane == 0) { int *ax = a->aux + (size_t)env * AUXN; ax[4] = rc; ax[5] = lc; ax[6] = iters; ax[7] = (int)lent; }    // ax[7]: slot masks of the last substep (tests)
         return;
     }
 
@@ -1526,6 +1641,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real)
             real fx = 0, fy = 0, fz = 0;
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) {
+                if ((lent >> (4 * f + kk)) & 1u) continue;          // that slot carried another link's contact point, not this foot's
                 const int b0 = 18 + 15 * f + 3 + 3 * kk;
                 fz += s.lamP[b0] * P.inv_dt; fy -= s.lamP[b0 + 1] * P.inv_dt; fx += s.lamP[b0 + 2] * P.inv_dt;
             }
@@ -1794,6 +1910,14 @@ static void fill_params(const PlenCfg &c, DevParams<real> &p) {
             p.memb[b][i][3] = (real)GEN_MEMB_MASS[b][i];
         }
     }
+    for (int x = 0; x < GEN_NBOX; x++) {
+        for (int i = 0; i < 9; i++) p.box[x][i] = (real)GEN_BOX_R[x][i];
+        for (int i = 0; i < 3; i++) { p.box[x][9 + i] = (real)GEN_BOX_T[x][i]; p.box[x][12 + i] = (real)GEN_BOX_H[x][i]; }
+        p.box[x][15] = (real)GEN_BOX_BREAK[x];
+        p.box[x][16] = (real)(c.restitution * (GEN_BOX_LINK_RESTITUTION[x] / 0.5));      // c.restitution = link 0.5 x plane 0.5; the base link keeps Bullet's default 0
+        p.box_body[x] = GEN_BOX_BODY[x];
+    }
+    p.mu_box = (real)c.box_lateral_friction; p.body_contacts = c.body_contacts;
     p.num_iterations = c.num_iterations; p.max_episode_steps = c.max_episode_steps; p.joint_act = c.joint_act; p.reward_head = c.reward_head;
 }
 
@@ -1869,6 +1993,7 @@ int plenvec_default_cfg(PlenCfg *c, int joint_act) {
     c->restitution = 0.5 * 0.5; c->linear_damping = joint_act ? 0.1 : 0.0;
     c->motor_kp = 0.1; c->motor_kd = 1.0; c->motor_max_force = 0.15; c->spawn_z = 0.158;
     c->nonfinite_guard = 1;
+    c->box_lateral_friction = 0.5 * 0.8; c->body_contacts = 1;
     return PLENVEC_OK;
 }
 

@@ -35,7 +35,7 @@ def test_default_cfg_matches_reference_constants(lib):
     assert abs(c.lateral_friction - 0.64) < 1e-15 and abs(c.rolling_friction - 0.08) < 1e-15 and c.linear_damping == 0.0
     j = _lib.default_cfg(True)
     assert abs(j.rolling_friction - 0.008) < 1e-15 and j.linear_damping == 0.1 and j.joint_act == 1      # :439-442,:472-475
-    assert C.sizeof(_lib.PlenCfg) == 8 * 4 + 17 * 8 + 2 * 4 and c.nonfinite_guard == 1 and c.reserved0 == 0
+    assert C.sizeof(_lib.PlenCfg) == 8 * 4 + 18 * 8 + 2 * 4 and c.nonfinite_guard == 1 and c.body_contacts == 1 and abs(c.box_lateral_friction - 0.4) < 1e-15
 
 
 def test_error_paths_without_gpu(lib):
