@@ -55,6 +55,7 @@ def _lib(dtype="f64"):
         lib.oracle_step.argtypes = [C.c_void_p, dp, dp, ip]
         lib.oracle_rollout.restype = C.c_int
         lib.oracle_rollout.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), dp, dp, C.POINTER(C.c_uint8)]
+        lib.oracle_batch_rollout.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_float), dp, dp, C.c_double, C.c_int, C.c_int, dp, dp, C.POINTER(C.c_uint8)]
         lib.oracle_set_reward_head.argtypes = [C.c_void_p, C.c_int]
         lib.oracle_foot_forces.argtypes = [C.c_void_p, dp]
         lib.oracle_gazebo_contact.argtypes = [dp]
@@ -63,6 +64,25 @@ def _lib(dtype="f64"):
         lib.oracle_gazebo_script.restype = C.c_double
         _LIBS[dtype] = lib
     return _LIBS[dtype]
+
+
+def batch_rollout(actions, mass_scale=None, lateral_friction=None, rolling=-1.0, body_contacts=True, threads=None, dtype="f64"):
+    """actions float32 [T, N, 18] -> (obs [T, N, 26], rew [T, N], flags uint8 [T, N]): N independent oracle environments, each reset and
+    rolled out with auto-reset, partitioned over host threads (full-size parity tests)."""
+    lib = _lib(dtype)
+    a = np.ascontiguousarray(actions, dtype=np.float32)
+    T, n = a.shape[0], a.shape[1]
+    obs = np.zeros((T, n, 26)); rew = np.zeros((T, n)); flags = np.zeros((T, n), dtype=np.uint8)
+    ms = None if mass_scale is None else np.ascontiguousarray(mass_scale, dtype=np.float64)
+    mu = None if lateral_friction is None else np.ascontiguousarray(lateral_friction, dtype=np.float64)
+    if threads is None:
+        try:
+            threads = min(32, len(os.sched_getaffinity(0)))
+        except AttributeError:
+            threads = min(32, os.cpu_count() or 1)
+    lib.oracle_batch_rollout(n, T, a.ctypes.data_as(C.POINTER(C.c_float)), None if ms is None else _dp(ms), None if mu is None else _dp(mu),
+                             float(rolling), int(bool(body_contacts)), int(threads), _dp(obs), _dp(rew), flags.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return obs, rew, flags
 
 
 def native_lib():

@@ -1048,6 +1048,50 @@ API long long oracle_throughput(int n_envs, int threads, double budget_s, unsign
     return (long long)vsteps * n_envs;
 }
 
+/* ---------------------------------------------------------------- full-size parity helper (tests): n_envs independent environments,
+ * each created, given its own parameters, reset and rolled out for T control steps with the driver's auto-reset (oracle_rollout), the
+ * envs partitioned over `threads` POSIX threads.  actions [T][n_envs][18] float32; outputs obs [T][n_envs][26], rew [T][n_envs],
+ * flags [T][n_envs].  mass_scale / lateral_friction: per-env arrays or NULL.  rolling < 0 keeps the reference's rolling friction. */
+#include <pthread.h>
+typedef struct { int e0, e1, n, T; const float *act; const double *ms, *mu; double rolling; int body_contacts; double *obs, *rew; uint8_t *flags; } BatchJob;
+static void *batch_worker(void *arg) {
+    BatchJob *j = (BatchJob *)arg;
+    for (int e = j->e0; e < j->e1; e++) {
+        Oracle *o = oracle_create(0);
+        if (j->ms || j->mu) oracle_set_params(o, j->ms ? j->ms[e] : 1.0, j->mu ? j->mu[e] : -1.0);
+        if (j->rolling >= 0) o->w.rolling_friction = (real)j->rolling;
+        o->w.body_contacts = j->body_contacts;
+        oracle_reset(o, NULL);
+        for (int t = 0; t < j->T; t++) {
+            double a[ND], ob[26]; int done;
+            for (int d = 0; d < ND; d++) a[d] = j->act[((size_t)t * j->n + e) * ND + d];
+            double r = oracle_step(o, a, ob, &done);
+            int trunc = o->episode_timestep >= 500;
+            memcpy(j->obs + ((size_t)t * j->n + e) * 26, ob, sizeof ob);
+            j->rew[(size_t)t * j->n + e] = r;
+            j->flags[(size_t)t * j->n + e] = (uint8_t)((done ? 1 : 0) | (trunc ? 2 : 0));
+            if (done || trunc) oracle_reset(o, NULL);
+        }
+        oracle_destroy(o);
+    }
+    return NULL;
+}
+API void oracle_batch_rollout(int n_envs, int T, const float *actions, const double *mass_scale, const double *lateral_friction, double rolling,
+                              int body_contacts, int threads, double *obs, double *rew, uint8_t *flags) {
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    pthread_t th[256]; BatchJob jobs[256];
+    int per = (n_envs + threads - 1) / threads;
+    for (int k = 0; k < threads; k++) {
+        BatchJob *j = &jobs[k];
+        j->e0 = k * per < n_envs ? k * per : n_envs; j->e1 = (k + 1) * per < n_envs ? (k + 1) * per : n_envs;
+        j->n = n_envs; j->T = T; j->act = actions; j->ms = mass_scale; j->mu = lateral_friction; j->rolling = rolling; j->body_contacts = body_contacts;
+        j->obs = obs; j->rew = rew; j->flags = flags;
+        pthread_create(&th[k], NULL, batch_worker, j);
+    }
+    for (int k = 0; k < threads; k++) pthread_join(th[k], NULL);
+}
+
 API double oracle_last_residual(const Oracle *o) { return (double)o->last_residual; }
 API void oracle_set_reward_head(Oracle *o, int head) { o->reward_head = head; }
 API void oracle_foot_forces(const Oracle *o, double *f6) { for (int i = 0; i < 6; i++) f6[i] = o->foot_force[i / 3][i % 3]; }
