@@ -180,6 +180,28 @@ def test_recorded_policy_action_sequence_f64(golden_dir):
         assert max(errs[:exact_steps]) <= 1e-9 and max(errs) <= 1e-5, (rolling, errs)
 
 
+def test_recorded_policy_action_sequence_f32(golden_dir):
+    """The same recorded commands through the f32 kernel: f32 rounding (6e-8) stays at the 1e-5 level for the 14 steps
+    before the robot starts to tumble with rolling friction off, and for the first 2 steps in the reference configuration, whose solver
+    amplifies it by ~50x per control step from the start (measured: 8e-7, 9e-6, 5e-4, ...; the f64 kernel: 2e-15, 1e-15, 5e-13, 5e-13, 4e-4)."""
+    a = np.load(os.path.join(golden_dir, "policy_cmd_sequence.npz"))["actions"]
+    for rolling, steps, tol in ((0.0, 14, 5e-5), (None, 2, 5e-5)):
+        ov = {} if rolling is None else {"rolling_friction": rolling}
+        env = _env(1, torch.float32, cfg_overrides=ov); env.reset()
+        o = OracleEnv()
+        if rolling is not None:
+            o.set_friction(rolling=rolling)
+        o.reset()
+        errs = []
+        for t in range(steps):
+            nobs, rew, done, _ = env.step(torch.tensor(a[t:t + 1]).cuda())
+            ob, r, d, _ = o.step(a[t].astype(np.float64))
+            errs.append(max(np.abs(ob - nobs[0].cpu().numpy().astype(np.float64)).max(), abs(r - float(rew[0])) / max(1.0, abs(r)) * 1e-2))
+            assert bool(int(done[0]) & 1) == d
+        env.close()
+        assert max(errs) <= tol, (rolling, errs)
+
+
 def test_rollout_well_conditioned_f32():
     g = torch.Generator().manual_seed(0)
     acts = ((torch.rand(10, 16, 18, generator=g) * 2 - 1) * 0.3).float()
@@ -280,6 +302,19 @@ def test_reference_walking_trajectory_joint_act_f64():
     eo, er, mism, cmpd = _rollout_vs_oracle(torch.float64, 2, acts.shape[0], acts, joint_act=True)
     assert cmpd >= 40 and mism == 0
     assert np.median(eo) <= 1e-9 and eo.max() <= 1e-5 and er.max() <= 1e-5
+
+
+def test_reference_walking_trajectory_joint_act_f32():
+    """The reference's open-loop walking trajectory through the f32 kernel against the f64 oracle: 70 control steps (20 bend + 50 of the
+    gait) without a single flag mismatch; the error grows smoothly from 5e-7 to ~2e-3 (f64: 1e-15 to 1e-12)."""
+    from plen_ml_walk_amd.trajectory_eval import assemble_joint_trajectories
+    walk, bend = assemble_joint_trajectories()
+    a = np.concatenate([np.tile(bend, (20, 1)), walk[:50]], 0)
+    acts = torch.tensor(np.repeat(a[:, None, :], 2, axis=1), dtype=torch.float32)
+    eo, er, mism, cmpd = _rollout_vs_oracle(torch.float32, 2, acts.shape[0], acts, joint_act=True)
+    assert cmpd >= 2 * 70 and mism == 0
+    # (an error of exactly 1 is a foot-contact flag that switches one control step earlier or later in f32)
+    assert eo[:24].max() <= 5e-5 and np.median(eo) <= 1e-3 and (eo > 0.5).sum() <= 4 and eo[eo <= 0.5].max() <= 2e-2
 
 
 def test_asm_path_bitwise_equals_compiler_path(tmp_path):
