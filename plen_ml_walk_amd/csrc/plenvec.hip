@@ -852,7 +852,7 @@ __device__ __forceinline__ void euler_from_quat(const real *q, real *rpy) {   //
 // corners of the first 8 such boxes, one per lane: lane = 8 * (rank of the box among the near ones) + corner.  The valid ones (height <=
 // threshold) are ranked by (height, lane) and the deepest take the free contact slots (foot point out of range) in slot order; what does
 // not fit is dropped.  The three port lanes of a lent slot then get the corner's position, parameters and Jacobian (base + the chain of
-// joints that moves the box's body).  Same rule, same order as oracle/plen_oracle.c collide().
+// joints that moves the box's body).  The rule and its tie-breaks are spelled out in DESIGN.md (contact model); the test oracle states the same.
 template <typename real>
 __device__ __forceinline__ void box_contacts(Smem<real> &s, const DevParams<real> &P, const int lane, const unsigned near, unsigned &act, unsigned &lent,
                                              const bool is_lin, const int pf, const int pk, const int pax, const int p, const real (&O0)[3],
