@@ -27,9 +27,12 @@
  *
  * Known, documented deviation: contact generation.  Bullet runs GJK/EPA foot-hull vs ground-box
  * with a persistent 4-point manifold whose point positions depend on solver history; that is not
- * reproducible without Bullet itself.  Here each foot has 4 fixed candidate points (corner-most
- * sole-hull vertices, 1 mm spherical margin) tested against the half-space z<=0; a candidate is a
- * manifold point while its distance is below the foot's contact-breaking threshold.
+ * reproducible without Bullet itself.  Here the candidates of a foot are the 8 corners of its
+ * octagonal sole outline (one representative hull vertex per rounded corner, 1 mm spherical
+ * margin) tested against the half-space z<=0; those within the foot's
+ * contact-breaking threshold are reduced to <= 4 manifold points per collision pass: per sole
+ * diagonal the in-range vertex extreme along it (area-spanning like btPersistentManifold's
+ * reduction, but memoryless); a flat foot yields its four corner-most vertices.
  * The 31 box colliders of the other links (plen.urdf:504-1274) collide with the ground too (Bullet:
  * btBoxBoxDetector against plane.urdf's box -> the penetrating corners of the face turned to the
  * ground): a box corner is a contact point while its height is below the link's breaking threshold.
@@ -490,19 +493,32 @@ static void collide(Oracle *o) {
     for (int f = 0; f < 2; f++) {
         int link = f == 0 ? RAW_RFOOT_LINK : RAW_LFOOT_LINK, b = link + 1;
         real thr = (real)(f == 0 ? RAW_RFOOT_BREAK : RAW_LFOOT_BREAK);
+        /* candidates: the representatives of the sole outline's 8 corner fillets (Bullet's manifold merges points closer than the breaking
+         * threshold, and a fillet is ~1.5 mm long), sphere-swept by the margin; in range while distance <= breaking threshold */
+        real wv[32][3]; int in_range[32];
+        for (int v = 0; v < 32; v++) {
+            const double *pl = f == 0 ? RAW_RFOOT_SOLE[v] : RAW_LFOOT_SOLE[v];
+            real l[3] = {(real)pl[0], (real)pl[1], (real)pl[2]};
+            m3mulv(wv[v], o->Rw[b], l); v3add(wv[v], wv[v], o->Ow[b]);
+            in_range[v] = (f == 0 ? RAW_RFOOT_SOLE_REP[v] : RAW_LFOOT_SOLE_REP[v]) && (wv[v][2] - (real)RAW_MARGIN) <= thr;
+        }
+        /* manifold reduction: per sole diagonal k the in-range vertex extreme along it (first in-range entry of the precomputed order);
+         * a vertex already chosen for an earlier diagonal is not repeated.  Whole sole in range -> the four corner-most vertices. */
+        int chosen[4] = {-1, -1, -1, -1};
         for (int k = 0; k < 4; k++) {
-            const double *pl = f == 0 ? RAW_RFOOT_POINTS[k] : RAW_LFOOT_POINTS[k];
-            real l[3] = {(real)pl[0], (real)pl[1], (real)pl[2]}, wpt[3];
-            m3mulv(wpt, o->Rw[b], l); v3add(wpt, wpt, o->Ow[b]);
-            real dist = wpt[2] - (real)RAW_MARGIN;
-            if (dist <= thr) {
-                int c = 4 * f + k;
-                slot[c].used = 1; slot[c].foot = f; slot[c].link = link; slot[c].box = -1; slot[c].dist = dist;
-                v3set(slot[c].pos, wpt[0], wpt[1], dist);   /* position on the robot (sphere-swept vertex) */
-                slot[c].mu = o->w.lateral_friction; slot[c].rest = o->w.restitution;
-                slot_used[c] = 1;
-                if (f == 0) o->right_contact = 1; else o->left_contact = 1;
-            }
+            const int *ord = f == 0 ? RAW_RFOOT_SOLE_ORDER[k] : RAW_LFOOT_SOLE_ORDER[k];
+            int win = -1;
+            for (int j = 0; j < 32; j++) if (in_range[ord[j]]) { win = ord[j]; break; }
+            for (int k2 = 0; k2 < k; k2++) if (win >= 0 && chosen[k2] == win) win = -1;
+            chosen[k] = win;
+            if (win < 0) continue;
+            int c = 4 * f + k;
+            real dist = wv[win][2] - (real)RAW_MARGIN;
+            slot[c].used = 1; slot[c].foot = f; slot[c].link = link; slot[c].box = -1; slot[c].dist = dist;
+            v3set(slot[c].pos, wv[win][0], wv[win][1], dist);   /* position on the robot (sphere-swept vertex) */
+            slot[c].mu = o->w.lateral_friction; slot[c].rest = o->w.restitution;
+            slot_used[c] = 1;
+            if (f == 0) o->right_contact = 1; else o->left_contact = 1;
         }
     }
     if (o->w.body_contacts) {

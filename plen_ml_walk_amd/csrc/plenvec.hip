@@ -60,7 +60,9 @@ struct DevParams {
     real dt, inv_dt, gz, erp, erp2, slop, res_thr, res_thr_sqrt, rest_thr, vmax;
     real mu_lat, mu_spin, mu_roll, restitution, lin_damp, kp, kd, max_imp, spawn_z;
     real margin, brk[2];
-    real pts[2][4][3];
+    real sole[2][32][4];     // the 32 sole-plane hull vertices of each foot (foot body frame), xyz | 1 if the vertex represents its corner fillet (contact candidate)
+    unsigned sole_src[2][32];   // [f][j]: byte k = the vertex with the j-th highest key along sole diagonal k
+    unsigned corner_pack[2];    // [f]: byte k = sole_src[f][0] byte k, the corner-most vertex of diagonal k (what a flat foot selects)
     real mdl[NB][28];   // JR9 | JT3 | axis3 | com3 | inertia xx yy zz xy xz yz | mass | pad3
     real memb[NB][GEN_MAXMEMB][4];   // member links of each composite body: COM (body frame) | mass  (per-link linear damping)
     int nmemb[NB];
@@ -1091,6 +1093,41 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         valid_port = is_joint || is_tors || is_lin; \
         p = is_joint ? lane : (valid_port ? 18 + 15 * pf + pl : 0); \
     } while (0)
+    // Foot manifolds.  The 32 sole-plane hull vertices of each foot sit one per lane (lane = 32 f + v); candidates are the representatives
+    // of the outline's 8 corner fillets (Bullet merges manifold points closer than the breaking threshold), in range while their
+    // sphere-swept distance <= the foot's contact breaking threshold.  Reduction to <= 4 points per foot (slot 4f+k): per sole diagonal k the
+    // in-range vertex extreme along it -- lane 32f+j looks up (LDS crossbar) whether the vertex with the j-th highest key along k is in
+    // range, so the winner is the first set bit of a ballot; a vertex that already won an earlier diagonal is not taken twice.  A flat
+    // foot selects its four corner-most vertices; a slot without a point keeps the corner vertex (its rows are no-ops).
+    unsigned act = 0, wpack0, wpack1;
+    {
+        const int f_ = lane >> 5;
+        const real *sv = &P.sole[0][0][0] + (unsigned)lane * 4u;
+        const real *RF = s.RO[f_ ? GEN_LFOOT_BODY : GEN_RFOOT_BODY];
+        const real zv = RF[11] + (RF[6] * sv[0] + RF[7] * sv[1] + RF[8] * sv[2]);
+        const int in_range = (sv[3] != (real)0 && zv - P.margin <= P.brk[f_]) ? 1 : 0;        // sv[3]: 1 for the representative of a corner fillet
+        const unsigned src = (&P.sole_src[0][0])[lane];
+        unsigned wp[2] = {P.corner_pack[0], P.corner_pack[1]};
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const int from = (int)((src >> (8 * kk)) & 31u) + (lane & 32);
+            const int got = __builtin_amdgcn_ds_bpermute(from << 2, in_range);
+            const unsigned long long m = __ballot(got != 0);
+#pragma unroll
+            for (int f2 = 0; f2 < 2; f2++) {
+                const unsigned half = (unsigned)(m >> (32 * f2));
+                if (half) {
+                    const int j = __builtin_ctz(half);
+                    const unsigned v = ((unsigned)__builtin_amdgcn_readlane((int)src, 32 * f2 + j) >> (8 * kk)) & 31u;
+                    bool dup = false;
+#pragma unroll
+                    for (int k2 = 0; k2 < kk; k2++) dup = dup || (((act >> (4 * f2 + k2)) & 1u) && ((wp[f2] >> (8 * k2)) & 31u) == v);
+                    if (!dup) { act |= 1u << (4 * f2 + kk); wp[f2] = (wp[f2] & ~(0xffu << (8 * kk))) | (v << (8 * kk)); }
+                }
+            }
+        }
+        wpack0 = wp[0]; wpack1 = wp[1];
+    }
     LANE_ROLES();
     const int fb = pf == 0 ? GEN_RFOOT_BODY : GEN_LFOOT_BODY;
     real dist = 0;
@@ -1100,7 +1137,8 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         for (int j = 0; j < NV; j++) s.YT[j][p] = 0;
         real ax[3] = {pax == 2 ? (real)1 : (real)0, pax == 1 ? (real)-1 : (real)0, pax == 0 ? (real)1 : (real)0};
         if (is_lin) {
-            const real *pt = P.pts[pf][pk];
+            const unsigned wv = ((pf ? wpack1 : wpack0) >> (8 * pk)) & 31u;          // the sole vertex this slot's foot point sits on
+            const real *pt = &P.sole[0][0][0] + ((unsigned)pf * 32u + wv) * 4u;
             real wp[3];
             matvec3(wp, s.RO[fb], pt);
             dist = wp[2] + s.RO[fb][11] - P.margin;
@@ -1125,12 +1163,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             s.YT[5 + b][p] = val;
         }
     }
-    const bool cp_active = is_lin && dist <= P.brk[pf];
-    const unsigned long long act_ballot = __ballot(cp_active && pax == 0);
-    // active-point mask in manifold order (right foot points 0..3, left foot 4..7)
-    unsigned act = 0;
-#pragma unroll
-    for (int c = 0; c < 8; c++) act |= (unsigned)((act_ballot >> (LANE_NORMAL0 + 4 * c)) & 1ull) << c;
+    // act: occupied-slot mask in manifold order (right foot points 0..3, left foot 4..7), so far the foot points
     rc = (act & 0x0fu) != 0; lc = (act & 0xf0u) != 0;        // getContactPoints(robot, plane, link 11 | 19): foot points only
     // per-lane contact parameters of this lane's slot (foot point: the reference's foot values; a lent slot gets its box's below)
     real rest_l = P.restitution, mu_l = mu_lat;
@@ -1898,7 +1931,16 @@ static void fill_params(const PlenCfg &c, DevParams<real> &p) {
     p.mu_roll = (real)c.rolling_friction; p.restitution = (real)c.restitution; p.lin_damp = (real)c.linear_damping;
     p.kp = (real)c.motor_kp; p.kd = (real)c.motor_kd; p.max_imp = (real)(c.motor_max_force * c.dt); p.spawn_z = (real)c.spawn_z;
     p.margin = (real)GEN_MARGIN; p.brk[0] = (real)GEN_RFOOT_BREAK; p.brk[1] = (real)GEN_LFOOT_BREAK;
-    for (int k = 0; k < 4; k++) for (int i = 0; i < 3; i++) { p.pts[0][k][i] = (real)GEN_RFOOT_POINTS[k][i]; p.pts[1][k][i] = (real)GEN_LFOOT_POINTS[k][i]; }
+    for (int f = 0; f < 2; f++) {
+        p.corner_pack[f] = 0;
+        for (int v = 0; v < 32; v++) {
+            for (int i = 0; i < 3; i++) p.sole[f][v][i] = (real)(f == 0 ? GEN_RFOOT_SOLE[v][i] : GEN_LFOOT_SOLE[v][i]);
+            p.sole[f][v][3] = (real)(f == 0 ? GEN_RFOOT_SOLE_REP[v] : GEN_LFOOT_SOLE_REP[v]);
+            p.sole_src[f][v] = 0;
+            for (int k = 0; k < 4; k++) p.sole_src[f][v] |= (unsigned)(f == 0 ? GEN_RFOOT_SOLE_ORDER[k][v] : GEN_LFOOT_SOLE_ORDER[k][v]) << (8 * k);
+        }
+        p.corner_pack[f] = p.sole_src[f][0];
+    }
     for (int b = 0; b < NB; b++) {
         for (int i = 0; i < 9; i++) p.mdl[b][i] = (real)GEN_JR[b][i];
         for (int i = 0; i < 3; i++) { p.mdl[b][9 + i] = (real)GEN_JT[b][i]; p.mdl[b][12 + i] = (real)GEN_AXIS[b][i]; p.mdl[b][15 + i] = (real)GEN_COM[b][i]; }

@@ -72,6 +72,9 @@ BODIES = bodies()
 FOOT_BODY = [6, 12]   # right, left (DoF order: right leg 1..6, left leg 7..12)
 FOOT_POINTS = [np.array(MODEL["feet"][0]["points"]), np.array(MODEL["feet"][1]["points"])]
 FOOT_BREAK = [MODEL["feet"][0]["break_threshold"], MODEL["feet"][1]["break_threshold"]]
+FOOT_SOLE = [np.array(MODEL["feet"][0]["sole"]), np.array(MODEL["feet"][1]["sole"])]       # 32 sole-plane hull vertices per foot
+FOOT_SOLE_ORDER = [MODEL["feet"][0]["sole_order"], MODEL["feet"][1]["sole_order"]]         # per sole diagonal: vertices by descending key
+FOOT_SOLE_REP = [np.array(MODEL["feet"][0]["sole_rep"], bool), np.array(MODEL["feet"][1]["sole_rep"], bool)]   # the 8 corner representatives
 MARGIN = MODEL["margin"]
 BOXES = MODEL["boxes"]          # box colliders of the non-foot links, pose in their composite body's frame
 MAXNEAR = 8
@@ -212,7 +215,7 @@ def port_jacobians(kin, pos, body_contacts=True):
     J = np.zeros((NPORT, NV))
     for d in range(ND):
         J[d, 6 + d] = 1.0
-    pts = np.zeros((2, 4, 3)); dist = np.zeros((2, 4))
+    pts = np.zeros((2, 4, 3)); dist = np.zeros((2, 4)); foot_active = np.zeros((2, 4), bool)
     for f in range(2):
         fb = FOOT_BODY[f]
         anc = ancestors(fb)
@@ -221,8 +224,17 @@ def port_jacobians(kin, pos, body_contacts=True):
             J[base + a_i, 0:3] = ax
             for b in anc:
                 J[base + a_i, 5 + b] = A[b] @ ax
+        # manifold of this foot: per sole diagonal the in-range sole vertex extreme along it, no vertex twice
+        wv = O[fb] + FOOT_SOLE[f] @ R[fb].T
+        in_range = FOOT_SOLE_REP[f] & (wv[:, 2] - MARGIN <= FOOT_BREAK[f])
+        chosen = []
         for k in range(4):
-            w = O[fb] + R[fb] @ FOOT_POINTS[f][k]
+            win = next((v for v in FOOT_SOLE_ORDER[f][k] if in_range[v]), None)
+            if win in chosen:
+                win = None
+            chosen.append(win)
+            foot_active[f, k] = win is not None
+            w = wv[win] if win is not None else O[fb] + R[fb] @ FOOT_POINTS[f][k]        # (an unused slot keeps the corner point: its rows do not exist)
             dist[f, k] = w[2] - MARGIN
             P = np.array([w[0], w[1], dist[f, k]])
             pts[f, k] = P
@@ -233,7 +245,7 @@ def port_jacobians(kin, pos, body_contacts=True):
                 for b in anc:
                     J[row, 5 + b] = A[b] @ np.cross(P - O[b], ax)
     # slots whose foot point is out of range are lent to box corners, deepest first
-    slots = [dict(kind="foot", f=c // 4, k=c % 4) if dist[c // 4, c % 4] <= FOOT_BREAK[c // 4] else None for c in range(8)]
+    slots = [dict(kind="foot", f=c // 4, k=c % 4) if foot_active[c // 4, c % 4] else None for c in range(8)]
     if body_contacts:
         cands = box_candidates(kin)
         for c in range(8):

@@ -236,12 +236,45 @@ def main():
             pick = top[np.argmax(np.abs(nrm[top, 0]))]
             pts_idx.append(int(sole_idx[pick]))
         pts_local = hv[pts_idx]
+        # Round 2: ALL sole-hull vertices are contact candidates; per collision pass the ones within the breaking threshold are reduced to
+        # <= 4 manifold points: for each of the four sole diagonals the in-range vertex that is extreme along it (Bullet's manifold keeps the
+        # set spanning the largest area).  sole_order[k][j] = vertex with the j-th highest key along diagonal k (ties: larger |x|, then lower
+        # index), so "first in-range entry of sole_order[k]" is the winner; with the whole sole in range the winners are pts_idx above.
+        order2d = ConvexHull(sole[:, :2]).vertices            # counter-clockwise outline
+        assert len(order2d) == len(sole_idx) == 32, "the HIP path assumes 32 sole vertices per foot (one lane each)"
+        sole_local = hv[sole_idx[order2d]]
+        nrm2 = nrm[order2d]
+        # The outline is an octagon whose 8 corners are 4-vertex fillets ~1.5 mm long.  Bullet's manifold merges points closer than the
+        # breaking threshold (~1 mm, btPersistentManifold::getCacheEntry), so a fillet is ONE contact location: its corner-most vertex
+        # represents it (sole_rep = 1) and only the 8 representatives are candidates (one tilted corner = one point, one edge = two).
+        xy = sole[order2d][:, :2]
+        gap = np.linalg.norm(xy - np.roll(xy, 1, axis=0), axis=1) > 1.2e-3          # True where a new fillet starts
+        start = int(np.where(gap)[0][0])
+        groups, cur = [], []
+        for i in range(32):
+            v = (start + i) % 32
+            if gap[v] and cur:
+                groups.append(cur); cur = []
+            cur.append(v)
+        groups.append(cur)
+        assert len(groups) == 8 and all(len(g) == 4 for g in groups), [len(g) for g in groups]
+        sole_rep = [0] * 32
+        for g in groups:
+            sole_rep[max(g, key=lambda v: (round(float(abs(nrm2[v, 0]) + abs(nrm2[v, 1])), 9), -v))] = 1
+        sole_order = []
+        for kdir, (sx, sy) in enumerate(((-1, -1), (-1, 1), (1, -1), (1, 1))):
+            score = sx * nrm2[:, 0] + sy * nrm2[:, 1]
+            o = sorted(range(32), key=lambda v: (-round(float(score[v]), 9), -abs(float(nrm2[v, 0])), v))
+            o = [v for v in o if sole_rep[v]] + [v for v in o if not sole_rep[v]]        # representatives first (the others never come into range)
+            assert np.allclose(sole_local[o[0]], pts_local[kdir]), "flat stance must reproduce the round-1 corner points"
+            sole_order.append([int(v) for v in o])
         q = w[pts_idx][[0, 1, 3, 2], :2]
         best_area = 0.5 * abs(np.dot(q[:, 0], np.roll(q[:, 1], -1)) - np.dot(q[:, 1], np.roll(q[:, 0], -1)))
         feet.append(dict(side=side, link=k, n_hull=len(hv), n_sole=len(sole_idx),
                          sole_z_at_spawn=float(zmin + 0.158), quad_area=float(best_area),
                          sole_polygon_area=float(ConvexHull(sole[:, :2]).volume), sole_bbox=(2 * hxy).tolist(),
-                         points=pts_local.tolist(), margin=MARGIN, break_threshold=l["break_threshold"]))
+                         points=pts_local.tolist(), sole=sole_local.tolist(), sole_order=sole_order, sole_rep=sole_rep,
+                         margin=MARGIN, break_threshold=l["break_threshold"]))
 
     # ---- merged composite bodies (fixed joints folded) ----
     # body 0 = base composite; bodies 1..18 in DoF order; frame of body b = link frame of its moving link
@@ -370,6 +403,11 @@ def write_raw_header(m, path):
             f.write("static const double RAW_%s_HULL[%d][3] = {\n%s};\n" % (tag, len(hv), carr([x for v in hv for x in v], nested=3)))
             f.write("static const double RAW_%s_POINTS[4][3] = {\n%s};\n" % (tag, carr([x for v in ft["points"] for x in v], nested=3)))
             f.write("static const double RAW_%s_BREAK = %r;\n" % (tag, ft["break_threshold"]))
+            f.write("/* the 32 sole-plane hull vertices (link frame, outline order) and, per sole diagonal, the vertices by descending key */\n")
+            f.write("static const double RAW_%s_SOLE[32][3] = {\n%s};\n" % (tag, carr([x for v in ft["sole"] for x in v], nested=3)))
+            f.write("static const int RAW_%s_SOLE_ORDER[4][32] = {%s};\n" % (tag, ", ".join("{" + ", ".join(str(v) for v in o) + "}" for o in ft["sole_order"])))
+            f.write("/* 1: the vertex represents its corner fillet and is a contact candidate */\n")
+            f.write("static const int RAW_%s_SOLE_REP[32] = {%s};\n" % (tag, ", ".join(str(v) for v in ft["sole_rep"])))
         f.write("static const double RAW_MARGIN = %r;\n" % m["margin"])
         X = m["boxes"]
         f.write("/* box colliders of the non-foot links (pose in the LINK frame; link -1 = base); half extents already include Bullet's margin */\n")
@@ -408,6 +446,11 @@ def write_merged_header(m, path):
             f.write("#define GEN_%s_BODY %d\n" % (tag, body))
             f.write("static const double GEN_%s_POINTS[4][3] = {\n%s};\n" % (tag, carr([x for v in ft["points"] for x in v], nested=3)))
             f.write("static const double GEN_%s_BREAK = %r;\n" % (tag, ft["break_threshold"]))
+            f.write("/* the 32 sole-plane hull vertices (foot body frame, outline order) and, per sole diagonal, the vertices by descending key */\n")
+            f.write("static const double GEN_%s_SOLE[32][3] = {\n%s};\n" % (tag, carr([x for v in ft["sole"] for x in v], nested=3)))
+            f.write("static const int GEN_%s_SOLE_ORDER[4][32] = {%s};\n" % (tag, ", ".join("{" + ", ".join(str(v) for v in o) + "}" for o in ft["sole_order"])))
+            f.write("/* 1: the vertex represents its corner fillet and is a contact candidate */\n")
+            f.write("static const int GEN_%s_SOLE_REP[32] = {%s};\n" % (tag, ", ".join(str(v) for v in ft["sole_rep"])))
         nmax = max(len(b["member_mass"]) for b in B)
         f.write("/* member links of every composite body (mass, COM in the body frame): Bullet applies its linear damping per LINK */\n")
         f.write("#define GEN_MAXMEMB %d\n" % nmax)
