@@ -1,0 +1,62 @@
+/*
+ * plentd3.h -- C ABI of libplentd3.so: the hand-written HIP kernels (gfx950) for the non-GEMM work of one TD3 iteration.
+ *
+ * The reference's learner is Python/torch (plen_ros/src/plen_ros_helpers/td3.py); it has no FFI of its own.  These entry points are
+ * what plen_ml_walk_amd/td3_fused.py binds with ctypes; each cites the reference lines whose arithmetic it carries out.  The dense
+ * layers between them stay library GEMMs (torch.mm / addmm -> rocBLAS / hipBLASLt).
+ *
+ * Conventions: every pointer is a caller-owned DEVICE pointer to float32 (int64 for idx); work is enqueued on the hipStream_t passed
+ * as `stream` (void* so the header needs no HIP) and is capturable in a hipGraph; return 0 or a negative HIP error code.
+ * Row layouts: packed replay / batch row = s[26] | a[18] | s2[26] | r | not_done (TD3_ROW = 72 floats, td3.py:136-147 tuple order
+ * state, action, next_state, reward, with not_done = 1 - done as td3.py:187-191 hands it to train); state-action matrix = s | a (44).
+ */
+#ifndef PLENTD3_H
+#define PLENTD3_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TD3_S 26
+#define TD3_A 18
+#define TD3_SA 44
+#define TD3_ROW 72
+
+/* td3.py:166-193 ReplayBuffer.sample: out[b] = data[idx[b]]; also sa_pi[b][0:26] = state (policy pass input), loss[0:2] = 0 */
+int plentd3_gather(const float *data, const int64_t *idx, float *out, float *sa_pi, float *loss, int B, void *stream);
+/* td3.py:175 sampling on the device + the gather above: idx = min(floor(u filled), filled - 1), filled = min(*total, capacity), u in [0,1); idx_out may be NULL */
+int plentd3_sample_gather(const float *data, const float *u, const int64_t *total, int64_t capacity, int64_t *idx_out, float *out, float *sa_pi, float *loss, int B, void *stream);
+/* plen_td3.py:101-104 exploration: a = clamp(max_a tanh(pre) + noise sigma, +-max_a) over n = B*18 elements */
+int plentd3_explore(const float *pre, const float *noise, float *a, float sigma, float max_a, int n, void *stream);
+/* plen_td3.py:109-113 replay_buffer.add for a whole vector step: ring rows (*total + e) % capacity = s | a | s2 | r | 1 - done_bool,
+ * done_bool = terminal and not time-limit (done = PLENVEC_DONE_* bits of plenvec_step); real arrays are float32 */
+int plentd3_store(float *data, const int64_t *total, int64_t capacity, const float *s, const float *a, const float *s2, const float *r, const uint8_t *done, int n, void *stream);
+/* td3.py:299-304: sa2 = [s2 | clamp(max_a tanh(pre) + clamp(noise sigma, +-clip), +-max_a)], pre = actor_target's last pre-activation */
+int plentd3_target_action(const float *pre, const float *noise, const float *batch, float *sa2, float sigma, float clip, float max_a, int B, void *stream);
+/* twin last layers on h2 = [h2_a | h2_b] ([B][512]).  mode 0, td3.py:306-309: y = r + not_done gamma min(q_a, q_b).
+ * mode 1, td3.py:312-319: dq[b][c] = 2 (q_c - y) / B, loss[0] += sum (q_c - y)^2 / B, db3_c += sum_b dq[b][c] */
+int plentd3_q_heads(const float *h2, const float *w3a, const float *b3a, const float *w3b, const float *b3b, const float *batch, float *y, float *dq,
+                    float *loss, float *db3a, float *db3b, float gamma, int B, int mode, void *stream);
+/* back through last layer + ReLU: dh2 = dq w3 (h2 > 0); dq NULL = policy pass (td3.py:337), dq = -1/B, critic a only */
+int plentd3_dh2(const float *dq, const float *w3a, const float *w3b, const float *h2, float *dh2, int B, int ncrit, int h2_stride, void *stream);
+/* ReLU backward in place: g *= (h > 0) */
+int plentd3_relu_mask(float *g, const float *h, int B, int n, int h_stride, void *stream);
+/* out[j] += sum_b w[b] g[b][j] (w NULL: bias gradient; w = dq column, g = h2_c: the last layer's weight gradient); out zeroed by the caller */
+int plentd3_colsum(const float *g, int g_stride, const float *w, int w_stride, float *out, int B, int n, void *stream);
+/* nn.Linear backward (td3.py:323, :341): dW[n][k] += sum_b dH[b][n] X[b][k] and (db non-NULL) db[n] += sum_b dH[b][n]; split over the batch on
+ * the matrix cores (v_mfma_f32_32x32x2_f32), partial tiles added with float atomics: dW / db must be zeroed by the caller.  Strides in floats. */
+int plentd3_wgrad(const float *dH, int dh_stride, const float *X, int x_stride, float *dW, int dw_stride, float *db, int B, int N, int K, void *stream);
+/* td3.py:57: a = max_a tanh(pre), also written into sa_pi[:, 26:44] */
+int plentd3_tanh_out(const float *pre, float *a, float *sa_pi, float max_a, int B, void *stream);
+/* its backward: dz = dsa[:, 26:44] (max_a - a^2 / max_a) */
+int plentd3_dtanh(const float *dsa, const float *a, float *dz, float max_a, int B, void *stream);
+/* h = relu(h + bias) in place */
+int plentd3_bias_relu(float *h, const float *bias, int B, int n, void *stream);
+/* td3.py:348-356: target = tau param + (1 - tau) target over a flat parameter buffer */
+int plentd3_polyak(float *target, const float *param, float tau, int n, void *stream);
+const char *plentd3_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

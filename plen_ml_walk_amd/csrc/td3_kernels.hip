@@ -1,0 +1,335 @@
+// td3_kernels.hip -- hand-written HIP kernels (gfx950) for the non-GEMM work of one TD3 iteration.
+//
+// The reference's TD3Agent.train (plen_ros/src/plen_ros_helpers/td3.py:259-356) is ~170 small library kernels per iteration when
+// written with autograd (elementwise clamps, adds, fills, reductions, index ops, one launch each, ~5 us apiece on an MI355X: more GPU
+// time than the GEMMs).  plen_ml_walk_amd/td3_fused.py runs the same arithmetic with a hand-derived backward pass: the dense layers stay
+// library GEMMs (rocBLAS / hipBLASLt through torch.mm / addmm), everything between them is fused into the kernels below, each one
+// coalesced pass over its operands.  C ABI (include/plentd3.h): raw device pointers, sizes and a hipStream_t; no torch types.
+//
+// Layout conventions: activations are row-major [B][n]; a "strided" operand has an explicit row stride (it is a column slice of a wider
+// row-major matrix, e.g. the action columns 26..43 of a [B][44] state-action matrix, or one column of the packed replay rows).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/plentd3.h"
+
+#define TD3_H 256          // hidden width of actor and critics (td3.py:34-36, 80-88)
+
+static __device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---- K1: gather sampled replay rows (td3.py:166-193 ReplayBuffer.sample): out[b][:] = data[idx[b]][:] (row = s26 | a18 | s2_26 | r | not_done),
+//      and the state part again into the policy pass's state-action matrix sa_pi[b][0:26].  Also zeroes the loss accumulator.
+__global__ void k_gather(const float *__restrict__ data, const int64_t *__restrict__ idx, float *__restrict__ out, float *__restrict__ sa_pi, float *loss, int B) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0 && loss) { loss[0] = 0.f; loss[1] = 0.f; }
+    const int b = t / TD3_ROW, c = t % TD3_ROW;
+    if (b >= B) return;
+    const float v = data[(size_t)idx[b] * TD3_ROW + c];
+    out[(size_t)b * TD3_ROW + c] = v;
+    if (sa_pi && c < TD3_S) sa_pi[(size_t)b * TD3_SA + c] = v;
+}
+
+// ---- K2: target policy smoothing (td3.py:299-304): a2 = clamp(max_a * tanh(pre) + clamp(noise * sigma, +-clip), +-max_a); writes the
+//      target critics' input sa2 = [s2 | a2] (s2 taken from the gathered batch rows)
+__global__ void k_target_action(const float *__restrict__ pre, const float *__restrict__ noise, const float *__restrict__ batch, float *__restrict__ sa2,
+                                float sigma, float clip, float max_a, int B) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = t / TD3_SA, c = t % TD3_SA;
+    if (b >= B) return;
+    float v;
+    if (c < TD3_S) v = batch[(size_t)b * TD3_ROW + TD3_S + TD3_A + c];
+    else {
+        const int j = c - TD3_S;
+        const float n = fminf(fmaxf(noise[(size_t)b * TD3_A + j] * sigma, -clip), clip);
+        v = fminf(fmaxf(max_a * tanhf(pre[(size_t)b * TD3_A + j]) + n, -max_a), max_a);
+    }
+    sa2[(size_t)b * TD3_SA + c] = v;
+}
+
+// ---- K3 / K4: the twin critics' last layer (256 -> 1 each) as one wave per batch row over h2 = [h2_a | h2_b] ([B][512], post-ReLU):
+//      q_c = h2_c . w3_c + b3_c.
+//   mode 0 (targets, td3.py:306-309): y[b] = r + not_done * gamma * min(q_a, q_b)
+//   mode 1 (critic loss, td3.py:312-319): dq[b][c] = 2 (q_c - y[b]) / B  (d loss / d q_c for loss = mse(q_a,y) + mse(q_b,y));
+//                                         loss[0] += sum_c (q_c - y)^2 / B;  db3_c += dq (bias gradient of the last layer)
+__global__ void k_q_heads(const float *__restrict__ h2, const float *__restrict__ w3a, const float *__restrict__ b3a, const float *__restrict__ w3b,
+                          const float *__restrict__ b3b, const float *__restrict__ batch, float *__restrict__ y, float *__restrict__ dq, float *loss,
+                          float *db3a, float *db3b, float gamma, int B, int mode) {
+    // a wave reads a whole row pair [h2_a | h2_b] = 512 floats as two float4 per lane (lanes 0-31: critic a, 32-63: critic b); 4 rows per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane >> 5, l = lane & 31;
+    const float4 wv0 = *reinterpret_cast<const float4 *>((c ? w3b : w3a) + 4 * l), wv1 = *reinterpret_cast<const float4 *>((c ? w3b : w3a) + 128 + 4 * l);
+    const float bias = c ? b3b[0] : b3a[0];
+    float lsum = 0.f, gsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int b = (blockIdx.x * 4 + wave) * 4 + r;
+        if (b >= B) break;
+        const float *row = h2 + (size_t)b * (2 * TD3_H) + c * TD3_H;
+        const float4 h0 = *reinterpret_cast<const float4 *>(row + 4 * l), h1 = *reinterpret_cast<const float4 *>(row + 128 + 4 * l);
+        float sacc = h0.x * wv0.x + h0.y * wv0.y + h0.z * wv0.z + h0.w * wv0.w + h1.x * wv1.x + h1.y * wv1.y + h1.z * wv1.z + h1.w * wv1.w;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);              // within each 32-lane half
+        const float q = sacc + bias;                                               // q_a in lanes 0-31, q_b in lanes 32-63
+        const float qo = __shfl_xor(q, 32);
+        if (mode == 0) {
+            if (lane == 0) y[b] = batch[(size_t)b * TD3_ROW + TD3_ROW - 2] + batch[(size_t)b * TD3_ROW + TD3_ROW - 1] * gamma * fminf(q, qo);
+        } else {
+            const float e = q - y[b], inv = 1.f / (float)B;
+            if (l == 0) { dq[2 * b + c] = 2.f * e * inv; lsum += e * e * inv; gsum += 2.f * e * inv; }
+        }
+    }
+    if (mode == 1) {             // one atomic per workgroup and quantity
+        __shared__ float red[4][3];
+        if (lane == 0) { red[wave][0] = lsum; red[wave][1] = gsum; }
+        __syncthreads();
+        if (lane == 32) { red[wave][0] += lsum; red[wave][2] = gsum; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float s0 = 0, s1 = 0, s2 = 0;
+            for (int w = 0; w < 4; w++) { s0 += red[w][0]; s1 += red[w][1]; s2 += red[w][2]; }
+            atomicAdd(loss, s0); atomicAdd(db3a, s1); atomicAdd(db3b, s2);
+        }
+    }
+}
+
+// ---- K5: back through the last layer and the ReLU before it:  dh2[b][c*256 + j] = dq[b][c] * w3_c[j] * (h2[b][c*256 + j] > 0)
+//      dq == nullptr: the policy pass (td3.py:337 actor_loss = -Q1(s, pi(s)).mean()): dq = -1/B for every row, critic a only (ncrit = 1)
+__global__ void k_dh2(const float *__restrict__ dq, const float *__restrict__ w3a, const float *__restrict__ w3b, const float *__restrict__ h2,
+                      float *__restrict__ dh2, int B, int ncrit, int h2_stride) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int W = ncrit * TD3_H;
+    const int b = t / W, j = t % W;
+    if (b >= B) return;
+    const int c = j / TD3_H, jj = j % TD3_H;
+    const float g = dq ? dq[2 * b + c] : -1.f / (float)B;
+    const float h = h2[(size_t)b * h2_stride + j];
+    dh2[(size_t)b * W + j] = h > 0.f ? g * (c ? w3b[jj] : w3a[jj]) : 0.f;
+}
+
+// ---- K6: g *= (h > 0) in place (ReLU backward); g [B][n] contiguous, h has row stride hs
+__global__ void k_relu_mask(float *__restrict__ g, const float *__restrict__ h, int B, int n, int hs) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = t / n, j = t % n;
+    if (b >= B) return;
+    if (!(h[(size_t)b * hs + j] > 0.f)) g[(size_t)b * n + j] = 0.f;
+}
+
+// ---- K7: column sums over the batch (bias gradients):  out[j] += sum_b w[b] * g[b][j]   (w == nullptr: plain sum).  With w = dq column c and
+//      g = h2_c this is also the last layer's weight gradient dW3_c = h2_c^T dq_c (td3.py:323 critic_loss.backward()).
+//      Workgroup = 64 columns x 4 row-groups; grid.y splits the batch; one atomic per column and workgroup.  out must be zeroed beforehand.
+__global__ void k_colsum(const float *__restrict__ g, int gs, const float *__restrict__ w, int ws, float *__restrict__ out, int B, int n) {
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int rows_per = (B + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * rows_per, r1 = min(B, r0 + rows_per);
+    float s = 0.f;
+    if (col < n)
+        for (int b = r0 + rg; b < r1; b += 4) s += (w ? w[(size_t)b * ws] : 1.f) * g[(size_t)b * gs + col];
+    __shared__ float red[4][64];
+    red[rg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rg == 0 && col < n) atomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ---- K8: the actor's output nonlinearity (td3.py:57): a = max_a * tanh(pre), stored densely and into the action columns of sa_pi
+__global__ void k_tanh_out(const float *__restrict__ pre, float *__restrict__ a, float *__restrict__ sa_pi, float max_a, int B) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = t / TD3_A, j = t % TD3_A;
+    if (b >= B) return;
+    const float v = max_a * tanhf(pre[t]);
+    a[t] = v;
+    sa_pi[(size_t)b * TD3_SA + TD3_S + j] = v;
+}
+
+// ---- K9: back through it:  dz[b][j] = dsa[b][26 + j] * (max_a - a^2 / max_a)        (d/dx max_a tanh x = max_a (1 - tanh^2 x))
+__global__ void k_dtanh(const float *__restrict__ dsa, const float *__restrict__ a, float *__restrict__ dz, float max_a, int B) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = t / TD3_A, j = t % TD3_A;
+    if (b >= B) return;
+    const float v = a[t];
+    dz[t] = dsa[(size_t)b * TD3_SA + TD3_S + j] * (max_a - v * v / max_a);
+}
+
+// ---- K10: h = relu(h + bias) in place (used when the GEMM library offers no fused bias+ReLU epilogue)
+__global__ void k_bias_relu(float *__restrict__ h, const float *__restrict__ bias, int B, int n) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * n) return;
+    h[t] = fmaxf(h[t] + bias[t % n], 0.f);
+}
+
+// ---- K11: Polyak averaging of a whole flat parameter buffer (td3.py:348-356):  t = tau * p + (1 - tau) * t
+__global__ void k_polyak(float *__restrict__ t, const float *__restrict__ p, float tau, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) t[i] = tau * p[i] + (1.f - tau) * t[i];
+}
+
+// ---- K15: weight gradient of a dense layer on the matrix cores:  dW[n][k] += sum_b dH[b][n] X[b][k],  db[n] += sum_b dH[b][n]
+//      (td3.py:323 / :341 .backward() of nn.Linear).  The library GEMM for this shape -- a 4096-long reduction into a 256 x 256 (or smaller)
+//      result -- takes 24.5 us whatever the size (scripts/gpu_gemm_probe.py): too few output tiles to fill 256 CUs and no split over the
+//      reduction.  Here the batch is split into chunks: one wave per (32 x 32 output tile, chunk), v_mfma_f32_32x32x2_f32 with both operands
+//      straight from global memory -- lane l feeds A[i = l%32][kk = l/32] = dH[b + l/32][n0 + l%32] and B[kk][j = l%32] = X[b + l/32][k0 + l%32],
+//      two coalesced 128-byte row segments per operand and step, no transpose, no LDS -- and the partial tiles are added into dW (zeroed by
+//      the caller) with float atomics.  Waves of the first column tile also sum their dH operand: the bias gradient comes for free.
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void k_wgrad(const float *__restrict__ dH, int ds, const float *__restrict__ X, int xs, float *__restrict__ dW, int dws,
+                                               float *__restrict__ db, int B, int N, int K, int rows_per_chunk) {
+    // workgroup = one (32 x 32 output tile, batch chunk); its 4 waves take every 4th pair of batch rows and are summed through LDS, so that a
+    // tile costs one set of 1024 atomics per chunk instead of four
+    __shared__ float red[3][64][17];
+    __shared__ float bred[3][32];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nt = (N + 31) / 32, kt = (K + 31) / 32;
+    const int tile = blockIdx.x % (nt * kt), chunk = blockIdx.x / (nt * kt);
+    const int n0 = (tile / kt) * 32, k0 = (tile % kt) * 32;
+    const int b0 = chunk * rows_per_chunk, b1 = min(B, b0 + rows_per_chunk);
+    const int col = lane & 31, half = lane >> 5;
+    const bool na = n0 + col < N, ka = k0 + col < K;
+    floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float bsum = 0.f;
+    // wave w: row pairs b0 + 2 (4 u + w), in groups of 8 pairs (16 loads in flight before the first MFMA needs its operands)
+    int b = b0 + 2 * w;
+#pragma unroll 1
+    for (; b + 2 * 4 * 7 + 1 < b1; b += 2 * 4 * 8) {
+        float av[8], bv[8];
+        const float *pa = dH + (size_t)(b + half) * ds + n0 + col, *pb = X + (size_t)(b + half) * xs + k0 + col;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            av[u] = na ? pa[(size_t)(8 * u) * ds] : 0.f;
+            bv[u] = ka ? pb[(size_t)(8 * u) * xs] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0); bsum += av[u]; }
+    }
+    for (; b < b1; b += 8) {                          // ragged tail (also an odd last row)
+        const bool ra = b + half < b1;
+        const float a = (na && ra) ? dH[(size_t)(b + half) * ds + n0 + col] : 0.f, x = (ka && ra) ? X[(size_t)(b + half) * xs + k0 + col] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x, acc, 0, 0, 0); bsum += a;
+    }
+    bsum += __shfl_xor(bsum, 32);
+    if (w > 0) {
+#pragma unroll
+        for (int v = 0; v < 16; v++) red[w - 1][lane][v] = acc[v];
+        if (half == 0) bred[w - 1][col] = bsum;
+    }
+    __syncthreads();
+    if (w == 0) {
+        // result layout of the 32x32 MFMA: lane l holds column j = l % 32 and rows i = 8 * (v / 4) + 4 * (l / 32) + v % 4, v = 0..15
+        if (ka) {
+#pragma unroll
+            for (int v = 0; v < 16; v++) {
+                const int i = 8 * (v / 4) + 4 * half + (v % 4);
+                if (n0 + i < N) atomicAdd(dW + (size_t)(n0 + i) * dws + k0 + col, acc[v] + red[0][lane][v] + red[1][lane][v] + red[2][lane][v]);
+            }
+        }
+        if (db && k0 == 0 && half == 0 && na) atomicAdd(db + n0 + col, bsum + bred[0][col] + bred[1][col] + bred[2][col]);
+    }
+}
+
+// ---- K12: replay sampling without a host round trip (td3.py:175 np.random.randint(0, len, B)): idx[b] = min(floor(u[b] * filled), filled - 1),
+//      filled = min(*total, capacity), u uniform in [0, 1); then the gather of K1
+__global__ void k_sample_gather(const float *__restrict__ data, const float *__restrict__ u, const int64_t *__restrict__ total, int64_t capacity,
+                                int64_t *__restrict__ idx_out, float *__restrict__ out, float *__restrict__ sa_pi, float *loss, int B) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0 && loss) { loss[0] = 0.f; loss[1] = 0.f; }
+    const int b = t / TD3_ROW, c = t % TD3_ROW;
+    if (b >= B) return;
+    const int64_t filled = total[0] < capacity ? total[0] : capacity;
+    int64_t i = (int64_t)(u[b] * (float)filled);
+    i = i < filled - 1 ? i : filled - 1;
+    i = i > 0 ? i : 0;
+    if (c == 0 && idx_out) idx_out[b] = i;
+    const float v = data[(size_t)i * TD3_ROW + c];
+    out[(size_t)b * TD3_ROW + c] = v;
+    if (sa_pi && c < TD3_S) sa_pi[(size_t)b * TD3_SA + c] = v;
+}
+
+// ---- K13: exploration action of the collect phase (plen_td3.py:101-104): a = clamp(max_a tanh(pre) + noise * sigma, +-max_a)
+__global__ void k_explore(const float *__restrict__ pre, const float *__restrict__ noise, float *__restrict__ a, float sigma, float max_a, int n) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) a[t] = fminf(fmaxf(max_a * tanhf(pre[t]) + noise[t] * sigma, -max_a), max_a);
+}
+
+// ---- K14: write one vector step into the replay ring (plen_td3.py:109-113): row (total + e) % capacity = s | a | s2 | r | 1 - done_bool,
+//      done_bool = compute_done() fired AND the time limit did not (PLENVEC_DONE_TERMINAL = 1, _TIMELIMIT = 2)
+__global__ void k_store(float *__restrict__ data, const int64_t *__restrict__ total, int64_t capacity, const float *__restrict__ s, const float *__restrict__ a,
+                        const float *__restrict__ s2, const float *__restrict__ r, const uint8_t *__restrict__ done, int n) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = t / TD3_ROW, c = t % TD3_ROW;
+    if (e >= n) return;
+    const int64_t row = (total[0] + e) % capacity;
+    float v;
+    if (c < TD3_S) v = s[(size_t)e * TD3_S + c];
+    else if (c < TD3_SA) v = a[(size_t)e * TD3_A + c - TD3_S];
+    else if (c < TD3_SA + TD3_S) v = s2[(size_t)e * TD3_S + c - TD3_SA];
+    else if (c == TD3_ROW - 2) v = r[e];
+    else v = ((done[e] & 1) && !(done[e] & 2)) ? 0.f : 1.f;
+    data[(size_t)row * TD3_ROW + c] = v;
+}
+
+#define GRID(n_) dim3(((n_) + 255) / 256), dim3(256), 0, (hipStream_t)stream
+#define CHECK() do { hipError_t e_ = hipGetLastError(); return e_ == hipSuccess ? 0 : -(int)e_; } while (0)
+
+extern "C" {
+
+int plentd3_gather(const float *data, const int64_t *idx, float *out, float *sa_pi, float *loss, int B, void *stream) {
+    hipLaunchKernelGGL(k_gather, GRID(B * TD3_ROW), data, idx, out, sa_pi, loss, B); CHECK();
+}
+int plentd3_sample_gather(const float *data, const float *u, const int64_t *total, int64_t capacity, int64_t *idx_out, float *out, float *sa_pi, float *loss, int B, void *stream) {
+    hipLaunchKernelGGL(k_sample_gather, GRID(B * TD3_ROW), data, u, total, capacity, idx_out, out, sa_pi, loss, B); CHECK();
+}
+int plentd3_explore(const float *pre, const float *noise, float *a, float sigma, float max_a, int n, void *stream) {
+    hipLaunchKernelGGL(k_explore, GRID(n), pre, noise, a, sigma, max_a, n); CHECK();
+}
+int plentd3_store(float *data, const int64_t *total, int64_t capacity, const float *s, const float *a, const float *s2, const float *r, const uint8_t *done, int n, void *stream) {
+    hipLaunchKernelGGL(k_store, GRID(n * TD3_ROW), data, total, capacity, s, a, s2, r, done, n); CHECK();
+}
+int plentd3_wgrad(const float *dH, int dh_stride, const float *X, int x_stride, float *dW, int dw_stride, float *db, int B, int N, int K, void *stream) {
+    const int tiles = ((N + 31) / 32) * ((K + 31) / 32);
+    // batch chunks so that about 256-512 workgroups (4 waves each) run, at least 256 rows per workgroup
+    int chunks = (384 + tiles - 1) / tiles;
+    if (chunks > (B + 255) / 256) chunks = (B + 255) / 256;
+    if (chunks < 1) chunks = 1;
+    int rows = (B + chunks - 1) / chunks;
+    rows = (rows + 63) / 64 * 64;
+    chunks = (B + rows - 1) / rows;
+    hipLaunchKernelGGL(k_wgrad, dim3(tiles * chunks), dim3(256), 0, (hipStream_t)stream, dH, dh_stride, X, x_stride, dW, dw_stride, db, B, N, K, rows); CHECK();
+}
+int plentd3_target_action(const float *pre, const float *noise, const float *batch, float *sa2, float sigma, float clip, float max_a, int B, void *stream) {
+    hipLaunchKernelGGL(k_target_action, GRID(B * TD3_SA), pre, noise, batch, sa2, sigma, clip, max_a, B); CHECK();
+}
+int plentd3_q_heads(const float *h2, const float *w3a, const float *b3a, const float *w3b, const float *b3b, const float *batch, float *y, float *dq,
+                    float *loss, float *db3a, float *db3b, float gamma, int B, int mode, void *stream) {
+    hipLaunchKernelGGL(k_q_heads, dim3((B + 15) / 16), dim3(256), 0, (hipStream_t)stream, h2, w3a, b3a, w3b, b3b, batch, y, dq, loss, db3a, db3b, gamma, B, mode); CHECK();
+}
+int plentd3_dh2(const float *dq, const float *w3a, const float *w3b, const float *h2, float *dh2, int B, int ncrit, int h2_stride, void *stream) {
+    hipLaunchKernelGGL(k_dh2, GRID(B * ncrit * TD3_H), dq, w3a, w3b, h2, dh2, B, ncrit, h2_stride); CHECK();
+}
+int plentd3_relu_mask(float *g, const float *h, int B, int n, int h_stride, void *stream) {
+    hipLaunchKernelGGL(k_relu_mask, GRID(B * n), g, h, B, n, h_stride); CHECK();
+}
+int plentd3_colsum(const float *g, int g_stride, const float *w, int w_stride, float *out, int B, int n, void *stream) {
+    // enough workgroups to fill the chip (>= 512), at least 16 rows each
+    const int cb = (n + 63) / 64;
+    int splits = (512 + cb - 1) / cb;
+    if (splits > B / 16) splits = B / 16;
+    if (splits > 128) splits = 128;
+    if (splits < 1) splits = 1;
+    hipLaunchKernelGGL(k_colsum, dim3((n + 63) / 64, splits), dim3(256), 0, (hipStream_t)stream, g, g_stride, w, w_stride, out, B, n); CHECK();
+}
+int plentd3_tanh_out(const float *pre, float *a, float *sa_pi, float max_a, int B, void *stream) {
+    hipLaunchKernelGGL(k_tanh_out, GRID(B * TD3_A), pre, a, sa_pi, max_a, B); CHECK();
+}
+int plentd3_dtanh(const float *dsa, const float *a, float *dz, float max_a, int B, void *stream) {
+    hipLaunchKernelGGL(k_dtanh, GRID(B * TD3_A), dsa, a, dz, max_a, B); CHECK();
+}
+int plentd3_bias_relu(float *h, const float *bias, int B, int n, void *stream) {
+    hipLaunchKernelGGL(k_bias_relu, GRID(B * n), h, bias, B, n); CHECK();
+}
+int plentd3_polyak(float *target, const float *param, float tau, int n, void *stream) {
+    hipLaunchKernelGGL(k_polyak, GRID(n), target, param, tau, n); CHECK();
+}
+const char *plentd3_version(void) { return "plentd3 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -108,11 +108,15 @@ class ReplayBuffer(object):
         my_path = os.path.abspath(os.path.dirname(__file__))
         self.buffer_path = os.path.join(my_path, "../replay_buffer")
         n, dev = self.max_size, self.device
-        self.state = torch.empty(n, state_dim, dtype=torch.float32, device=dev)
-        self.action = torch.empty(n, action_dim, dtype=torch.float32, device=dev)
-        self.next_state = torch.empty(n, state_dim, dtype=torch.float32, device=dev)
-        self.reward = torch.empty(n, 1, dtype=torch.float32, device=dev)
-        self.not_done = torch.empty(n, 1, dtype=torch.float32, device=dev)
+        # one packed row per transition: state | action | next_state | reward | not_done (72 floats for PLEN); the five tensors of the
+        # reference's interface are column views of it, so a sampled batch is ONE gather (td3_fused / csrc/td3_kernels.hip k_gather)
+        sd, ad = int(state_dim), int(action_dim)
+        self.data = torch.empty(n, 2 * sd + ad + 2, dtype=torch.float32, device=dev)
+        self.state = self.data[:, 0:sd]
+        self.action = self.data[:, sd:sd + ad]
+        self.next_state = self.data[:, sd + ad:2 * sd + ad]
+        self.reward = self.data[:, 2 * sd + ad:2 * sd + ad + 1]
+        self.not_done = self.data[:, 2 * sd + ad + 1:2 * sd + ad + 2]
         self.storage = _StorageView(self)
         self._gen = None
 
@@ -194,14 +198,52 @@ class ReplayBuffer(object):
             self.ptr = int(z["ptr"]) % self.max_size
 
 
+def _flat_order(module):
+    """Parameters of a network in the order they are laid out in its flat buffers.  Critic: the twin Q networks' first layers (fc1, fc4)
+    and the biases of their first and second layers are adjacent, so that [fc1.weight; fc4.weight] is ONE [512, 44] matrix "W14" (one
+    GEMM for both networks' first layers, td3_fused.py) and [fc1.bias; fc4.bias] = "b14", [fc2.bias; fc5.bias] = "b25" single vectors."""
+    if isinstance(module, Critic):
+        m = module
+        return [m.fc1.weight, m.fc4.weight, m.fc1.bias, m.fc4.bias, m.fc2.weight, m.fc5.weight, m.fc2.bias, m.fc5.bias,
+                m.fc3.weight, m.fc6.weight, m.fc3.bias, m.fc6.bias]
+    return [p for p in module.parameters() if p.requires_grad]
+
+
+def _stacked_views(module, flat):
+    if not isinstance(module, Critic):
+        return {}
+    n1 = module.fc1.weight.numel()
+    h, k = module.fc1.weight.shape
+    o_b14 = 2 * n1
+    o_b25 = o_b14 + 2 * h + 2 * module.fc2.weight.numel()
+    return {"W14": flat[0:2 * n1].view(2 * h, k), "b14": flat[o_b14:o_b14 + 2 * h], "b25": flat[o_b25:o_b25 + 2 * h]}
+
+
+class _FlatParams(object):
+    """All parameters of one network as views into ONE contiguous buffer (layout: _flat_order): Polyak averaging is one pass over two flat
+    buffers, and the critics' stacked first-layer views exist.  state_dict keys, shapes and values are unchanged."""
+
+    def __init__(self, module):
+        params = _flat_order(module)
+        self.flat = torch.empty(sum(p.numel() for p in params), dtype=params[0].dtype, device=params[0].device)
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                v = self.flat[off:off + p.numel()].view_as(p)
+                v.copy_(p.data)
+                p.data = v
+                off += p.numel()
+        self.views = _stacked_views(module, self.flat)
+
+
 class _FlatGrads(object):
-    """All gradients of one network as views into ONE contiguous buffer, so a data-parallel step is
+    """All gradients of one network as views into ONE contiguous buffer (same layout as _FlatParams), so a data-parallel step is
     a single in-place all-reduce (critic 155 138 floats, actor 77 330: latency-bound messages, one
     bucket each)."""
 
     def __init__(self, module, data_parallel=True):
         self.data_parallel = data_parallel
-        params = [p for p in module.parameters() if p.requires_grad]
+        params = _flat_order(module)
         self.params = params
         total = sum(p.numel() for p in params)
         self.flat = torch.zeros(total, dtype=params[0].dtype, device=params[0].device)
@@ -209,6 +251,7 @@ class _FlatGrads(object):
         for p in params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
+        self.views = _stacked_views(module, self.flat)
 
     def zero(self):
         self.flat.zero_()
@@ -288,6 +331,8 @@ class TD3Agent(object):
         self._broadcast_parameters()                       # every rank starts from rank 0's initialisation
         self.actor_target = copy.deepcopy(self.actor)
         self.critic_target = copy.deepcopy(self.critic)
+        self._actor_flat, self._critic_flat = _FlatParams(self.actor), _FlatParams(self.critic)
+        self._actor_target_flat, self._critic_target_flat = _FlatParams(self.actor_target), _FlatParams(self.critic_target)
         self.actor_optimizer = torch.optim.Adam(self.actor.parameters(), lr=lr)
         self.critic_optimizer = torch.optim.Adam(self.critic.parameters(), lr=lr)
         self._actor_grads = _FlatGrads(self.actor, data_parallel)
@@ -329,9 +374,10 @@ class TD3Agent(object):
 
     # ---- checkpoints: the reference's four files per checkpoint (td3.py:358-376) -----------------
     def save(self, filename):
-        torch.save(self.critic.state_dict(), filename + "_critic")
+        # (parameters are views of one flat buffer per network: clone, so that each file holds its own tensors only)
+        torch.save({k: v.clone() for k, v in self.critic.state_dict().items()}, filename + "_critic")
         torch.save(self.critic_optimizer.state_dict(), filename + "_critic_optimizer")
-        torch.save(self.actor.state_dict(), filename + "_actor")
+        torch.save({k: v.clone() for k, v in self.actor.state_dict().items()}, filename + "_actor")
         torch.save(self.actor_optimizer.state_dict(), filename + "_actor_optimizer")
 
     def load(self, filename, load_optimizers=True):

@@ -1,0 +1,240 @@
+"""One TD3 iteration (reference plen_ros/src/plen_ros_helpers/td3.py:259-356) with a hand-derived backward pass: library GEMMs for
+the dense layers (torch.mm / addmm -> rocBLAS / hipBLASLt on the MI355X) and the hand-written HIP kernels of csrc/td3_kernels.hip
+(C ABI include/plentd3.h, bound here with ctypes) for everything between them.
+
+Why: the autograd formulation (td3.td3_update) is ~170 small kernels per iteration -- clamps, adds, fills, reductions, index ops, ~5 us
+each -- and spends more GPU time in them than in its GEMMs.  This path issues 14 GEMMs + 12 fused kernels for a critic iteration and
+26 + 22 for a critic + actor + targets iteration, on the SAME parameters, gradient buckets and optimisers as the autograd path
+(TD3Agent keeps each network's parameters and gradients in one flat buffer; the twin critics' first layers are adjacent in it, so both
+Q networks' first layers are one GEMM).  tests/test_robustness_gpu.py checks it against the reference's golden iteration and against
+td3.td3_update.  GPU only: there is no CPU build of the kernels (the autograd path is the CPU / gloo implementation)."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libplentd3.so")
+EXPORTS = ["plentd3_gather", "plentd3_sample_gather", "plentd3_explore", "plentd3_store", "plentd3_target_action", "plentd3_q_heads", "plentd3_dh2", "plentd3_relu_mask", "plentd3_colsum", "plentd3_wgrad",
+           "plentd3_tanh_out", "plentd3_dtanh", "plentd3_bias_relu", "plentd3_polyak", "plentd3_version"]
+ROW, S, A, SA, H = 72, 26, 18, 44, 256
+_lib = None
+
+
+class PlenTd3Error(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PlenTd3Error("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950)" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name in EXPORTS:
+            getattr(lib, name)
+        lib.plentd3_version.restype = C.c_char_p
+        vp, i, f = C.c_void_p, C.c_int, C.c_float
+        lib.plentd3_gather.argtypes = [vp, vp, vp, vp, vp, i, vp]
+        lib.plentd3_sample_gather.argtypes = [vp, vp, vp, C.c_int64, vp, vp, vp, vp, i, vp]
+        lib.plentd3_explore.argtypes = [vp, vp, vp, f, f, i, vp]
+        lib.plentd3_store.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, i, vp]
+        lib.plentd3_target_action.argtypes = [vp, vp, vp, vp, f, f, f, i, vp]
+        lib.plentd3_q_heads.argtypes = [vp] * 11 + [f, i, i, vp]
+        lib.plentd3_dh2.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp]
+        lib.plentd3_relu_mask.argtypes = [vp, vp, i, i, i, vp]
+        lib.plentd3_colsum.argtypes = [vp, i, vp, i, vp, i, i, vp]
+        lib.plentd3_wgrad.argtypes = [vp, i, vp, i, vp, i, vp, i, i, i, vp]
+        lib.plentd3_tanh_out.argtypes = [vp, vp, vp, f, i, vp]
+        lib.plentd3_dtanh.argtypes = [vp, vp, vp, f, i, vp]
+        lib.plentd3_bias_relu.argtypes = [vp, vp, i, i, vp]
+        lib.plentd3_polyak.argtypes = [vp, vp, f, i, vp]
+        _lib = lib
+    return _lib
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _chk(rc):
+    if rc != 0:
+        raise PlenTd3Error("libplentd3 kernel launch failed: HIP error %d" % -rc)
+
+
+class FusedTD3(object):
+    """update(data, idx, with_policy) == td3.td3_update(agent, (data rows idx split into s, a, s2, r, not_done), with_policy)."""
+
+    def __init__(self, agent):
+        if agent.device.type != "cuda":
+            raise PlenTd3Error("FusedTD3 needs the agent on a HIP device")
+        self.agent = agent
+        self.lib = load()
+        self.dev = agent.device
+        # does the GEMM library fuse bias + ReLU into the epilogue here?  (hipBLASLt: yes; verified numerically once)
+        self.epilogue = False
+        try:
+            x = torch.randn(8, 12, device=self.dev); w = torch.randn(5, 12, device=self.dev); b = torch.randn(5, device=self.dev)
+            y = torch._addmm_activation(b, x, w.t())
+            self.epilogue = bool(torch.allclose(y, torch.relu(torch.addmm(b, x, w.t())), atol=1e-5))
+        except Exception:
+            self.epilogue = False
+
+    def _wgrad(self, dh, x, gw, gb):
+        """gw += dh^T x, gb += column sums of dh (gw, gb: zeroed views of a flat gradient bucket); dh, x may be column slices."""
+        B, N = dh.shape
+        K = x.shape[1]
+        assert dh.stride(1) == 1 and x.stride(1) == 1 and gw.is_contiguous() and gw.shape == (N, K)
+        _chk(self.lib.plentd3_wgrad(_p(dh), dh.stride(0), _p(x), x.stride(0), _p(gw), K, _p(gb), B, N, K, self._stream()))
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def _lin_relu(self, x, w, b, out=None):
+        if self.epilogue:
+            return torch._addmm_activation(b, x, w.t(), out=out) if out is not None else torch._addmm_activation(b, x, w.t())
+        h = torch.addmm(b, x, w.t(), out=out) if out is not None else torch.addmm(b, x, w.t())
+        return h.relu_() if out is None else h
+
+    def update(self, data, idx, with_policy, noise=None, all_reduce=True, total=None):
+        """The whole iteration; with torch.distributed initialised the two gradient buckets are averaged over ranks before their Adam steps."""
+        ag = self.agent
+        loss = self.critic_backward(data, idx, noise, total)
+        if all_reduce:
+            ag._critic_grads.all_reduce_mean()
+        ag.critic_optimizer.step()
+        ag.last_critic_loss = loss
+        if with_policy:
+            self.policy_backward()
+            if all_reduce:
+                ag._actor_grads.all_reduce_mean()
+            ag.actor_optimizer.step()
+            ag.last_actor_loss = None          # (-mean Q1 itself is not needed for the update; the autograd path reports it)
+            self.polyak()
+        return loss
+
+    def explore(self, state, sigma):
+        """Collect-phase action (plen_td3.py:101-104): clamp(actor(state) + N(0, sigma), +-max_action) -- 3 GEMMs, the noise draw, one fused kernel."""
+        ag = self.agent
+        ac = ag.actor
+        with torch.no_grad():
+            p2 = self._lin_relu(self._lin_relu(state, ac.fc1.weight, ac.fc1.bias), ac.fc2.weight, ac.fc2.bias)
+            pre = torch.addmm(ac.fc3.bias, p2, ac.fc3.weight.t())
+            noise = torch.randn_like(pre)
+            a = torch.empty_like(pre)
+            _chk(self.lib.plentd3_explore(_p(pre), _p(noise), _p(a), float(sigma), float(ag.max_action), pre.numel(), self._stream()))
+        return a
+
+    def store(self, data, total, state, action, next_obs, reward, done):
+        """One vector step into the packed replay ring at positions (total + e) % capacity (plen_td3.py:109-113); `total` = device int64 scalar."""
+        n = int(state.shape[0])
+        for t in (state, action, next_obs, reward):
+            assert t.dtype == torch.float32 and t.is_contiguous()
+        assert done.dtype == torch.uint8 and total.dtype == torch.long
+        _chk(self.lib.plentd3_store(_p(data), _p(total), int(data.shape[0]), _p(state), _p(action), _p(next_obs), _p(reward), _p(done), n, self._stream()))
+
+    def critic_backward(self, data, idx, noise=None, total=None):
+        """Sample, targets, critic forward / loss / backward: gradients land in the critic's flat bucket.  Returns the loss (device scalar).
+        idx: LongTensor [B] of replay rows, or an int B with `total` (device int64 scalar: transitions written so far) to draw them here."""
+        ag, lib, st = self.agent, self.lib, self._stream()
+        dev = self.dev
+        assert data.dtype == torch.float32 and data.is_contiguous() and data.shape[1] == ROW
+        new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        if isinstance(idx, int):
+            B = idx
+            batch, sa_pi, loss = new(B, ROW), new(B, SA), new(2)
+            u = torch.rand(B, device=dev)
+            _chk(lib.plentd3_sample_gather(_p(data), _p(u), _p(total), int(data.shape[0]), None, _p(batch), _p(sa_pi), _p(loss), B, st))
+        else:
+            B = int(idx.shape[0])
+            assert idx.dtype == torch.long
+            batch, sa_pi, loss = new(B, ROW), new(B, SA), new(2)
+            _chk(lib.plentd3_gather(_p(data), _p(idx), _p(batch), _p(sa_pi), _p(loss), B, st))
+        s, sa, s2 = batch[:, :S], batch[:, :SA], batch[:, SA:SA + S]
+        relu_both = not self.epilogue
+        with torch.no_grad():
+            # ---- target policy smoothing + clipped double-Q target (td3.py:277-309) ----
+            at, ct = ag.actor_target, ag.critic_target
+            a1 = self._lin_relu(s2, at.fc1.weight, at.fc1.bias)
+            a2 = self._lin_relu(a1, at.fc2.weight, at.fc2.bias)
+            pre = torch.addmm(at.fc3.bias, a2, at.fc3.weight.t())
+            if noise is None:
+                noise = torch.randn(B, A, device=dev)
+            sa2 = new(B, SA)
+            _chk(lib.plentd3_target_action(_p(pre), _p(noise.contiguous()), _p(batch), _p(sa2), float(ag.policy_noise), float(ag.noise_clip), float(ag.max_action), B, st))
+            tv = ag._critic_target_flat.views
+            h1 = self._lin_relu(sa2, tv["W14"], tv["b14"])                       # both target critics' first layers in one GEMM
+            h2 = new(B, 2 * H)
+            self._lin_relu(h1[:, :H], ct.fc2.weight, ct.fc2.bias, out=h2[:, :H])
+            self._lin_relu(h1[:, H:], ct.fc5.weight, ct.fc5.bias, out=h2[:, H:])
+            if relu_both:
+                h2.relu_()
+            y = new(B)
+            _chk(lib.plentd3_q_heads(_p(h2), _p(ct.fc3.weight), _p(ct.fc3.bias), _p(ct.fc6.weight), _p(ct.fc6.bias), _p(batch), _p(y), None, None, None, None,
+                                     float(ag.discount), B, 0, st))
+            # ---- critic forward, loss, backward (td3.py:312-331) ----
+            cr = ag.critic
+            cv, gv = ag._critic_flat.views, ag._critic_grads.views
+            ag._critic_grads.zero()
+            c1 = self._lin_relu(sa, cv["W14"], cv["b14"])
+            c2 = new(B, 2 * H)
+            self._lin_relu(c1[:, :H], cr.fc2.weight, cr.fc2.bias, out=c2[:, :H])
+            self._lin_relu(c1[:, H:], cr.fc5.weight, cr.fc5.bias, out=c2[:, H:])
+            if relu_both:
+                c2.relu_()
+            dq = new(B, 2)
+            _chk(lib.plentd3_q_heads(_p(c2), _p(cr.fc3.weight), _p(cr.fc3.bias), _p(cr.fc6.weight), _p(cr.fc6.bias), _p(batch), _p(y), _p(dq), _p(loss),
+                                     _p(cr.fc3.bias.grad), _p(cr.fc6.bias.grad), float(ag.discount), B, 1, st))
+            # last layer weight gradients: dW3_c = h2_c^T dq_c
+            _chk(lib.plentd3_colsum(_p(c2), 2 * H, _p(dq), 2, _p(cr.fc3.weight.grad), B, H, st))
+            _chk(lib.plentd3_colsum(C.c_void_p(c2.data_ptr() + 4 * H), 2 * H, C.c_void_p(dq.data_ptr() + 4), 2, _p(cr.fc6.weight.grad), B, H, st))
+            dh2 = new(B, 2 * H)
+            _chk(lib.plentd3_dh2(_p(dq), _p(cr.fc3.weight), _p(cr.fc6.weight), _p(c2), _p(dh2), B, 2, 2 * H, st))
+            self._wgrad(dh2[:, :H], c1[:, :H], cr.fc2.weight.grad, cr.fc2.bias.grad)
+            self._wgrad(dh2[:, H:], c1[:, H:], cr.fc5.weight.grad, cr.fc5.bias.grad)
+            dh1 = new(B, 2 * H)
+            torch.mm(dh2[:, :H], cr.fc2.weight, out=dh1[:, :H])
+            torch.mm(dh2[:, H:], cr.fc5.weight, out=dh1[:, H:])
+            _chk(lib.plentd3_relu_mask(_p(dh1), _p(c1), B, 2 * H, 2 * H, st))
+            self._wgrad(dh1, sa, gv["W14"], gv["b14"])
+        self._saved = (s, sa_pi, B)
+        return loss[0]
+
+    def policy_backward(self):
+        """Delayed policy gradient through the (already updated) critic's Q1 (td3.py:334-345): gradients land in the actor's flat bucket."""
+        ag, lib, st = self.agent, self.lib, self._stream()
+        dev = self.dev
+        s, sa_pi, B = self._saved
+        new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        cr = ag.critic
+        if True:
+            with torch.no_grad():
+                ac = ag.actor
+                ag._actor_grads.zero()
+                p1 = self._lin_relu(s, ac.fc1.weight, ac.fc1.bias)
+                p2 = self._lin_relu(p1, ac.fc2.weight, ac.fc2.bias)
+                pre = torch.addmm(ac.fc3.bias, p2, ac.fc3.weight.t())
+                a_pi = new(B, A)
+                _chk(lib.plentd3_tanh_out(_p(pre), _p(a_pi), _p(sa_pi), float(ag.max_action), B, st))
+                g1 = self._lin_relu(sa_pi, cr.fc1.weight, cr.fc1.bias)
+                g2 = self._lin_relu(g1, cr.fc2.weight, cr.fc2.bias)
+                dg2 = new(B, H)
+                _chk(lib.plentd3_dh2(None, _p(cr.fc3.weight), None, _p(g2), _p(dg2), B, 1, H, st))       # d(-mean Q1)/d g2
+                dg1 = torch.mm(dg2, cr.fc2.weight)
+                _chk(lib.plentd3_relu_mask(_p(dg1), _p(g1), B, H, H, st))
+                dsa = torch.mm(dg1, cr.fc1.weight)                                                        # [B, 44]; columns 26.. = d/d action
+                dz = new(B, A)
+                _chk(lib.plentd3_dtanh(_p(dsa), _p(a_pi), _p(dz), float(ag.max_action), B, st))
+                self._wgrad(dz, p2, ac.fc3.weight.grad, ac.fc3.bias.grad)
+                dp2 = torch.mm(dz, ac.fc3.weight)
+                _chk(lib.plentd3_relu_mask(_p(dp2), _p(p2), B, H, H, st))
+                self._wgrad(dp2, p1, ac.fc2.weight.grad, ac.fc2.bias.grad)
+                dp1 = torch.mm(dp2, ac.fc2.weight)
+                _chk(lib.plentd3_relu_mask(_p(dp1), _p(p1), B, H, H, st))
+                self._wgrad(dp1, s, ac.fc1.weight.grad, ac.fc1.bias.grad)
+
+    def polyak(self):
+        """target = tau * online + (1 - tau) * target for critic then actor (td3.py:348-356), one pass per network over the flat buffers."""
+        ag, st = self.agent, self._stream()
+        for flat, tflat in ((ag._critic_flat, ag._critic_target_flat), (ag._actor_flat, ag._actor_target_flat)):
+            _chk(self.lib.plentd3_polyak(_p(tflat.flat), _p(flat.flat), float(ag.tau), flat.flat.numel(), st))

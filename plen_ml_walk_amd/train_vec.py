@@ -43,8 +43,8 @@ def save_training(agent, trainer, prefix):
     """Checkpoint = the reference's four files (td3.py:358-366) + the two target networks (which the reference's
     save/load silently drops, SURVEY App. A #10) + a small JSON with the loop counters."""
     agent.save(prefix)
-    torch.save(agent.actor_target.state_dict(), prefix + "_actor_target")
-    torch.save(agent.critic_target.state_dict(), prefix + "_critic_target")
+    torch.save({k: v.clone() for k, v in agent.actor_target.state_dict().items()}, prefix + "_actor_target")
+    torch.save({k: v.clone() for k, v in agent.critic_target.state_dict().items()}, prefix + "_critic_target")
     with open(prefix + "_trainer.json", "w") as fh:
         json.dump({"env_steps": int(trainer.env_steps), "grad_steps": int(trainer.grad_steps), "total_it": int(agent.total_it)}, fh)
 
@@ -199,10 +199,15 @@ class GraphedVecTD3Trainer(object):
     eager runs ARE the loop's real iterations, so the collect/update cadence and policy_freq alternation are exactly the eager
     trainer's from the first step on."""
 
-    def __init__(self, env, agent, replay, start_timesteps=10000, expl_noise=0.1, batch_size=4096, updates_per_step=1, seed=0):
+    def __init__(self, env, agent, replay, start_timesteps=10000, expl_noise=0.1, batch_size=4096, updates_per_step=1, seed=0, fused=True):
         import torch.distributed as dist
         from . import td3 as T
         assert agent.device.type == "cuda"
+        # fused = the hand-derived update of td3_fused.py (library GEMMs + the HIP kernels of csrc/td3_kernels.hip); False = autograd (td3.td3_update)
+        self.fused = None
+        if fused:
+            from .td3_fused import FusedTD3
+            self.fused = FusedTD3(agent)
         self.env, self.agent, self.replay = env, agent, replay
         self.start_timesteps, self.expl_noise = start_timesteps, expl_noise
         self.batch_size, self.updates_per_step = batch_size, updates_per_step
@@ -231,44 +236,65 @@ class GraphedVecTD3Trainer(object):
         def collect(random_actions):
             if random_actions:
                 action = torch.rand(n, 18, device=dev) * 2 - 1
+            elif self.fused is not None:
+                action = self.fused.explore(self.state, agent.max_action * expl_noise)
             else:
                 with torch.no_grad():
                     action = agent.actor(self.state)
                     action = (action + torch.randn_like(action) * (agent.max_action * expl_noise)).clamp(-agent.max_action, agent.max_action)
             next_obs, reward, done, info = env.step(action)
-            idx = (self.total_t + self.arange_n) % replay.max_size
-            terminal = ((done & 1) != 0) & ((done & 2) == 0)
-            replay.state.index_copy_(0, idx, self.state)
-            replay.action.index_copy_(0, idx, action)
-            replay.next_state.index_copy_(0, idx, next_obs.to(torch.float32))
-            replay.reward.index_copy_(0, idx, reward.to(torch.float32).reshape(n, 1))
-            replay.not_done.index_copy_(0, idx, 1.0 - terminal.to(torch.float32).reshape(n, 1))
+            if self.fused is not None and next_obs.dtype == torch.float32:
+                self.fused.store(replay.data, self.total_t, self.state, action, next_obs, reward, done)      # one kernel: packed rows into the ring
+            else:
+                idx = (self.total_t + self.arange_n) % replay.max_size
+                terminal = ((done & 1) != 0) & ((done & 2) == 0)
+                # one packed row per transition (ReplayBuffer.data): state | action | next_state | reward | not_done
+                rows = torch.cat([self.state, action, next_obs.to(torch.float32), reward.to(torch.float32).reshape(n, 1),
+                                  1.0 - terminal.to(torch.float32).reshape(n, 1)], 1)
+                replay.data.index_copy_(0, idx, rows)
             self.total_t += n
             self.state.copy_(info["obs"])
 
-        def sample():
+        def sample_indices():
             size_t = torch.clamp(self.total_t, max=replay.max_size)
             ind = (torch.rand(batch_size, device=dev) * size_t).long().clamp_(max=replay.max_size - 1)
-            ind = torch.minimum(ind, size_t - 1)
+            return torch.minimum(ind, size_t - 1)
+
+        def sample():
+            ind = sample_indices()
             return (replay.state[ind], replay.action[ind], replay.next_state[ind], replay.reward[ind], replay.not_done[ind])
 
+        fz = self.fused
+
         def update(with_policy):                       # one rank, or collectives captured: the whole iteration in one graph
-            loss = T.td3_update(agent, sample(), with_policy, all_reduce=self.world > 1)
+            if fz is not None:
+                loss = fz.update(replay.data, batch_size, with_policy, all_reduce=self.world > 1, total=self.total_t)
+            else:
+                loss = T.td3_update(agent, sample(), with_policy, all_reduce=self.world > 1)
             self._critic_loss.copy_(loss)
 
         # --- segments for eager collectives between graph replays (world > 1) ---
         def seg_critic_backward():
-            self._batch = sample()
-            self._critic_loss.copy_(T.td3_critic_backward(agent, self._batch))
+            if fz is not None:
+                self._critic_loss.copy_(fz.critic_backward(replay.data, batch_size, total=self.total_t))
+            else:
+                self._batch = sample()
+                self._critic_loss.copy_(T.td3_critic_backward(agent, self._batch))
 
         def seg_critic_step(with_policy):
             agent.critic_optimizer.step()
             if with_policy:
-                T.td3_actor_backward(agent, self._batch)
+                if fz is not None:
+                    fz.policy_backward()
+                else:
+                    T.td3_actor_backward(agent, self._batch)
 
         def seg_actor_step():
             agent.actor_optimizer.step()
-            T.td3_polyak(agent)
+            if fz is not None:
+                fz.polyak()
+            else:
+                T.td3_polyak(agent)
 
         self._collect_fn, self._update_fn = collect, update
         self._segs = (seg_critic_backward, seg_critic_step, seg_actor_step)

@@ -27,6 +27,23 @@ def test_header_symbols_are_exported(lib):
         assert hasattr(lib, n), n
 
 
+def test_td3_kernel_library_exports_its_header():
+    """libplentd3.so (fused TD3 update kernels): loads without a GPU and exports exactly what include/plentd3.h declares."""
+    from plen_ml_walk_amd.build import build_td3_kernels
+    from plen_ml_walk_amd import td3_fused
+    build_td3_kernels()
+    hdr = open(os.path.join(ROOT, "include", "plentd3.h")).read()
+    names = sorted(set(re.findall(r"\b(plentd3_[a-z0-9_]+)\s*\(", hdr)))
+    assert sorted(td3_fused.EXPORTS) == names and len(names) == 15
+    lib = td3_fused.load()
+    for n in names:
+        assert hasattr(lib, n), n
+    if not torch.cuda.is_available():
+        from plen_ml_walk_amd.td3 import TD3Agent
+        with pytest.raises(td3_fused.PlenTd3Error):
+            td3_fused.FusedTD3(TD3Agent(26, 18, 1.0, device="cpu"))
+
+
 def test_default_cfg_matches_reference_constants(lib):
     from plen_ml_walk_amd import _lib
     c = _lib.default_cfg(False)

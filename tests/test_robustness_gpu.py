@@ -226,3 +226,98 @@ def test_graphed_trainer_cadence_and_resumed_optimizer_state(tmp_path):
     assert float(next(iter(agent.actor_optimizer.state_dict()["state"].values()))["step"]) == 7.0
     assert torch.isfinite(agent.last_critic_loss)
     env2.close()
+
+
+# ------------------------------------------------------------------------------------------------ fused TD3 update (td3_fused.py + csrc/td3_kernels.hip)
+def test_fused_td3_update_matches_the_reference_golden_iterations(golden_dir):
+    """The hand-derived update (library GEMMs + the HIP kernels of libplentd3.so) on the reference's golden problem: same initial parameters,
+    sampled indices and smoothing noise as td3.py produced -> the same parameters and targets after iteration 1 (critic only) and
+    iteration 2 (critic, actor, Polyak), to the tolerance the autograd path is held to."""
+    from plen_ml_walk_amd.td3_fused import FusedTD3
+    g, a, buf = _golden_agent(golden_dir, "cuda")
+    fz = FusedTD3(a)
+    for k in range(2):
+        idx = torch.as_tensor(g["idx"][k]).cuda().long()
+        noise = torch.as_tensor(g["noise"][k]).cuda()
+        a.total_it += 1
+        loss = fz.update(buf.data, idx, with_policy=a.total_it % a.policy_freq == 0, noise=noise, all_reduce=False)
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss)
+        _check_against_golden(g, a, k)
+
+
+@pytest.mark.parametrize("B", [256, 4096])
+def test_fused_td3_update_equals_autograd_update(B):
+    """Same random problem through td3.td3_update (autograd) and FusedTD3.update: loss, every gradient and every parameter / target after a
+    critic-only and a critic + policy iteration agree to f32 GEMM rounding (hence also the flat-buffer layout and the stacked first layers)."""
+    from plen_ml_walk_amd import td3 as T
+    from plen_ml_walk_amd.td3_fused import FusedTD3
+    torch.manual_seed(3)
+    ref = T.TD3Agent(26, 18, 1.0, data_parallel=False)
+    fus = T.TD3Agent(26, 18, 1.0, data_parallel=False)
+    for dst, src in ((fus.actor, ref.actor), (fus.critic, ref.critic), (fus.actor_target, ref.actor_target), (fus.critic_target, ref.critic_target)):
+        dst.load_state_dict(src.state_dict())
+    fz = FusedTD3(fus)
+    buf = T.ReplayBuffer(3 * B)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    n = 2 * B
+    buf.add_batch(torch.randn(n, 26, generator=gen, device="cuda"), torch.rand(n, 18, generator=gen, device="cuda") * 2 - 1,
+                  torch.randn(n, 26, generator=gen, device="cuda"), torch.randn(n, generator=gen, device="cuda") * 3,
+                  (torch.rand(n, generator=gen, device="cuda") < 0.1).float())
+    for it in range(4):
+        idx = torch.randint(0, n, (B,), generator=gen, device="cuda")
+        noise = torch.randn(B, 18, generator=gen, device="cuda")
+        wp = (it + 1) % 2 == 0
+        lr_ = T.td3_update(ref, buf.sample(B, ind=idx), wp, noise=noise, all_reduce=False)
+        lf_ = fz.update(buf.data, idx, wp, noise=noise, all_reduce=False)
+        torch.cuda.synchronize()
+        assert abs(float(lr_) - float(lf_)) <= 1e-4 * max(1.0, abs(float(lr_)))
+        rel = lambda x, y: float((x - y).abs().max() / y.abs().max().clamp_min(1e-12))
+        if not wp:          # (on a policy iteration autograd's actor_loss.backward() also adds into the critic's .grad; nothing reads that)
+            for pr, pf in zip(ref.critic.parameters(), fus.critic.parameters()):
+                assert rel(pf.grad, pr.grad) <= 2e-4, (it, "critic grad")
+        if wp:
+            for pr, pf in zip(ref.actor.parameters(), fus.actor.parameters()):
+                assert rel(pf.grad, pr.grad) <= 2e-4, (it, "actor grad")
+        for nr, nf in ((ref.actor, fus.actor), (ref.critic, fus.critic), (ref.actor_target, fus.actor_target), (ref.critic_target, fus.critic_target)):
+            for (k, vr), (_, vf) in zip(nr.state_dict().items(), nf.state_dict().items()):
+                assert float((vr - vf).abs().max()) <= 2e-5, (it, k)
+
+
+def test_graph_trainer_fused_and_autograd_updates_learn_alike():
+    """GraphedVecTD3Trainer with fused=True (default) and fused=False on the same seeds: both run, the ring fills identically, critic
+    losses are finite and of the same size after 30 iterations (the two differ in RNG consumption, so no bitwise claim)."""
+    from plen_ml_walk_amd.td3 import ReplayBuffer, TD3Agent
+    from plen_ml_walk_amd.train_vec import GraphedVecTD3Trainer
+    n = 256
+    out = {}
+    for fused in (True, False):
+        torch.manual_seed(0)
+        env = _env(n); agent = TD3Agent(26, 18, 1.0); replay = ReplayBuffer(20000)
+        tr = GraphedVecTD3Trainer(env, agent, replay, start_timesteps=512, batch_size=256, updates_per_step=1, seed=0, fused=fused)
+        for _ in range(32):
+            tr.step()
+        torch.cuda.synchronize()
+        assert tr.env_steps == 32 * n and tr.grad_steps == 31 and replay.size == 32 * n
+        assert torch.isfinite(agent.last_critic_loss) and torch.isfinite(replay.data[:replay.size]).all()
+        out[fused] = float(agent.last_critic_loss)
+        env.close()
+    assert 0.2 <= out[True] / out[False] <= 5.0
+
+
+@pytest.mark.parametrize("B,N,K", [(4096, 256, 256), (4096, 512, 44), (4096, 256, 26), (4096, 18, 256), (300, 256, 256), (77, 33, 45)])
+def test_mfma_weight_gradient_kernel(B, N, K):
+    """k_wgrad (v_mfma_f32_32x32x2_f32, batch split, atomics) against torch: dW = dH^T X and db = column sums of dH, on column-slice operands,
+    ragged tile and batch sizes included.  f32 MFMA with f32 accumulation: agreement to summation-order rounding."""
+    from plen_ml_walk_amd.td3_fused import FusedTD3
+    from plen_ml_walk_amd.td3 import TD3Agent
+    fz = FusedTD3(TD3Agent(26, 18, 1.0, data_parallel=False))
+    g = torch.Generator(device="cuda").manual_seed(B + N + K)
+    dh_full = torch.randn(B, N + 7, generator=g, device="cuda"); x_full = torch.randn(B, K + 5, generator=g, device="cuda")
+    dh, x = dh_full[:, 3:3 + N], x_full[:, 2:2 + K]
+    gw = torch.zeros(N, K, device="cuda"); gb = torch.zeros(N, device="cuda")
+    fz._wgrad(dh, x, gw, gb)
+    torch.cuda.synchronize()
+    want_w = dh.double().t() @ x.double(); want_b = dh.double().sum(0)
+    assert float((gw.double() - want_w).abs().max()) <= 2e-5 * float(want_w.abs().max()) + 1e-4
+    assert float((gb.double() - want_b).abs().max()) <= 2e-5 * float(want_b.abs().max()) + 1e-4
