@@ -29,10 +29,12 @@ def setup_distributed():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # PLEN_DIST_BACKEND=gloo: development override (two ranks sharing ONE GPU cannot use RCCL; gloo moves CUDA tensors through the host)
+        backend = os.environ.get("PLEN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-            dist.init_process_group(backend, device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+            lr = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(lr)
+            dist.init_process_group(backend, device_id=torch.device("cuda", lr))
         else:
             dist.init_process_group(backend)
     from . import sharding
@@ -133,7 +135,7 @@ def main(argv=None):
     from .td3 import ReplayBuffer, TD3Agent
     import torch.distributed as dist
     rank, world = setup_distributed()
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
     torch.manual_seed(a.seed)                                     # identical init on every rank (then broadcast anyway)
     env = PlenVecEnv(a.envs, device=dev)
