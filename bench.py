@@ -283,11 +283,17 @@ def main():
     import torch.distributed as dist
     from plen_ml_walk_amd import sharding
     rank, world, local_rank = sharding.world_info()
+    backend = os.environ.get("PLEN_DIST_BACKEND", "nccl")        # "gloo": development only (several ranks sharing one GPU, scripts/gpu_two_ranks_one_gpu.sh)
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)            # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     legs_wanted = [x for x in a.legs.split(",") if x]
     head = env_leg(a, a.dtype, dev, rank, world, dist, a.steps, a.warmup)
