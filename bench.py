@@ -219,17 +219,31 @@ def td3_leg(a, dev, rank, world, dist, steps, warmup):
     from plen_ml_walk_amd import sharding
     from plen_ml_walk_amd.vec_env import PlenVecEnv
     from plen_ml_walk_amd.td3 import ReplayBuffer, TD3Agent
-    from plen_ml_walk_amd.train_vec import GraphedVecTD3Trainer
+    from plen_ml_walk_amd.train_vec import GraphedVecTD3Trainer, PipelinedVecTD3Trainer
     n = a.envs_per_gpu
     torch.manual_seed(0)
-    env = PlenVecEnv(n, device=dev)
-    if a.dr:
-        gd = torch.Generator(device=dev).manual_seed(1000 + rank)
-        env.set_params(mass_scale=0.8 + 0.4 * torch.rand(n, generator=gd, device=dev), lateral_friction=0.4 + 0.6 * torch.rand(n, generator=gd, device=dev))
     agent = TD3Agent(26, 18, 1.0, device=dev)
     replay = ReplayBuffer(1000000, device=dev)
     replay.seed(rank)
-    tr = GraphedVecTD3Trainer(env, agent, replay, start_timesteps=10000, expl_noise=0.1, batch_size=a.td3_batch, updates_per_step=a.td3_updates, seed=1000 + rank)
+    # one rank: actor / learner overlap (two half batches + the update on three streams); several ranks: the synchronous graph trainer with
+    # the gradient all-reduces between its graph segments
+    pipelined = world == 1 and a.td3_updates == 1 and a.td3_schedule == "pipelined" and n % 2 == 0
+    if pipelined:
+        envs = [PlenVecEnv(n // 2, device=dev) for _ in range(2)]
+        env = envs[0]
+        if a.dr:
+            gd = torch.Generator(device=dev).manual_seed(1000 + rank)
+            ms, mu = 0.8 + 0.4 * torch.rand(n, generator=gd, device=dev), 0.4 + 0.6 * torch.rand(n, generator=gd, device=dev)
+            for h, e in enumerate(envs):
+                e.set_params(mass_scale=ms[h * n // 2:(h + 1) * n // 2], lateral_friction=mu[h * n // 2:(h + 1) * n // 2])
+        tr = PipelinedVecTD3Trainer(envs, agent, replay, start_timesteps=10000, expl_noise=0.1, batch_size=a.td3_batch, seed=1000 + rank)
+    else:
+        envs = [PlenVecEnv(n, device=dev)]
+        env = envs[0]
+        if a.dr:
+            gd = torch.Generator(device=dev).manual_seed(1000 + rank)
+            env.set_params(mass_scale=0.8 + 0.4 * torch.rand(n, generator=gd, device=dev), lateral_friction=0.4 + 0.6 * torch.rand(n, generator=gd, device=dev))
+        tr = GraphedVecTD3Trainer(env, agent, replay, start_timesteps=10000, expl_noise=0.1, batch_size=a.td3_batch, updates_per_step=a.td3_updates, seed=1000 + rank)
 
     def barrier():
         torch.cuda.synchronize()
@@ -237,7 +251,7 @@ def td3_leg(a, dev, rank, world, dist, steps, warmup):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(warmup, 8)):          # past the random-action phase (3 vector steps at 4096 envs) and the graph captures
+    for _ in range(max(warmup, 30)):         # past the random-action phase (3 vector steps at 4096 envs) and every graph capture
         tr.step()
     barrier()
     e0, g0, t0 = tr.env_steps, tr.grad_steps, time.perf_counter()
@@ -250,10 +264,14 @@ def td3_leg(a, dev, rank, world, dist, steps, warmup):
            "batch_per_rank": a.td3_batch, "updates_per_vector_step": a.td3_updates, "replay_capacity": 1000000, "start_timesteps": 10000,
            "update_to_data": "%d gradient step(s) of batch %d per vector step of %d env-steps per rank (samples drawn per env-step: %.2f; the reference "
                              "does 1 step of batch 100 per single env-step, plen_td3.py:119-120)" % (a.td3_updates, a.td3_batch, n, a.td3_updates * a.td3_batch / n),
-           "hip_graphs": True, "collective": ("RCCL all-reduce of the flat critic (155138 f32) and actor (77330 f32) gradient buckets per update, mode %s" % tr.allreduce_mode) if world > 1 else None,
+           "hip_graphs": True,
+           "schedule": ("actor/learner overlap: 2 half batches of %d envs and the update on three HIP streams, acting policy two updates old (train_vec.PipelinedVecTD3Trainer)" % (n // 2))
+                       if pipelined else "synchronous: collect all envs, then update (train_vec.GraphedVecTD3Trainer)",
+           "collective": ("RCCL all-reduce of the flat critic (155138 f32) and actor (77330 f32) gradient buckets per update, mode %s" % getattr(tr, "allreduce_mode", None)) if world > 1 else None,
            "critic_loss": float(agent.last_critic_loss) if agent.last_critic_loss is not None else None,
            "workload": "BASELINE.json configs[%d]: %d envs per GPU + TD3 (actor 26-256-256-18, twin critic 44-256-256-1, Adam 3e-4, policy_freq 2), exploration N(0, 0.1)" % (2 if world == 1 else 3, n)}
-    env.close()
+    for e in envs:
+        e.close()
     return out
 
 
@@ -271,6 +289,7 @@ def main():
     ap.add_argument("--td3-batch", type=int, default=4096)
     ap.add_argument("--td3-updates", type=int, default=1)
     ap.add_argument("--td3-steps", type=int, default=200)
+    ap.add_argument("--td3-schedule", default="pipelined", choices=["pipelined", "sync"], help="one rank: actor/learner overlap on three streams, or the synchronous graph loop")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -24,8 +24,10 @@ extern "C" {
 
 /* td3.py:166-193 ReplayBuffer.sample: out[b] = data[idx[b]]; also sa_pi[b][0:26] = state (policy pass input), loss[0:2] = 0 */
 int plentd3_gather(const float *data, const int64_t *idx, float *out, float *sa_pi, float *loss, int B, void *stream);
-/* td3.py:175 sampling on the device + the gather above: idx = min(floor(u filled), filled - 1), filled = min(*total, capacity), u in [0,1); idx_out may be NULL */
-int plentd3_sample_gather(const float *data, const float *u, const int64_t *total, int64_t capacity, int64_t *idx_out, float *out, float *sa_pi, float *loss, int B, void *stream);
+/* td3.py:175 sampling on the device + the gather above: u in [0,1) -> a uniformly drawn COMPLETE row of the ring.  *total = transitions written so
+ * far (the ring wraps when it exceeds capacity); guard = rows from position *total on that concurrent writers may be filling (0 for a synchronous
+ * loop), excluded once the ring has wrapped onto them; idx_out may be NULL */
+int plentd3_sample_gather(const float *data, const float *u, const int64_t *total, int64_t capacity, int64_t guard, int64_t *idx_out, float *out, float *sa_pi, float *loss, int B, void *stream);
 /* plen_td3.py:101-104 exploration: a = clamp(max_a tanh(pre) + noise sigma, +-max_a) over n = B*18 elements */
 int plentd3_explore(const float *pre, const float *noise, float *a, float sigma, float max_a, int n, void *stream);
 /* plen_td3.py:109-113 replay_buffer.add for a whole vector step: ring rows (*total + e) % capacity = s | a | s2 | r | 1 - done_bool,

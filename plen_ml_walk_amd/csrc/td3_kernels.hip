@@ -227,18 +227,24 @@ __global__ __launch_bounds__(256) void k_wgrad(const float *__restrict__ dH, int
     }
 }
 
-// ---- K12: replay sampling without a host round trip (td3.py:175 np.random.randint(0, len, B)): idx[b] = min(floor(u[b] * filled), filled - 1),
-//      filled = min(*total, capacity), u uniform in [0, 1); then the gather of K1
-__global__ void k_sample_gather(const float *__restrict__ data, const float *__restrict__ u, const int64_t *__restrict__ total, int64_t capacity,
+// ---- K12: replay sampling without a host round trip (td3.py:175 np.random.randint(0, len, B)): u uniform in [0, 1) -> a row of the ring that
+//      holds a complete transition, then the gather of K1.  *total = transitions written so far (may exceed the capacity: the ring wraps);
+//      guard = rows after position *total that concurrent writers may be filling right now (0 for a synchronous loop): they are excluded
+//      once the ring has wrapped onto them.
+__global__ void k_sample_gather(const float *__restrict__ data, const float *__restrict__ u, const int64_t *__restrict__ total, int64_t capacity, int64_t guard,
                                 int64_t *__restrict__ idx_out, float *__restrict__ out, float *__restrict__ sa_pi, float *loss, int B) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0 && loss) { loss[0] = 0.f; loss[1] = 0.f; }
     const int b = t / TD3_ROW, c = t % TD3_ROW;
     if (b >= B) return;
-    const int64_t filled = total[0] < capacity ? total[0] : capacity;
+    const int64_t tot = total[0];
+    int64_t filled, start;
+    if (tot + guard <= capacity) { filled = tot; start = 0; }                               // ring not yet wrapped onto the rows in flight
+    else { filled = capacity - guard; start = (tot + guard) % capacity; }                   // the oldest complete row follows the rows in flight
     int64_t i = (int64_t)(u[b] * (float)filled);
     i = i < filled - 1 ? i : filled - 1;
     i = i > 0 ? i : 0;
+    i = (start + i) % capacity;
     if (c == 0 && idx_out) idx_out[b] = i;
     const float v = data[(size_t)i * TD3_ROW + c];
     out[(size_t)b * TD3_ROW + c] = v;
@@ -276,8 +282,8 @@ extern "C" {
 int plentd3_gather(const float *data, const int64_t *idx, float *out, float *sa_pi, float *loss, int B, void *stream) {
     hipLaunchKernelGGL(k_gather, GRID(B * TD3_ROW), data, idx, out, sa_pi, loss, B); CHECK();
 }
-int plentd3_sample_gather(const float *data, const float *u, const int64_t *total, int64_t capacity, int64_t *idx_out, float *out, float *sa_pi, float *loss, int B, void *stream) {
-    hipLaunchKernelGGL(k_sample_gather, GRID(B * TD3_ROW), data, u, total, capacity, idx_out, out, sa_pi, loss, B); CHECK();
+int plentd3_sample_gather(const float *data, const float *u, const int64_t *total, int64_t capacity, int64_t guard, int64_t *idx_out, float *out, float *sa_pi, float *loss, int B, void *stream) {
+    hipLaunchKernelGGL(k_sample_gather, GRID(B * TD3_ROW), data, u, total, capacity, guard, idx_out, out, sa_pi, loss, B); CHECK();
 }
 int plentd3_explore(const float *pre, const float *noise, float *a, float sigma, float max_a, int n, void *stream) {
     hipLaunchKernelGGL(k_explore, GRID(n), pre, noise, a, sigma, max_a, n); CHECK();

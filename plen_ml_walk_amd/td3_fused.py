@@ -36,7 +36,7 @@ def load():
         lib.plentd3_version.restype = C.c_char_p
         vp, i, f = C.c_void_p, C.c_int, C.c_float
         lib.plentd3_gather.argtypes = [vp, vp, vp, vp, vp, i, vp]
-        lib.plentd3_sample_gather.argtypes = [vp, vp, vp, C.c_int64, vp, vp, vp, vp, i, vp]
+        lib.plentd3_sample_gather.argtypes = [vp, vp, vp, C.c_int64, C.c_int64, vp, vp, vp, vp, i, vp]
         lib.plentd3_explore.argtypes = [vp, vp, vp, f, f, i, vp]
         lib.plentd3_store.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, i, vp]
         lib.plentd3_target_action.argtypes = [vp, vp, vp, vp, f, f, f, i, vp]
@@ -96,10 +96,10 @@ class FusedTD3(object):
         h = torch.addmm(b, x, w.t(), out=out) if out is not None else torch.addmm(b, x, w.t())
         return h.relu_() if out is None else h
 
-    def update(self, data, idx, with_policy, noise=None, all_reduce=True, total=None):
+    def update(self, data, idx, with_policy, noise=None, all_reduce=True, total=None, guard=0):
         """The whole iteration; with torch.distributed initialised the two gradient buckets are averaged over ranks before their Adam steps."""
         ag = self.agent
-        loss = self.critic_backward(data, idx, noise, total)
+        loss = self.critic_backward(data, idx, noise, total, guard)
         if all_reduce:
             ag._critic_grads.all_reduce_mean()
         ag.critic_optimizer.step()
@@ -113,10 +113,11 @@ class FusedTD3(object):
             self.polyak()
         return loss
 
-    def explore(self, state, sigma):
-        """Collect-phase action (plen_td3.py:101-104): clamp(actor(state) + N(0, sigma), +-max_action) -- 3 GEMMs, the noise draw, one fused kernel."""
+    def explore(self, state, sigma, actor=None):
+        """Collect-phase action (plen_td3.py:101-104): clamp(actor(state) + N(0, sigma), +-max_action) -- 3 GEMMs, the noise draw, one fused kernel.
+        `actor`: the network to act with (default the online actor; the pipelined trainer passes a behaviour copy)."""
         ag = self.agent
-        ac = ag.actor
+        ac = ag.actor if actor is None else actor
         with torch.no_grad():
             p2 = self._lin_relu(self._lin_relu(state, ac.fc1.weight, ac.fc1.bias), ac.fc2.weight, ac.fc2.bias)
             pre = torch.addmm(ac.fc3.bias, p2, ac.fc3.weight.t())
@@ -133,7 +134,7 @@ class FusedTD3(object):
         assert done.dtype == torch.uint8 and total.dtype == torch.long
         _chk(self.lib.plentd3_store(_p(data), _p(total), int(data.shape[0]), _p(state), _p(action), _p(next_obs), _p(reward), _p(done), n, self._stream()))
 
-    def critic_backward(self, data, idx, noise=None, total=None):
+    def critic_backward(self, data, idx, noise=None, total=None, guard=0):
         """Sample, targets, critic forward / loss / backward: gradients land in the critic's flat bucket.  Returns the loss (device scalar).
         idx: LongTensor [B] of replay rows, or an int B with `total` (device int64 scalar: transitions written so far) to draw them here."""
         ag, lib, st = self.agent, self.lib, self._stream()
@@ -144,7 +145,7 @@ class FusedTD3(object):
             B = idx
             batch, sa_pi, loss = new(B, ROW), new(B, SA), new(2)
             u = torch.rand(B, device=dev)
-            _chk(lib.plentd3_sample_gather(_p(data), _p(u), _p(total), int(data.shape[0]), None, _p(batch), _p(sa_pi), _p(loss), B, st))
+            _chk(lib.plentd3_sample_gather(_p(data), _p(u), _p(total), int(data.shape[0]), int(guard), None, _p(batch), _p(sa_pi), _p(loss), B, st))
         else:
             B = int(idx.shape[0])
             assert idx.dtype == torch.long

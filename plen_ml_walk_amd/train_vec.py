@@ -373,5 +373,130 @@ class GraphedVecTD3Trainer(object):
         self.agent.last_critic_loss = self._critic_loss
 
 
+class PipelinedVecTD3Trainer(object):
+    """Actor / learner overlap on ONE GPU (single rank): the envs step as two half batches on their own HIP streams and the fused TD3
+    update runs on a third, all three replaying hipGraphs with only event dependencies between them.
+
+    Why: one 4096-env launch owns every wave slot of the chip for as long as its slowest waves run, and the update's ~50 small kernels
+    cannot start beside it (measured, scripts/gpu_overlap_probe.py: 4096 envs 0.52 ms + update 0.46 ms = 0.99 ms together); a 2048-env
+    launch leaves half the slots free: 0.41 ms + 0.46 ms run in 0.53 ms together.  So the loop is software-pipelined:
+        collector h, step t : waits for update t-2;  acts with the behaviour actor written by update t-2 (a ring of 3 copies of the actor's
+                              flat parameter buffer);  steps its 2048 envs;  stores the transitions into its rows of the ring
+        update t            : waits for both collectors' step t-1;  samples rows written before step t (rows of steps t, t+1, which
+                              collectors may be writing right now, are excluded once the ring has wrapped: k_sample_gather's guard);
+                              at its end copies the actor into behaviour copy (t+1) % 3
+    No tensor is written by one stream while another may read it (each dependency above is an event): the collection side is bitwise
+    reproducible given its seeds (tested with learning off; the learner's float-atomic reductions are order-dependent in the last bits).
+    The only semantic difference from VecTD3Trainer is that the acting policy is two updates old and the learner one vector step
+    behind -- off-policy TD3 does not care.  One update of `batch_size` per vector step of `num_envs` env-steps, as in the synchronous loops."""
+
+    def __init__(self, envs, agent, replay, start_timesteps=10000, expl_noise=0.1, batch_size=4096, seed=0):
+        import copy
+        from . import td3 as T
+        from .td3_fused import FusedTD3
+        assert len(envs) == 2 and envs[0].num_envs == envs[1].num_envs and agent.device.type == "cuda"
+        self.envs, self.agent, self.replay = envs, agent, replay
+        self.nh = envs[0].num_envs
+        self.n = 2 * self.nh
+        self.start_timesteps, self.expl_noise, self.batch_size = start_timesteps, expl_noise, batch_size
+        dev = agent.device
+        assert replay.max_size >= 4 * self.n, "the ring must hold more than the rows in flight"
+        self.fused = FusedTD3(agent)
+        torch.manual_seed(seed)
+        agent.actor_optimizer = GraphedVecTD3Trainer._capturable_adam(agent.actor_optimizer, agent.actor)
+        agent.critic_optimizer = GraphedVecTD3Trainer._capturable_adam(agent.critic_optimizer, agent.critic)
+        # behaviour actors: 3 copies of the actor whose parameters are views of their own flat buffers
+        self.behaviour = [copy.deepcopy(agent.actor) for _ in range(3)]
+        self.bflat = [T._FlatParams(b) for b in self.behaviour]
+        self.streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        self.su = torch.cuda.Stream(device=dev)
+        self.state = [e.reset().to(torch.float32).clone() for e in envs]
+        self.base = [torch.tensor(h * self.nh, dtype=torch.long, device=dev) for h in range(2)]       # next ring row of each half
+        self.total_u = torch.zeros((), dtype=torch.long, device=dev)                                  # rows complete before the current step
+        self._critic_loss = torch.zeros((), device=dev)
+        self.t = 0
+        self.env_steps = self.grad_steps = 0
+        self._graphs, self._eager_runs = {}, {}
+        self._ev_col = {}
+        self._ev_upd = {}
+        torch.cuda.synchronize(dev)
+
+    # one half-batch vector step: act, step the envs, store (all on the current stream)
+    def _collect(self, h, random_actions, buf):
+        env, nh = self.envs[h], self.nh
+        dev = self.agent.device
+        if random_actions:
+            action = torch.rand(nh, 18, device=dev) * 2 - 1
+        else:
+            action = self.fused.explore(self.state[h], self.agent.max_action * self.expl_noise, actor=self.behaviour[buf])
+        next_obs, reward, done, info = env.step(action)
+        self.fused.store(self.replay.data, self.base[h], self.state[h], action, next_obs, reward, done)
+        self.base[h] += self.n
+        self.state[h].copy_(info["obs"])
+
+    def _update(self, with_policy, buf_out):
+        loss = self.fused.update(self.replay.data, self.batch_size, with_policy, all_reduce=False, total=self.total_u, guard=2 * self.n)
+        self._critic_loss.copy_(loss)
+        self.total_u += self.n
+        self.bflat[buf_out].flat.copy_(self.agent._actor_flat.flat)
+
+    def _run(self, key, stream, fn, *args):
+        """fn(*args) on `stream`: eagerly the first two times the key is seen, then as a replay of its graph captured on that stream."""
+        with torch.cuda.stream(stream):
+            g = self._graphs.get(key)
+            if g is None:
+                runs = self._eager_runs.get(key, 0)
+                if runs < 2:
+                    fn(*args)
+                    self._eager_runs[key] = runs + 1
+                    return
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    fn(*args)
+                self._graphs[key] = g
+            g.replay()
+
+    def step(self):
+        t, n = self.t, self.n
+        warm = t * n < self.start_timesteps                    # uniform random actions until the ring holds start_timesteps transitions
+        learn = not warm and t >= 1
+        for h in range(2):
+            s = self.streams[h]
+            ev = self._ev_upd.get(t - 2)
+            if ev is not None:
+                s.wait_event(ev)
+            self._run(("collect", h, warm, (t - 1) % 3), s, self._collect, h, warm, (t - 1) % 3)
+            e = torch.cuda.Event(); e.record(s); self._ev_col[(h, t)] = e
+        su = self.su
+        for h in range(2):
+            ev = self._ev_col.get((h, t - 1))
+            if ev is not None:
+                su.wait_event(ev)
+        if learn:
+            with_policy = (self.grad_steps + 1) % self.agent.policy_freq == 0
+            self._run(("update", with_policy, (t + 1) % 3), su, self._update, with_policy, (t + 1) % 3)
+            self.grad_steps += 1
+            self.agent.total_it = self.grad_steps
+        else:
+            with torch.cuda.stream(su):
+                self.total_u += n                               # invariant: total_u == t * n when update t samples (rows of steps < t are complete)
+                self.bflat[(t + 1) % 3].flat.copy_(self.agent._actor_flat.flat)
+        e = torch.cuda.Event(); e.record(su); self._ev_upd[t] = e
+        for k in [k for k in self._ev_upd if k < t - 3]:
+            del self._ev_upd[k]
+        for k in [k for k in self._ev_col if k[1] < t - 3]:
+            del self._ev_col[k]
+        self.t += 1
+        self.env_steps += n
+        done = self.t * n
+        self.replay.size = min(done, self.replay.max_size)
+        self.replay.ptr = done % self.replay.max_size if done >= self.replay.max_size else 0
+        self.agent.last_critic_loss = self._critic_loss
+
+    def sync(self):
+        for s in self.streams + [self.su]:
+            s.synchronize()
+
+
 if __name__ == "__main__":
     main()

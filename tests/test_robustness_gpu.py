@@ -321,3 +321,48 @@ def test_mfma_weight_gradient_kernel(B, N, K):
     want_w = dh.double().t() @ x.double(); want_b = dh.double().sum(0)
     assert float((gw.double() - want_w).abs().max()) <= 2e-5 * float(want_w.abs().max()) + 1e-4
     assert float((gb.double() - want_b).abs().max()) <= 2e-5 * float(want_b.abs().max()) + 1e-4
+
+
+def test_pipelined_trainer_overlaps_without_races():
+    """PipelinedVecTD3Trainer (two half batches + the fused update on three streams, event dependencies only): counters, ring contents and
+    ORDER are those of the synchronous loop -- every stored transition's next_state is the state stored one vector step later for the same
+    env (unless its episode ended), which a torn or misplaced row would break; losses finite.  The collection side is bitwise reproducible
+    (checked with learning off); the learner's float-atomic reductions (k_wgrad, k_colsum) are order-dependent in the last bits, like any
+    split-K GEMM, so a learning run is not."""
+    from plen_ml_walk_amd.td3 import ReplayBuffer, TD3Agent
+    from plen_ml_walk_amd.train_vec import PipelinedVecTD3Trainer
+    n, T = 512, 45
+    runs = []
+    for start in (3 * n, 10 ** 9, 10 ** 9):
+        torch.manual_seed(0)
+        envs = [_env(n // 2), _env(n // 2)]
+        agent = TD3Agent(26, 18, 1.0); replay = ReplayBuffer(40 * n)        # the ring wraps during the run: the sampling guard is exercised
+        tr = PipelinedVecTD3Trainer(envs, agent, replay, start_timesteps=start, batch_size=512, seed=7)
+        for _ in range(T):
+            tr.step()
+        tr.sync(); torch.cuda.synchronize()
+        learning = start < 10 ** 9
+        assert tr.env_steps == T * n and tr.grad_steps == (T - 3 if learning else 0) and agent.total_it == tr.grad_steps
+        assert int(tr.total_u) == T * n and int(tr.base[0]) == T * n and int(tr.base[1]) == T * n + n // 2
+        assert replay.size == 40 * n and replay.ptr == (T * n) % (40 * n)
+        d = replay.data
+        assert torch.isfinite(d).all() and ((d[:, 71] == 0) | (d[:, 71] == 1)).all()
+        if learning:
+            assert torch.isfinite(agent.last_critic_loss) and float(agent.last_critic_loss) > 0
+        # continuity: rows of steps 10..38 (not overwritten by the wrap: steps 40..44 overwrote rows of steps 0..4)
+        ok = tot = 0
+        for t in range(10, 38):
+            a, b = d[t * n:(t + 1) * n], d[(t + 1) * n:(t + 2) * n]
+            same = (a[:, 44:70] == b[:, 0:26]).all(1)
+            tot += n; ok += int(same.sum())
+            ended = ~same
+            # where the chain is broken the episode ended: the next stored state is the reset observation (identical for every env)
+            if ended.any():
+                assert (b[ended, 0:26] == b[ended][0, 0:26]).all()
+        assert ok / tot >= 0.9
+        assert float(d[:, 26:44].abs().max()) <= 1.0 and (d[(d[:, 71] == 0), 70] < -50).all()
+        runs.append(d.clone())
+        for e in envs:
+            e.close()
+    assert torch.equal(runs[1], runs[2])          # collection (RNG, env steps, ring writes on two streams): bitwise reproducible
+    assert not torch.equal(runs[0], runs[1])      # ... and the learning run did act with a learned policy
