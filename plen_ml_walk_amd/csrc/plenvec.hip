@@ -164,21 +164,44 @@ __device__ __forceinline__ float wrlane(float dst, float val, int lane) {
     asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(sv), "i"(L));
     return dst;
 }
+// f64: two v_writelane_b32 on the halves (val is wave-uniform: it comes from a v_readlane broadcast).  The former `lane == L ? val : dst`
+// cost a v_mov + v_cndmask per half AND one live 64-bit lane mask per row, i.e. ~50 SGPR pairs held (and spilled) across the solver loop.
 template <int L>
-__device__ __forceinline__ double wrlane(double dst, double val, int lane) { return lane == L ? val : dst; }
+__device__ __forceinline__ double wrlane(double dst, double val, int lane) {
+    (void)lane;
+    const long long d = __builtin_bit_cast(long long, dst), v = __builtin_bit_cast(long long, val);
+    int lo = (int)(d & 0xffffffffLL), hi = (int)(d >> 32);
+    const int slo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffLL)), shi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+    asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4" : "+v"(lo), "+v"(hi) : "s"(slo), "s"(shi), "i"(L));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+// compiler-path commit of a row's delta into lane L of the per-pass vector: f32 keeps the select (bit-identical to the asm path's
+// v_writelane and what the NO_ASM build is there to check), f64 uses the writelane form above
+template <int L>
+__device__ __forceinline__ float commit_lane(float dvec, float db, int lane) { return lane == L ? db : dvec; }
+template <int L>
+__device__ __forceinline__ double commit_lane(double dvec, double db, int lane) { return wrlane<L>(dvec, db, lane); }
 
-// lane i receives x[i-1] (lane 0 keeps its own): one DPP move for f32, the LDS crossbar for f64
+// a DPP move of a double = the same DPP move on its two halves (the LDS crossbar __shfl costs 2 ds_bpermute + address arithmetic)
+template <int CTRL, bool BOUND_ZERO>
+__device__ __forceinline__ double dpp64(double x, double old) {
+    const long long b = __builtin_bit_cast(long long, x), o = __builtin_bit_cast(long long, old);
+    const int lo = __builtin_amdgcn_update_dpp((int)(o & 0xffffffffLL), (int)(b & 0xffffffffLL), CTRL, 0xf, 0xf, BOUND_ZERO);
+    const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(b >> 32), CTRL, 0xf, 0xf, BOUND_ZERO);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+// lane i receives x[i-1] (lane 0 keeps its own): one DPP move (two for f64)
 __device__ __forceinline__ float shift_up1(float x) {
     const int b = __builtin_bit_cast(int, x);
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
 }
-__device__ __forceinline__ double shift_up1(double x) { return __shfl_up(x, 1); }
+__device__ __forceinline__ double shift_up1(double x) { return dpp64<0x138 /* wave_shr:1 */, false>(x, x); }
 // lane i receives x[i+1] (lane 63 keeps its own)
 __device__ __forceinline__ float shift_down1(float x) {
     const int b = __builtin_bit_cast(int, x);
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
 }
-__device__ __forceinline__ double shift_down1(double x) { return __shfl_down(x, 1); }
+__device__ __forceinline__ double shift_down1(double x) { return dpp64<0x130 /* wave_shl:1 */, false>(x, x); }
 // lane i receives x[src_i] through the LDS crossbar (no LDS storage involved)
 __device__ __forceinline__ float gather_lane(float x, int src) {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, x)));
@@ -261,7 +284,7 @@ __device__ __forceinline__ void pgs_row2d(real &e, const real blo, const real bh
 #pragma clang fp contract(off)
         const real d = min_(max_(-e, blo), bhi);
         const real db = bcast(d, lane_of_port(PP));
-        if (lane == lane_of_port(PP)) dvec = db;
+        dvec = commit_lane<lane_of_port(PP)>(dvec, db, lane);
         e = fma_(db, acol, e);
     }
 }
@@ -497,7 +520,7 @@ __device__ __forceinline__ void pgs_rowTd(real &e, const real nt1, const real t2
 #pragma clang fp contract(off)
         const real d = min_(max_(-e, nt1), t2);
         const real db = bcast(d, lane_of_port(PP));
-        if (lane == lane_of_port(PP)) dvec = db;
+        dvec = commit_lane<lane_of_port(PP)>(dvec, db, lane);
         e = fma_(db, acol, e);
     }
 }
@@ -528,12 +551,12 @@ __device__ __forceinline__ float quad_swap12(float x) {
     const int b = __builtin_bit_cast(int, x);
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, 0xD8 /* quad_perm:[0,2,1,3] */, 0xf, 0xf, false));
 }
-__device__ __forceinline__ double quad_swap12(double x) { const int l = threadIdx.x; const int q = l & 3; return __shfl(x, (q == 1 || q == 2) ? (l ^ 3) : l); }
+__device__ __forceinline__ double quad_swap12(double x) { return dpp64<0xD8 /* quad_perm:[0,2,1,3] */, false>(x, x); }
 __device__ __forceinline__ float quad_bcast0(float x) {
     const int b = __builtin_bit_cast(int, x);
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, 0x00 /* quad_perm:[0,0,0,0] */, 0xf, 0xf, false));
 }
-__device__ __forceinline__ double quad_bcast0(double x) { return __shfl(x, (int)threadIdx.x & ~3); }
+__device__ __forceinline__ double quad_bcast0(double x) { return dpp64<0x00 /* quad_perm:[0,0,0,0] */, false>(x, x); }
 
 template <int PN, typename real>
 __device__ __forceinline__ void pgs_cone(real &e, const real u, real &dvec, const real lmv, const real jdi, const real aA, const real aB,
@@ -607,7 +630,7 @@ __device__ __forceinline__ float row_shr(float x) {        // lane i <- x[i - S]
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x110 + S, 0xf, 0xf, true));
 }
 template <int S>
-__device__ __forceinline__ double row_shr(double x) { return __shfl_up(x, S, 16); }   // (lanes i < S keep their own value: they are padding)
+__device__ __forceinline__ double row_shr(double x) { return dpp64<0x110 + S, true>(x, 0.0); }   // 0 shifted in, like the f32 form
 template <typename real>
 __device__ __forceinline__ void prefix3(real *v) {          // inclusive prefix sum along the row, offsets 1, 2, 4 (chains are <= 6 long)
 #pragma unroll
