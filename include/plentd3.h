@@ -17,6 +17,9 @@
 extern "C" {
 #endif
 
+/* Random numbers: functions that draw take EITHER an explicit array (noise / u: golden tests feed the reference's draws) OR, with that pointer
+ * NULL, `rng` = device uint64[2] {seed, number of calls so far}: counter-based Philox4x32-10, so a captured graph needs no library RNG call.
+ * The call counter is bumped by a later kernel of the same launch sequence (`rng_bump` arguments, NULL = leave it). */
 #define TD3_S 26
 #define TD3_A 18
 #define TD3_SA 44
@@ -27,18 +30,20 @@ int plentd3_gather(const float *data, const int64_t *idx, float *out, float *sa_
 /* td3.py:175 sampling on the device + the gather above: u in [0,1) -> a uniformly drawn COMPLETE row of the ring.  *total = transitions written so
  * far (the ring wraps when it exceeds capacity); guard = rows from position *total on that concurrent writers may be filling (0 for a synchronous
  * loop), excluded once the ring has wrapped onto them; idx_out may be NULL */
-int plentd3_sample_gather(const float *data, const float *u, const int64_t *total, int64_t capacity, int64_t guard, int64_t *idx_out, float *out, float *sa_pi, float *loss, int B, void *stream);
+int plentd3_sample_gather(const float *data, const float *u, const uint64_t *rng, const int64_t *total, int64_t capacity, int64_t guard, int64_t *idx_out, float *out, float *sa_pi, float *loss, int B, void *stream);
 /* plen_td3.py:101-104 exploration: a = clamp(max_a tanh(pre) + noise sigma, +-max_a) over n = B*18 elements */
-int plentd3_explore(const float *pre, const float *noise, float *a, float sigma, float max_a, int n, void *stream);
+int plentd3_explore(const float *pre, const float *noise, const uint64_t *rng, float *a, float sigma, float max_a, int n, void *stream);
+/* plen_td3.py:91-92 warm-up actions: a = U[-1, 1) over n elements */
+int plentd3_uniform_actions(const uint64_t *rng, float *a, int n, void *stream);
 /* plen_td3.py:109-113 replay_buffer.add for a whole vector step: ring rows (*total + e) % capacity = s | a | s2 | r | 1 - done_bool,
  * done_bool = terminal and not time-limit (done = PLENVEC_DONE_* bits of plenvec_step); real arrays are float32 */
-int plentd3_store(float *data, const int64_t *total, int64_t capacity, const float *s, const float *a, const float *s2, const float *r, const uint8_t *done, int n, void *stream);
+int plentd3_store(float *data, const int64_t *total, int64_t capacity, const float *s, const float *a, const float *s2, const float *r, const uint8_t *done, uint64_t *rng_bump, int n, void *stream);
 /* td3.py:299-304: sa2 = [s2 | clamp(max_a tanh(pre) + clamp(noise sigma, +-clip), +-max_a)], pre = actor_target's last pre-activation */
-int plentd3_target_action(const float *pre, const float *noise, const float *batch, float *sa2, float sigma, float clip, float max_a, int B, void *stream);
+int plentd3_target_action(const float *pre, const float *noise, const uint64_t *rng, const float *batch, float *sa2, float sigma, float clip, float max_a, int B, void *stream);
 /* twin last layers on h2 = [h2_a | h2_b] ([B][512]).  mode 0, td3.py:306-309: y = r + not_done gamma min(q_a, q_b).
  * mode 1, td3.py:312-319: dq[b][c] = 2 (q_c - y) / B, loss[0] += sum (q_c - y)^2 / B, db3_c += sum_b dq[b][c] */
 int plentd3_q_heads(const float *h2, const float *w3a, const float *b3a, const float *w3b, const float *b3b, const float *batch, float *y, float *dq,
-                    float *loss, float *db3a, float *db3b, float gamma, int B, int mode, void *stream);
+                    float *loss, float *db3a, float *db3b, uint64_t *rng_bump, float gamma, int B, int mode, void *stream);
 /* back through last layer + ReLU: dh2 = dq w3 (h2 > 0); dq NULL = policy pass (td3.py:337), dq = -1/B, critic a only */
 int plentd3_dh2(const float *dq, const float *w3a, const float *w3b, const float *h2, float *dh2, int B, int ncrit, int h2_stride, void *stream);
 /* ReLU backward in place: g *= (h > 0) */

@@ -14,6 +14,44 @@
 
 #define TD3_H 256          // hidden width of actor and critics (td3.py:34-36, 80-88)
 
+// ---- counter-based random numbers (Philox4x32-10, Salmon et al. 2011) so that the captured graphs need no library RNG call (each costs a
+//      draw kernel plus a fill of the generator's offset tensor per graph replay).  rng = device uint64[2] {seed, calls so far}; a kernel reads
+//      the call counter at its start and a LATER kernel of the same stream bumps it, so every launch sees one consistent value.
+//      Element i of draw `tag` of call c gets the 4 words philox(counter = (i, c_lo, c_hi, tag), key = seed).
+struct u4 { uint32_t x, y, z, w; };
+static __device__ __forceinline__ u4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return u4{c0, c1, c2, c3};
+}
+static __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }              // [0, 1)
+static __device__ __forceinline__ float u01_open(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); } // (0, 1)
+// two independent standard normals from two words (Box-Muller)
+static __device__ __forceinline__ void normal2(uint32_t a, uint32_t b, float &n0, float &n1) {
+    const float r = sqrtf(-2.0f * logf(u01_open(a))), th = 6.283185307179586f * u01(b);
+    n0 = r * cosf(th); n1 = r * sinf(th);
+}
+// standard normal number e (0..) of draw `tag` of this call
+static __device__ __forceinline__ float rng_normal(const uint64_t *rng, uint32_t tag, uint32_t e) {
+    const uint64_t seed = rng[0], call = rng[1];
+    const u4 w = philox4x32(e >> 2, (uint32_t)call, (uint32_t)(call >> 32), tag, (uint32_t)seed, (uint32_t)(seed >> 32));
+    float n0, n1, n2, n3;
+    normal2(w.x, w.y, n0, n1); normal2(w.z, w.w, n2, n3);
+    const uint32_t k = e & 3u;
+    return k == 0 ? n0 : k == 1 ? n1 : k == 2 ? n2 : n3;
+}
+static __device__ __forceinline__ float rng_uniform(const uint64_t *rng, uint32_t tag, uint32_t e) {
+    const uint64_t seed = rng[0], call = rng[1];
+    const u4 w = philox4x32(e >> 2, (uint32_t)call, (uint32_t)(call >> 32), tag, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint32_t k = e & 3u;
+    return u01(k == 0 ? w.x : k == 1 ? w.y : k == 2 ? w.z : w.w);
+}
+
 static __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -34,8 +72,8 @@ __global__ void k_gather(const float *__restrict__ data, const int64_t *__restri
 
 // ---- K2: target policy smoothing (td3.py:299-304): a2 = clamp(max_a * tanh(pre) + clamp(noise * sigma, +-clip), +-max_a); writes the
 //      target critics' input sa2 = [s2 | a2] (s2 taken from the gathered batch rows)
-__global__ void k_target_action(const float *__restrict__ pre, const float *__restrict__ noise, const float *__restrict__ batch, float *__restrict__ sa2,
-                                float sigma, float clip, float max_a, int B) {
+__global__ void k_target_action(const float *__restrict__ pre, const float *__restrict__ noise, const uint64_t *__restrict__ rng, const float *__restrict__ batch,
+                                float *__restrict__ sa2, float sigma, float clip, float max_a, int B) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = t / TD3_SA, c = t % TD3_SA;
     if (b >= B) return;
@@ -43,7 +81,8 @@ __global__ void k_target_action(const float *__restrict__ pre, const float *__re
     if (c < TD3_S) v = batch[(size_t)b * TD3_ROW + TD3_S + TD3_A + c];
     else {
         const int j = c - TD3_S;
-        const float n = fminf(fmaxf(noise[(size_t)b * TD3_A + j] * sigma, -clip), clip);
+        const float z = noise ? noise[(size_t)b * TD3_A + j] : rng_normal(rng, 1u, (uint32_t)(b * TD3_A + j));      // torch.randn_like(action), td3.py:300
+        const float n = fminf(fmaxf(z * sigma, -clip), clip);
         v = fminf(fmaxf(max_a * tanhf(pre[(size_t)b * TD3_A + j]) + n, -max_a), max_a);
     }
     sa2[(size_t)b * TD3_SA + c] = v;
@@ -56,7 +95,8 @@ __global__ void k_target_action(const float *__restrict__ pre, const float *__re
 //                                         loss[0] += sum_c (q_c - y)^2 / B;  db3_c += dq (bias gradient of the last layer)
 __global__ void k_q_heads(const float *__restrict__ h2, const float *__restrict__ w3a, const float *__restrict__ b3a, const float *__restrict__ w3b,
                           const float *__restrict__ b3b, const float *__restrict__ batch, float *__restrict__ y, float *__restrict__ dq, float *loss,
-                          float *db3a, float *db3b, float gamma, int B, int mode) {
+                          float *db3a, float *db3b, uint64_t *rng_bump, float gamma, int B, int mode) {
+    if (rng_bump && blockIdx.x == 0 && threadIdx.x == 0) rng_bump[1] += 1;        // this update's draws (sampling, smoothing noise) are done
     // a wave reads a whole row pair [h2_a | h2_b] = 512 floats as two float4 per lane (lanes 0-31: critic a, 32-63: critic b); 4 rows per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane >> 5, l = lane & 31;
@@ -231,8 +271,8 @@ __global__ __launch_bounds__(256) void k_wgrad(const float *__restrict__ dH, int
 //      holds a complete transition, then the gather of K1.  *total = transitions written so far (may exceed the capacity: the ring wraps);
 //      guard = rows after position *total that concurrent writers may be filling right now (0 for a synchronous loop): they are excluded
 //      once the ring has wrapped onto them.
-__global__ void k_sample_gather(const float *__restrict__ data, const float *__restrict__ u, const int64_t *__restrict__ total, int64_t capacity, int64_t guard,
-                                int64_t *__restrict__ idx_out, float *__restrict__ out, float *__restrict__ sa_pi, float *loss, int B) {
+__global__ void k_sample_gather(const float *__restrict__ data, const float *__restrict__ u, const uint64_t *__restrict__ rng, const int64_t *__restrict__ total,
+                                int64_t capacity, int64_t guard, int64_t *__restrict__ idx_out, float *__restrict__ out, float *__restrict__ sa_pi, float *loss, int B) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0 && loss) { loss[0] = 0.f; loss[1] = 0.f; }
     const int b = t / TD3_ROW, c = t % TD3_ROW;
@@ -241,7 +281,8 @@ __global__ void k_sample_gather(const float *__restrict__ data, const float *__r
     int64_t filled, start;
     if (tot + guard <= capacity) { filled = tot; start = 0; }                               // ring not yet wrapped onto the rows in flight
     else { filled = capacity - guard; start = (tot + guard) % capacity; }                   // the oldest complete row follows the rows in flight
-    int64_t i = (int64_t)(u[b] * (float)filled);
+    const float ub = u ? u[b] : rng_uniform(rng, 0u, (uint32_t)b);
+    int64_t i = (int64_t)((double)ub * (double)filled);
     i = i < filled - 1 ? i : filled - 1;
     i = i > 0 ? i : 0;
     i = (start + i) % capacity;
@@ -252,16 +293,22 @@ __global__ void k_sample_gather(const float *__restrict__ data, const float *__r
 }
 
 // ---- K13: exploration action of the collect phase (plen_td3.py:101-104): a = clamp(max_a tanh(pre) + noise * sigma, +-max_a)
-__global__ void k_explore(const float *__restrict__ pre, const float *__restrict__ noise, float *__restrict__ a, float sigma, float max_a, int n) {
+__global__ void k_explore(const float *__restrict__ pre, const float *__restrict__ noise, const uint64_t *__restrict__ rng, float *__restrict__ a, float sigma, float max_a, int n) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) a[t] = fminf(fmaxf(max_a * tanhf(pre[t]) + noise[t] * sigma, -max_a), max_a);
+    if (t < n) a[t] = fminf(fmaxf(max_a * tanhf(pre[t]) + (noise ? noise[t] : rng_normal(rng, 2u, (uint32_t)t)) * sigma, -max_a), max_a);
+}
+// uniform random actions of the warm-up phase (plen_td3.py:91-92 env.action_space.sample()): a = U[-1, 1)
+__global__ void k_uniform_actions(const uint64_t *__restrict__ rng, float *__restrict__ a, int n) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) a[t] = 2.0f * rng_uniform(rng, 3u, (uint32_t)t) - 1.0f;
 }
 
 // ---- K14: write one vector step into the replay ring (plen_td3.py:109-113): row (total + e) % capacity = s | a | s2 | r | 1 - done_bool,
 //      done_bool = compute_done() fired AND the time limit did not (PLENVEC_DONE_TERMINAL = 1, _TIMELIMIT = 2)
 __global__ void k_store(float *__restrict__ data, const int64_t *__restrict__ total, int64_t capacity, const float *__restrict__ s, const float *__restrict__ a,
-                        const float *__restrict__ s2, const float *__restrict__ r, const uint8_t *__restrict__ done, int n) {
+                        const float *__restrict__ s2, const float *__restrict__ r, const uint8_t *__restrict__ done, uint64_t *rng_bump, int n) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rng_bump && t == 0) rng_bump[1] += 1;           // this collect step's action draw is done
     const int e = t / TD3_ROW, c = t % TD3_ROW;
     if (e >= n) return;
     const int64_t row = (total[0] + e) % capacity;
@@ -282,14 +329,17 @@ extern "C" {
 int plentd3_gather(const float *data, const int64_t *idx, float *out, float *sa_pi, float *loss, int B, void *stream) {
     hipLaunchKernelGGL(k_gather, GRID(B * TD3_ROW), data, idx, out, sa_pi, loss, B); CHECK();
 }
-int plentd3_sample_gather(const float *data, const float *u, const int64_t *total, int64_t capacity, int64_t guard, int64_t *idx_out, float *out, float *sa_pi, float *loss, int B, void *stream) {
-    hipLaunchKernelGGL(k_sample_gather, GRID(B * TD3_ROW), data, u, total, capacity, guard, idx_out, out, sa_pi, loss, B); CHECK();
+int plentd3_sample_gather(const float *data, const float *u, const uint64_t *rng, const int64_t *total, int64_t capacity, int64_t guard, int64_t *idx_out, float *out, float *sa_pi, float *loss, int B, void *stream) {
+    hipLaunchKernelGGL(k_sample_gather, GRID(B * TD3_ROW), data, u, rng, total, capacity, guard, idx_out, out, sa_pi, loss, B); CHECK();
 }
-int plentd3_explore(const float *pre, const float *noise, float *a, float sigma, float max_a, int n, void *stream) {
-    hipLaunchKernelGGL(k_explore, GRID(n), pre, noise, a, sigma, max_a, n); CHECK();
+int plentd3_explore(const float *pre, const float *noise, const uint64_t *rng, float *a, float sigma, float max_a, int n, void *stream) {
+    hipLaunchKernelGGL(k_explore, GRID(n), pre, noise, rng, a, sigma, max_a, n); CHECK();
 }
-int plentd3_store(float *data, const int64_t *total, int64_t capacity, const float *s, const float *a, const float *s2, const float *r, const uint8_t *done, int n, void *stream) {
-    hipLaunchKernelGGL(k_store, GRID(n * TD3_ROW), data, total, capacity, s, a, s2, r, done, n); CHECK();
+int plentd3_uniform_actions(const uint64_t *rng, float *a, int n, void *stream) {
+    hipLaunchKernelGGL(k_uniform_actions, GRID(n), rng, a, n); CHECK();
+}
+int plentd3_store(float *data, const int64_t *total, int64_t capacity, const float *s, const float *a, const float *s2, const float *r, const uint8_t *done, uint64_t *rng_bump, int n, void *stream) {
+    hipLaunchKernelGGL(k_store, GRID(n * TD3_ROW), data, total, capacity, s, a, s2, r, done, rng_bump, n); CHECK();
 }
 int plentd3_wgrad(const float *dH, int dh_stride, const float *X, int x_stride, float *dW, int dw_stride, float *db, int B, int N, int K, void *stream) {
     const int tiles = ((N + 31) / 32) * ((K + 31) / 32);
@@ -302,12 +352,12 @@ int plentd3_wgrad(const float *dH, int dh_stride, const float *X, int x_stride, 
     chunks = (B + rows - 1) / rows;
     hipLaunchKernelGGL(k_wgrad, dim3(tiles * chunks), dim3(256), 0, (hipStream_t)stream, dH, dh_stride, X, x_stride, dW, dw_stride, db, B, N, K, rows); CHECK();
 }
-int plentd3_target_action(const float *pre, const float *noise, const float *batch, float *sa2, float sigma, float clip, float max_a, int B, void *stream) {
-    hipLaunchKernelGGL(k_target_action, GRID(B * TD3_SA), pre, noise, batch, sa2, sigma, clip, max_a, B); CHECK();
+int plentd3_target_action(const float *pre, const float *noise, const uint64_t *rng, const float *batch, float *sa2, float sigma, float clip, float max_a, int B, void *stream) {
+    hipLaunchKernelGGL(k_target_action, GRID(B * TD3_SA), pre, noise, rng, batch, sa2, sigma, clip, max_a, B); CHECK();
 }
 int plentd3_q_heads(const float *h2, const float *w3a, const float *b3a, const float *w3b, const float *b3b, const float *batch, float *y, float *dq,
-                    float *loss, float *db3a, float *db3b, float gamma, int B, int mode, void *stream) {
-    hipLaunchKernelGGL(k_q_heads, dim3((B + 15) / 16), dim3(256), 0, (hipStream_t)stream, h2, w3a, b3a, w3b, b3b, batch, y, dq, loss, db3a, db3b, gamma, B, mode); CHECK();
+                    float *loss, float *db3a, float *db3b, uint64_t *rng_bump, float gamma, int B, int mode, void *stream) {
+    hipLaunchKernelGGL(k_q_heads, dim3((B + 15) / 16), dim3(256), 0, (hipStream_t)stream, h2, w3a, b3a, w3b, b3b, batch, y, dq, loss, db3a, db3b, rng_bump, gamma, B, mode); CHECK();
 }
 int plentd3_dh2(const float *dq, const float *w3a, const float *w3b, const float *h2, float *dh2, int B, int ncrit, int h2_stride, void *stream) {
     hipLaunchKernelGGL(k_dh2, GRID(B * ncrit * TD3_H), dq, w3a, w3b, h2, dh2, B, ncrit, h2_stride); CHECK();

@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libplentd3.so")
-EXPORTS = ["plentd3_gather", "plentd3_sample_gather", "plentd3_explore", "plentd3_store", "plentd3_target_action", "plentd3_q_heads", "plentd3_dh2", "plentd3_relu_mask", "plentd3_colsum", "plentd3_wgrad",
+EXPORTS = ["plentd3_gather", "plentd3_sample_gather", "plentd3_explore", "plentd3_uniform_actions", "plentd3_store", "plentd3_target_action", "plentd3_q_heads", "plentd3_dh2", "plentd3_relu_mask", "plentd3_colsum", "plentd3_wgrad",
            "plentd3_tanh_out", "plentd3_dtanh", "plentd3_bias_relu", "plentd3_polyak", "plentd3_version"]
 ROW, S, A, SA, H = 72, 26, 18, 44, 256
 _lib = None
@@ -36,11 +36,12 @@ def load():
         lib.plentd3_version.restype = C.c_char_p
         vp, i, f = C.c_void_p, C.c_int, C.c_float
         lib.plentd3_gather.argtypes = [vp, vp, vp, vp, vp, i, vp]
-        lib.plentd3_sample_gather.argtypes = [vp, vp, vp, C.c_int64, C.c_int64, vp, vp, vp, vp, i, vp]
-        lib.plentd3_explore.argtypes = [vp, vp, vp, f, f, i, vp]
-        lib.plentd3_store.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, i, vp]
-        lib.plentd3_target_action.argtypes = [vp, vp, vp, vp, f, f, f, i, vp]
-        lib.plentd3_q_heads.argtypes = [vp] * 11 + [f, i, i, vp]
+        lib.plentd3_sample_gather.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int64, vp, vp, vp, vp, i, vp]
+        lib.plentd3_explore.argtypes = [vp, vp, vp, vp, f, f, i, vp]
+        lib.plentd3_uniform_actions.argtypes = [vp, vp, i, vp]
+        lib.plentd3_store.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, i, vp]
+        lib.plentd3_target_action.argtypes = [vp, vp, vp, vp, vp, f, f, f, i, vp]
+        lib.plentd3_q_heads.argtypes = [vp] * 12 + [f, i, i, vp]
         lib.plentd3_dh2.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp]
         lib.plentd3_relu_mask.argtypes = [vp, vp, i, i, i, vp]
         lib.plentd3_colsum.argtypes = [vp, i, vp, i, vp, i, i, vp]
@@ -65,10 +66,12 @@ def _chk(rc):
 class FusedTD3(object):
     """update(data, idx, with_policy) == td3.td3_update(agent, (data rows idx split into s, a, s2, r, not_done), with_policy)."""
 
-    def __init__(self, agent):
+    def __init__(self, agent, seed=0):
         if agent.device.type != "cuda":
             raise PlenTd3Error("FusedTD3 needs the agent on a HIP device")
         self.agent = agent
+        # counter-based RNG state of the update's draws (replay indices, target-smoothing noise): {seed, calls so far} on the device
+        self.rng = self.new_rng(agent.device, seed)
         self.lib = load()
         self.dev = agent.device
         # does the GEMM library fuse bias + ReLU into the epilogue here?  (hipBLASLt: yes; verified numerically once)
@@ -86,6 +89,11 @@ class FusedTD3(object):
         K = x.shape[1]
         assert dh.stride(1) == 1 and x.stride(1) == 1 and gw.is_contiguous() and gw.shape == (N, K)
         _chk(self.lib.plentd3_wgrad(_p(dh), dh.stride(0), _p(x), x.stride(0), _p(gw), K, _p(gb), B, N, K, self._stream()))
+
+    @staticmethod
+    def new_rng(device, seed):
+        """Device state of one random stream for the kernels' Philox draws: int64[2] = {seed, calls so far}."""
+        return torch.tensor([int(seed) & 0x7fffffffffffffff, 0], dtype=torch.long, device=device)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
@@ -113,26 +121,34 @@ class FusedTD3(object):
             self.polyak()
         return loss
 
-    def explore(self, state, sigma, actor=None):
-        """Collect-phase action (plen_td3.py:101-104): clamp(actor(state) + N(0, sigma), +-max_action) -- 3 GEMMs, the noise draw, one fused kernel.
-        `actor`: the network to act with (default the online actor; the pipelined trainer passes a behaviour copy)."""
+    def explore(self, state, sigma, actor=None, rng=None):
+        """Collect-phase action (plen_td3.py:101-104): clamp(actor(state) + N(0, sigma), +-max_action) -- 3 GEMMs and one fused kernel that draws
+        its own noise from `rng` (new_rng(); bumped by the store() that follows).  `actor`: the network to act with (default the online
+        actor; the pipelined trainer passes a behaviour copy).  rng None: torch.randn (autograd-path compatible)."""
         ag = self.agent
         ac = ag.actor if actor is None else actor
         with torch.no_grad():
             p2 = self._lin_relu(self._lin_relu(state, ac.fc1.weight, ac.fc1.bias), ac.fc2.weight, ac.fc2.bias)
             pre = torch.addmm(ac.fc3.bias, p2, ac.fc3.weight.t())
-            noise = torch.randn_like(pre)
+            noise = torch.randn_like(pre) if rng is None else None
             a = torch.empty_like(pre)
-            _chk(self.lib.plentd3_explore(_p(pre), _p(noise), _p(a), float(sigma), float(ag.max_action), pre.numel(), self._stream()))
+            _chk(self.lib.plentd3_explore(_p(pre), _p(noise), _p(rng), _p(a), float(sigma), float(ag.max_action), pre.numel(), self._stream()))
         return a
 
-    def store(self, data, total, state, action, next_obs, reward, done):
-        """One vector step into the packed replay ring at positions (total + e) % capacity (plen_td3.py:109-113); `total` = device int64 scalar."""
+    def uniform_actions(self, n, rng):
+        """Warm-up actions U[-1, 1)^18 for n envs (plen_td3.py:91-92), drawn in-kernel from `rng` (bumped by the store() that follows)."""
+        a = torch.empty(n, A, device=self.dev, dtype=torch.float32)
+        _chk(self.lib.plentd3_uniform_actions(_p(rng), _p(a), n * A, self._stream()))
+        return a
+
+    def store(self, data, total, state, action, next_obs, reward, done, rng=None):
+        """One vector step into the packed replay ring at positions (total + e) % capacity (plen_td3.py:109-113); `total` = device int64 scalar.
+        rng: the collect stream's random state, whose call counter this kernel advances."""
         n = int(state.shape[0])
         for t in (state, action, next_obs, reward):
             assert t.dtype == torch.float32 and t.is_contiguous()
         assert done.dtype == torch.uint8 and total.dtype == torch.long
-        _chk(self.lib.plentd3_store(_p(data), _p(total), int(data.shape[0]), _p(state), _p(action), _p(next_obs), _p(reward), _p(done), n, self._stream()))
+        _chk(self.lib.plentd3_store(_p(data), _p(total), int(data.shape[0]), _p(state), _p(action), _p(next_obs), _p(reward), _p(done), _p(rng), n, self._stream()))
 
     def critic_backward(self, data, idx, noise=None, total=None, guard=0):
         """Sample, targets, critic forward / loss / backward: gradients land in the critic's flat bucket.  Returns the loss (device scalar).
@@ -144,8 +160,7 @@ class FusedTD3(object):
         if isinstance(idx, int):
             B = idx
             batch, sa_pi, loss = new(B, ROW), new(B, SA), new(2)
-            u = torch.rand(B, device=dev)
-            _chk(lib.plentd3_sample_gather(_p(data), _p(u), _p(total), int(data.shape[0]), int(guard), None, _p(batch), _p(sa_pi), _p(loss), B, st))
+            _chk(lib.plentd3_sample_gather(_p(data), None, _p(self.rng), _p(total), int(data.shape[0]), int(guard), None, _p(batch), _p(sa_pi), _p(loss), B, st))
         else:
             B = int(idx.shape[0])
             assert idx.dtype == torch.long
@@ -159,10 +174,9 @@ class FusedTD3(object):
             a1 = self._lin_relu(s2, at.fc1.weight, at.fc1.bias)
             a2 = self._lin_relu(a1, at.fc2.weight, at.fc2.bias)
             pre = torch.addmm(at.fc3.bias, a2, at.fc3.weight.t())
-            if noise is None:
-                noise = torch.randn(B, A, device=dev)
-            sa2 = new(B, SA)
-            _chk(lib.plentd3_target_action(_p(pre), _p(noise.contiguous()), _p(batch), _p(sa2), float(ag.policy_noise), float(ag.noise_clip), float(ag.max_action), B, st))
+            sa2 = new(B, SA)          # noise None: the kernel draws torch.randn_like(action)'s equivalent itself (Philox, self.rng)
+            _chk(lib.plentd3_target_action(_p(pre), _p(None if noise is None else noise.contiguous()), _p(self.rng), _p(batch), _p(sa2),
+                                           float(ag.policy_noise), float(ag.noise_clip), float(ag.max_action), B, st))
             tv = ag._critic_target_flat.views
             h1 = self._lin_relu(sa2, tv["W14"], tv["b14"])                       # both target critics' first layers in one GEMM
             h2 = new(B, 2 * H)
@@ -171,7 +185,7 @@ class FusedTD3(object):
             if relu_both:
                 h2.relu_()
             y = new(B)
-            _chk(lib.plentd3_q_heads(_p(h2), _p(ct.fc3.weight), _p(ct.fc3.bias), _p(ct.fc6.weight), _p(ct.fc6.bias), _p(batch), _p(y), None, None, None, None,
+            _chk(lib.plentd3_q_heads(_p(h2), _p(ct.fc3.weight), _p(ct.fc3.bias), _p(ct.fc6.weight), _p(ct.fc6.bias), _p(batch), _p(y), None, None, None, None, None,
                                      float(ag.discount), B, 0, st))
             # ---- critic forward, loss, backward (td3.py:312-331) ----
             cr = ag.critic
@@ -185,7 +199,7 @@ class FusedTD3(object):
                 c2.relu_()
             dq = new(B, 2)
             _chk(lib.plentd3_q_heads(_p(c2), _p(cr.fc3.weight), _p(cr.fc3.bias), _p(cr.fc6.weight), _p(cr.fc6.bias), _p(batch), _p(y), _p(dq), _p(loss),
-                                     _p(cr.fc3.bias.grad), _p(cr.fc6.bias.grad), float(ag.discount), B, 1, st))
+                                     _p(cr.fc3.bias.grad), _p(cr.fc6.bias.grad), _p(self.rng), float(ag.discount), B, 1, st))
             # last layer weight gradients: dW3_c = h2_c^T dq_c
             _chk(lib.plentd3_colsum(_p(c2), 2 * H, _p(dq), 2, _p(cr.fc3.weight.grad), B, H, st))
             _chk(lib.plentd3_colsum(C.c_void_p(c2.data_ptr() + 4 * H), 2 * H, C.c_void_p(dq.data_ptr() + 4), 2, _p(cr.fc6.weight.grad), B, H, st))

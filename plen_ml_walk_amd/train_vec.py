@@ -209,7 +209,8 @@ class GraphedVecTD3Trainer(object):
         self.fused = None
         if fused:
             from .td3_fused import FusedTD3
-            self.fused = FusedTD3(agent)
+            self.fused = FusedTD3(agent, seed=seed)
+            self._collect_rng = FusedTD3.new_rng(agent.device, seed + 7919)
         self.env, self.agent, self.replay = env, agent, replay
         self.start_timesteps, self.expl_noise = start_timesteps, expl_noise
         self.batch_size, self.updates_per_step = batch_size, updates_per_step
@@ -236,17 +237,19 @@ class GraphedVecTD3Trainer(object):
         self._batch = None          # the sampled batch of the update in flight (static tensors once captured)
 
         def collect(random_actions):
-            if random_actions:
+            if random_actions and self.fused is not None:
+                action = self.fused.uniform_actions(n, self._collect_rng)
+            elif random_actions:
                 action = torch.rand(n, 18, device=dev) * 2 - 1
             elif self.fused is not None:
-                action = self.fused.explore(self.state, agent.max_action * expl_noise)
+                action = self.fused.explore(self.state, agent.max_action * expl_noise, rng=self._collect_rng)
             else:
                 with torch.no_grad():
                     action = agent.actor(self.state)
                     action = (action + torch.randn_like(action) * (agent.max_action * expl_noise)).clamp(-agent.max_action, agent.max_action)
             next_obs, reward, done, info = env.step(action)
             if self.fused is not None and next_obs.dtype == torch.float32:
-                self.fused.store(replay.data, self.total_t, self.state, action, next_obs, reward, done)      # one kernel: packed rows into the ring
+                self.fused.store(replay.data, self.total_t, self.state, action, next_obs, reward, done, rng=self._collect_rng)      # one kernel: packed rows into the ring
             else:
                 idx = (self.total_t + self.arange_n) % replay.max_size
                 terminal = ((done & 1) != 0) & ((done & 2) == 0)
@@ -401,7 +404,8 @@ class PipelinedVecTD3Trainer(object):
         self.start_timesteps, self.expl_noise, self.batch_size = start_timesteps, expl_noise, batch_size
         dev = agent.device
         assert replay.max_size >= 4 * self.n, "the ring must hold more than the rows in flight"
-        self.fused = FusedTD3(agent)
+        self.fused = FusedTD3(agent, seed=seed)
+        self.rngs = [FusedTD3.new_rng(dev, seed + 7919 * (h + 1)) for h in range(2)]              # one random stream per collector
         torch.manual_seed(seed)
         agent.actor_optimizer = GraphedVecTD3Trainer._capturable_adam(agent.actor_optimizer, agent.actor)
         agent.critic_optimizer = GraphedVecTD3Trainer._capturable_adam(agent.critic_optimizer, agent.critic)
@@ -426,11 +430,11 @@ class PipelinedVecTD3Trainer(object):
         env, nh = self.envs[h], self.nh
         dev = self.agent.device
         if random_actions:
-            action = torch.rand(nh, 18, device=dev) * 2 - 1
+            action = self.fused.uniform_actions(nh, self.rngs[h])
         else:
-            action = self.fused.explore(self.state[h], self.agent.max_action * self.expl_noise, actor=self.behaviour[buf])
+            action = self.fused.explore(self.state[h], self.agent.max_action * self.expl_noise, actor=self.behaviour[buf], rng=self.rngs[h])
         next_obs, reward, done, info = env.step(action)
-        self.fused.store(self.replay.data, self.base[h], self.state[h], action, next_obs, reward, done)
+        self.fused.store(self.replay.data, self.base[h], self.state[h], action, next_obs, reward, done, rng=self.rngs[h])
         self.base[h] += self.n
         self.state[h].copy_(info["obs"])
 

@@ -366,3 +366,41 @@ def test_pipelined_trainer_overlaps_without_races():
             e.close()
     assert torch.equal(runs[1], runs[2])          # collection (RNG, env steps, ring writes on two streams): bitwise reproducible
     assert not torch.equal(runs[0], runs[1])      # ... and the learning run did act with a learned policy
+
+
+def test_in_kernel_philox_draws():
+    """The kernels' own random numbers (Philox4x32-10 + Box-Muller; no library RNG call inside the captured graphs): uniform actions and
+    exploration noise have the right moments, differ between calls (the following store() bumps the call counter) and between seeds, and
+    are reproducible for equal (seed, call)."""
+    from plen_ml_walk_amd.td3 import TD3Agent
+    from plen_ml_walk_amd.td3_fused import FusedTD3
+    ag = TD3Agent(26, 18, 1.0, data_parallel=False)
+    with torch.no_grad():
+        ag.actor.fc3.weight.zero_(); ag.actor.fc3.bias.zero_()          # actor(state) == 0: explore() returns the clipped noise itself
+    fz = FusedTD3(ag)
+    n = 4096
+    state = torch.zeros(n, 26, device="cuda")
+    data = torch.zeros(4 * n, 72, device="cuda"); total = torch.zeros((), dtype=torch.long, device="cuda")
+    rew = torch.zeros(n, device="cuda"); done = torch.zeros(n, dtype=torch.uint8, device="cuda")
+
+    def draws(seed, calls):
+        rng = FusedTD3.new_rng("cuda", seed)
+        out = []
+        for _ in range(calls):
+            u = fz.uniform_actions(n, rng)
+            e = fz.explore(state, 0.2, rng=rng)                                 # clip at 5 sigma: moments of the plain normal
+            fz.store(data, total, state, u, state, rew, done, rng=rng)          # bumps the call counter
+            out.append((u.clone(), e.clone()))
+        assert int(rng[1]) == calls
+        return out
+    a, b, c = draws(11, 2), draws(11, 2), draws(12, 1)
+    for (u, e) in a:
+        assert abs(float(u.mean())) < 0.01 and abs(float(u.var()) - 1 / 3) < 0.01 and float(u.min()) >= -1 and float(u.max()) < 1
+        assert abs(float(e.mean())) < 0.005 and abs(float(e.std()) - 0.2) < 0.004 and float(e.abs().max()) <= 1.0
+        z = e / 0.2
+        assert abs(float((z ** 4).mean()) - 3.0) < 0.15 and abs(float((z ** 3).mean())) < 0.05      # normal kurtosis, no skew
+    assert torch.equal(a[0][0], b[0][0]) and torch.equal(a[1][1], b[1][1])    # same (seed, call): same numbers
+    assert not torch.equal(a[0][0], a[1][0]) and not torch.equal(a[0][0], c[0][0])
+    # no visible correlation between neighbouring elements or between the two draws of one call
+    u, e = a[0]
+    assert abs(float((u[:, :-1] * u[:, 1:]).mean())) < 0.01 and abs(float((u * e).mean())) < 0.01
