@@ -343,7 +343,8 @@ class GraphedVecTD3Trainer(object):
             self._eager_runs[key] = runs + 1
             return
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: another thread's HIP calls (the RCCL watchdog's event queries when world_size > 1) must not invalidate the capture
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             fn(*args)
         self._graphs[key] = g
         g.replay()                                   # the capture itself does not execute
@@ -455,7 +456,7 @@ class PipelinedVecTD3Trainer(object):
                     self._eager_runs[key] = runs + 1
                     return
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=stream):
+                with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
                     fn(*args)
                 self._graphs[key] = g
             g.replay()
