@@ -30,6 +30,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")        # before the HIP runtime initialises: see plen_ml_walk_amd/__init__.py
 
 ENVS_PER_GPU = 4096
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec

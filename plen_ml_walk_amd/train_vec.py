@@ -414,7 +414,8 @@ class PipelinedVecTD3Trainer(object):
         self.behaviour = [copy.deepcopy(agent.actor) for _ in range(3)]
         self.bflat = [T._FlatParams(b) for b in self.behaviour]
         self.streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
-        self.su = torch.cuda.Stream(device=dev)
+        # the update is ~50 short kernels that must slip in beside two long env launches: give its stream dispatch priority
+        self.su = torch.cuda.Stream(device=dev, priority=int(os.environ.get("PLEN_TD3_UPDATE_PRIORITY", "-1")))
         self.state = [e.reset().to(torch.float32).clone() for e in envs]
         self.base = [torch.tensor(h * self.nh, dtype=torch.long, device=dev) for h in range(2)]       # next ring row of each half
         self.total_u = torch.zeros((), dtype=torch.long, device=dev)                                  # rows complete before the current step

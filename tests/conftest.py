@@ -2,6 +2,8 @@ import os
 import sys
 import pytest
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # as plen_ml_walk_amd/__init__.py: before the HIP runtime initialises
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
