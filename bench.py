@@ -215,7 +215,19 @@ def env_leg(a, dtype_name, dev, rank, world, dist, steps, warmup):
 
 
 def td3_leg(a, dev, rank, world, dist, steps, warmup):
-    """BASELINE.json configs[2] (N = 1) / configs[3] (N > 1): envs + the full TD3 training loop on the same device(s)."""
+    """BASELINE.json configs[2] (N = 1) / configs[3] (N > 1): envs + the full TD3 training loop on the same device(s), at the benchmark's batch
+    (--td3-batch, default 4096 = as many samples per vector step as env-steps) and, beside it, at the reference's batch of 100 (td3.py:259)."""
+    out = _td3_run(a, dev, rank, world, dist, steps, warmup, a.td3_batch)
+    if a.td3_batch != 100:
+        try:
+            r = _td3_run(a, dev, rank, world, dist, max(50, steps // 2), warmup, 100)
+            out["reference_batch_100"] = {k: r[k] for k in ("value", "unit", "grad_steps_per_s", "ms_per_step", "batch_per_rank", "update_to_data")}
+        except Exception as ex:
+            out["reference_batch_100"] = {"value": None, "error": repr(ex)}
+    return out
+
+
+def _td3_run(a, dev, rank, world, dist, steps, warmup, batch):
     import torch
     from plen_ml_walk_amd import sharding
     from plen_ml_walk_amd.vec_env import PlenVecEnv
@@ -237,14 +249,14 @@ def td3_leg(a, dev, rank, world, dist, steps, warmup):
             ms, mu = 0.8 + 0.4 * torch.rand(n, generator=gd, device=dev), 0.4 + 0.6 * torch.rand(n, generator=gd, device=dev)
             for h, e in enumerate(envs):
                 e.set_params(mass_scale=ms[h * n // 2:(h + 1) * n // 2], lateral_friction=mu[h * n // 2:(h + 1) * n // 2])
-        tr = PipelinedVecTD3Trainer(envs, agent, replay, start_timesteps=10000, expl_noise=0.1, batch_size=a.td3_batch, seed=1000 + rank)
+        tr = PipelinedVecTD3Trainer(envs, agent, replay, start_timesteps=10000, expl_noise=0.1, batch_size=batch, seed=1000 + rank)
     else:
         envs = [PlenVecEnv(n, device=dev)]
         env = envs[0]
         if a.dr:
             gd = torch.Generator(device=dev).manual_seed(1000 + rank)
             env.set_params(mass_scale=0.8 + 0.4 * torch.rand(n, generator=gd, device=dev), lateral_friction=0.4 + 0.6 * torch.rand(n, generator=gd, device=dev))
-        tr = GraphedVecTD3Trainer(env, agent, replay, start_timesteps=10000, expl_noise=0.1, batch_size=a.td3_batch, updates_per_step=a.td3_updates, seed=1000 + rank)
+        tr = GraphedVecTD3Trainer(env, agent, replay, start_timesteps=10000, expl_noise=0.1, batch_size=batch, updates_per_step=a.td3_updates, seed=1000 + rank)
 
     def barrier():
         torch.cuda.synchronize()
@@ -262,9 +274,9 @@ def td3_leg(a, dev, rank, world, dist, steps, warmup):
     dt = sharding.max_over_ranks(time.perf_counter() - t0, dev)
     out = {"value": world * (tr.env_steps - e0) / dt, "unit": "env-steps/s", "grad_steps_per_s": (tr.grad_steps - g0) / dt,
            "env_dtype": "f32", "net_dtype": "f32", "steps": steps, "ms_per_step": dt / steps * 1e3,
-           "batch_per_rank": a.td3_batch, "updates_per_vector_step": a.td3_updates, "replay_capacity": 1000000, "start_timesteps": 10000,
-           "update_to_data": "%d gradient step(s) of batch %d per vector step of %d env-steps per rank (samples drawn per env-step: %.2f; the reference "
-                             "does 1 step of batch 100 per single env-step, plen_td3.py:119-120)" % (a.td3_updates, a.td3_batch, n, a.td3_updates * a.td3_batch / n),
+           "batch_per_rank": batch, "updates_per_vector_step": a.td3_updates, "replay_capacity": 1000000, "start_timesteps": 10000,
+           "update_to_data": "%d gradient step(s) of batch %d per vector step of %d env-steps per rank (samples drawn per env-step: %.3f; the reference "
+                             "does 1 step of batch 100 per single env-step, plen_td3.py:119-120)" % (a.td3_updates, batch, n, a.td3_updates * batch / n),
            "hip_graphs": True,
            "schedule": ("actor/learner overlap: 2 half batches of %d envs and the update on three HIP streams, acting policy two updates old (train_vec.PipelinedVecTD3Trainer)" % (n // 2))
                        if pipelined else "synchronous: collect all envs, then update (train_vec.GraphedVecTD3Trainer)",
