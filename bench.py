@@ -10,6 +10,7 @@ data-path collective (weak scaling).
 The headline `value` is measured in the REFERENCE'S arithmetic, f64 (PyBullet is a double-precision build and
 plen_env.py computes in NumPy float64); the same JSON line carries two more legs measured by the same process:
   legs.f32 : the f32 kernel (what an RL loop uses; agrees with the f64 oracle statistically)
+  legs.dr  : BASELINE.json configs[4]: the headline workload with per-env domain randomisation (mass, friction)
   legs.td3 : BASELINE.json configs[2]/[3]: 4096 envs per GPU + the full TD3 loop (actor/critic/replay in
              PyTorch-ROCm on the same device, f32 env, hipGraph-captured; RCCL gradient all-reduce for N > 1):
              env-steps/s AND gradient-steps/s, batch and update-to-data ratio stated.
@@ -113,15 +114,17 @@ def spawn_ranks(argv, n):
 
 
 # ------------------------------------------------------------------------------------------------ legs
-def env_leg(a, dtype_name, dev, rank, world, dist, steps, warmup):
-    """Random-action rollout of a.envs_per_gpu envs on this rank; returns the timing dict (max over ranks)."""
+def env_leg(a, dtype_name, dev, rank, world, dist, steps, warmup, dr=None):
+    """Random-action rollout of a.envs_per_gpu envs on this rank; returns the timing dict (max over ranks).  dr: per-env domain randomisation
+    (BASELINE.json configs[4]); None = as --dr says."""
+    dr = a.dr if dr is None else dr
     import torch
     from plen_ml_walk_amd import sharding
     from plen_ml_walk_amd.vec_env import PlenVecEnvPipelined
     n = a.envs_per_gpu
     dtype = torch.float32 if dtype_name == "f32" else torch.float64
     env = PlenVecEnvPipelined(n, groups=a.groups, device=dev, dtype=dtype)
-    if a.dr:
+    if dr:
         gd = torch.Generator(device=dev).manual_seed(1000 + rank)
         env.set_params(mass_scale=0.8 + 0.4 * torch.rand(n, generator=gd, device=dev), lateral_friction=0.4 + 0.6 * torch.rand(n, generator=gd, device=dev))
     env.reset()
@@ -156,6 +159,9 @@ def env_leg(a, dtype_name, dev, rank, world, dist, steps, warmup):
     single = kernel_ms1 = launches1 = None
     if a.groups > 1:
         env1 = PlenVecEnvPipelined(n, groups=1, device=dev, dtype=dtype)
+        if dr:
+            gd = torch.Generator(device=dev).manual_seed(1000 + rank)
+            env1.set_params(mass_scale=0.8 + 0.4 * torch.rand(n, generator=gd, device=dev), lateral_friction=0.4 + 0.6 * torch.rand(n, generator=gd, device=dev))
         env1.reset()
         for t in range(10):
             env1.step_async(actions[t % ring])
@@ -295,7 +301,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--dtype", default="f64", choices=["f32", "f64"], help="arithmetic of the headline leg (f64 = the reference's)")
-    ap.add_argument("--legs", default="f64,f32,td3", help="comma list of legs to run besides the headline one (f64, f32, td3)")
+    ap.add_argument("--legs", default="f64,f32,td3,dr", help="comma list of legs to run besides the headline one (f64, f32, td3, dr)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dr", action="store_true", help="BASELINE.json configs[4]: per-env link-mass scale U[0.8,1.2] and foot friction U[0.4,1.0], seed 1000+rank")
     ap.add_argument("--groups", type=int, default=2, help="independent sub-batches per GPU, one HIP stream each (1 = a single launch per step)")
@@ -338,6 +344,11 @@ def main():
                 legs[name] = env_leg(a, name, dev, rank, world, dist, a.steps, a.warmup)
             elif name == "td3":
                 legs[name] = td3_leg(a, dev, rank, world, dist, a.td3_steps, a.warmup)
+            elif name == "dr" and not a.dr:          # configs[4] on this many GPUs: the headline workload with per-env mass / friction
+                r = env_leg(a, a.dtype, dev, rank, world, dist, a.steps, a.warmup, dr=True)
+                legs[name] = {k: r[k] for k in ("value", "unit", "dtype", "ms_per_step", "kernel_ms_per_launch", "nonfinite_resets")}
+                legs[name]["workload"] = ("BASELINE.json configs[4]: %d envs per GPU, per-env link-mass scale U[0.8,1.2] and foot friction U[0.4,1.0] (seed 1000 + rank); parameters are "
+                                          "wave-uniform scalars of each env's wavefront, so there is no lane divergence to pay for" % a.envs_per_gpu)
         except Exception as ex:                                  # the headline stands on its own; a failed leg is reported, not hidden
             legs[name] = {"value": None, "error": repr(ex)}       # (with N > 1 ranks fail alike: same code, same shapes, same device type)
 
