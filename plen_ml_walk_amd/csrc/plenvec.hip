@@ -103,17 +103,35 @@ __device__ __constant__ double c_range_hi[ND] = {1.57, 1.5, 0.75, 0.3, 1.2, 0.4,
 
 // ---------------------------------------------------------------- math wrappers
 // f32: 1-ulp hardware reciprocal / reciprocal square root where a correctly rounded division is not part of the contract
+// PLENVEC_EXACT_MATH (experiment build, scripts/gpu_f32_exact_math.py): correctly rounded division / square root and libm sine / cosine in
+// the f32 path instead of the 1-ulp hardware approximations -- to measure whether THEY are what separates f32 from the f64 oracle (they are not).
+#ifdef PLENVEC_EXACT_MATH
+__device__ inline float rcp_(float x) { return 1.0f / x; }
+#else
 __device__ inline float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
 __device__ inline double rcp_(double x) { return 1.0 / x; }
+#ifdef PLENVEC_EXACT_MATH
+__device__ inline float rsqrt_(float x) { return 1.0f / sqrtf(x); }
+#else
 __device__ inline float rsqrt_(float x) { return __builtin_amdgcn_rsqf(x); }
+#endif
 __device__ inline double rsqrt_(double x) { return 1.0 / sqrt(x); }
 __device__ inline float sqrt_(float x) { return sqrtf(x); }
 __device__ inline double sqrt_(double x) { return sqrt(x); }
 // f32: the hardware sine/cosine (v_sin_f32 / v_cos_f32 on x / 2pi).  Arguments here are joint angles (|q| < pi) and half rotation
 // angles per substep (< pi/8); measured max abs error on [-pi, pi]: 2.7e-7 (sinf: 6e-8) for 2 instructions instead of ~40.
+#ifdef PLENVEC_EXACT_MATH
+__device__ inline float sin_(float x) { return sinf(x); }
+#else
 __device__ inline float sin_(float x) { return __sinf(x); }
+#endif
 __device__ inline double sin_(double x) { return sin(x); }
+#ifdef PLENVEC_EXACT_MATH
+__device__ inline float cos_(float x) { return cosf(x); }
+#else
 __device__ inline float cos_(float x) { return __cosf(x); }
+#endif
 __device__ inline double cos_(double x) { return cos(x); }
 __device__ inline float atan2_(float y, float x) { return atan2f(y, x); }
 __device__ inline double atan2_(double y, double x) { return atan2(y, x); }
@@ -569,7 +587,7 @@ __device__ __forceinline__ void pgs_cone(real &e, const real u, real &dvec, cons
     const real len2 = q + quad_swap12(q);           // |s|^2 of the pair, in both of its lanes
     real scale;
     // Bullet clamps row A to |lim*sin(atan2(sA,sB))| and row B to |lim*cos(..)|: a radial projection onto the circle
-    if constexpr (sizeof(real) == 4) scale = min_(1.0f, lmv * __builtin_amdgcn_rsqf(len2));   // 0*inf = NaN -> 1 (s == 0 then); 1 ulp, f32 path only
+    if constexpr (sizeof(real) == 4) scale = min_(1.0f, lmv * rsqrt_(len2));                   // v_rsq_f32; 0*inf = NaN -> 1 (s == 0 then); 1 ulp, f32 path only
     else scale = len2 >= lmv * lmv ? (len2 > 0 ? lmv / sqrt_(len2) : (real)0) : (real)1;
     const real d = fma_(w, scale, -u);              // deltaVel of this lane's row
     const real dA = bcast(d, LA), dB = bcast(d, LB);
@@ -1043,7 +1061,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         constexpr int K = NV - 1 - decltype(kc)::value;
         const real piv = bcast(Lr[K], K);
         real rd;
-        if constexpr (sizeof(real) == 4) rd = __builtin_amdgcn_rsqf(piv);       // 1 ulp; f32 path only
+        if constexpr (sizeof(real) == 4) rd = rsqrt_(piv);                      // v_rsq_f32, 1 ulp; f32 path only
         else rd = (real)1 / sqrt_(piv);
         if (lane == 0) s.col[K] = rd;                      // collected below: every lane needs its own 1/L[k][k]
         const real lik = lane < K ? Lr[K] * rd : (real)0;      // L[K][i] in lane i < K; zero on and below the diagonal of L^T
