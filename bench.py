@@ -244,9 +244,9 @@ def _td3_run(a, dev, rank, world, dist, steps, warmup, batch):
     agent = TD3Agent(26, 18, 1.0, device=dev)
     replay = ReplayBuffer(1000000, device=dev)
     replay.seed(rank)
-    # one rank: actor / learner overlap (two half batches + the update on three streams); several ranks: the synchronous graph trainer with
-    # the gradient all-reduces between its graph segments
-    pipelined = world == 1 and a.td3_updates == 1 and a.td3_schedule == "pipelined" and n % 2 == 0
+    # actor / learner overlap (two half batches + the update on three streams per rank; with several ranks the gradient all-reduces sit between
+    # the update's graph segments), or --td3-schedule sync: the synchronous graph trainer
+    pipelined = a.td3_updates == 1 and a.td3_schedule == "pipelined" and n % 2 == 0
     if pipelined:
         envs = [PlenVecEnv(n // 2, device=dev) for _ in range(2)]
         env = envs[0]
@@ -308,7 +308,7 @@ def main():
     ap.add_argument("--td3-batch", type=int, default=4096)
     ap.add_argument("--td3-updates", type=int, default=1)
     ap.add_argument("--td3-steps", type=int, default=200)
-    ap.add_argument("--td3-schedule", default="pipelined", choices=["pipelined", "sync"], help="one rank: actor/learner overlap on three streams, or the synchronous graph loop")
+    ap.add_argument("--td3-schedule", default="pipelined", choices=["pipelined", "sync"], help="actor/learner overlap on three streams per rank, or the synchronous graph loop")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -378,8 +378,10 @@ class GraphedVecTD3Trainer(object):
 
 
 class PipelinedVecTD3Trainer(object):
-    """Actor / learner overlap on ONE GPU (single rank): the envs step as two half batches on their own HIP streams and the fused TD3
-    update runs on a third, all three replaying hipGraphs with only event dependencies between them.
+    """Actor / learner overlap on each rank's GPU: the envs step as two half batches on their own HIP streams and the fused TD3
+    update runs on a third, all three replaying hipGraphs with only event dependencies between them.  With world_size > 1 the update is cut at
+    its two gradient all-reduces into graph segments, the collectives issued on the update stream between the replays (like
+    GraphedVecTD3Trainer); envs, replay and random streams are rank-local.
 
     Why: one 4096-env launch owns every wave slot of the chip for as long as its slowest waves run, and the update's ~50 small kernels
     cannot start beside it (measured, scripts/gpu_overlap_probe.py: 4096 envs 0.52 ms + update 0.46 ms = 0.99 ms together); a 2048-env
@@ -396,9 +398,12 @@ class PipelinedVecTD3Trainer(object):
 
     def __init__(self, envs, agent, replay, start_timesteps=10000, expl_noise=0.1, batch_size=4096, seed=0):
         import copy
+        import torch.distributed as dist
         from . import td3 as T
         from .td3_fused import FusedTD3
         assert len(envs) == 2 and envs[0].num_envs == envs[1].num_envs and agent.device.type == "cuda"
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.allreduce_mode = None if self.world == 1 else "eager-between-graphs"
         self.envs, self.agent, self.replay = envs, agent, replay
         self.nh = envs[0].num_envs
         self.n = 2 * self.nh
@@ -443,8 +448,27 @@ class PipelinedVecTD3Trainer(object):
     def _update(self, with_policy, buf_out):
         loss = self.fused.update(self.replay.data, self.batch_size, with_policy, all_reduce=False, total=self.total_u, guard=2 * self.n)
         self._critic_loss.copy_(loss)
+        self._finish(buf_out)
+
+    def _finish(self, buf_out):
         self.total_u += self.n
         self.bflat[buf_out].flat.copy_(self.agent._actor_flat.flat)
+
+    # the same update cut at its collectives (world_size > 1)
+    def _seg_critic_backward(self):
+        self._critic_loss.copy_(self.fused.critic_backward(self.replay.data, self.batch_size, total=self.total_u, guard=2 * self.n))
+
+    def _seg_critic_step(self, with_policy, buf_out):
+        self.agent.critic_optimizer.step()
+        if with_policy:
+            self.fused.policy_backward()
+        else:
+            self._finish(buf_out)
+
+    def _seg_actor_step(self, buf_out):
+        self.agent.actor_optimizer.step()
+        self.fused.polyak()
+        self._finish(buf_out)
 
     def _run(self, key, stream, fn, *args):
         """fn(*args) on `stream`: eagerly the first two times the key is seen, then as a replay of its graph captured on that stream."""
@@ -480,7 +504,17 @@ class PipelinedVecTD3Trainer(object):
                 su.wait_event(ev)
         if learn:
             with_policy = (self.grad_steps + 1) % self.agent.policy_freq == 0
-            self._run(("update", with_policy, (t + 1) % 3), su, self._update, with_policy, (t + 1) % 3)
+            if self.world == 1:
+                self._run(("update", with_policy, (t + 1) % 3), su, self._update, with_policy, (t + 1) % 3)
+            else:
+                self._run(("critic_backward",), su, self._seg_critic_backward)
+                with torch.cuda.stream(su):
+                    self.agent._critic_grads.all_reduce_mean()
+                self._run(("critic_step", with_policy, (t + 1) % 3), su, self._seg_critic_step, with_policy, (t + 1) % 3)
+                if with_policy:
+                    with torch.cuda.stream(su):
+                        self.agent._actor_grads.all_reduce_mean()
+                    self._run(("actor_step", (t + 1) % 3), su, self._seg_actor_step, (t + 1) % 3)
             self.grad_steps += 1
             self.agent.total_it = self.grad_steps
         else:

@@ -13,21 +13,28 @@ sys.path.insert(0, ROOT)
 
 def main():
     out, fused = sys.argv[1], int(sys.argv[2])
+    pipelined = len(sys.argv) > 3 and sys.argv[3] == "pipelined"
     from plen_ml_walk_amd import sharding
-    from plen_ml_walk_amd.train_vec import setup_distributed, GraphedVecTD3Trainer
+    from plen_ml_walk_amd.train_vec import setup_distributed, GraphedVecTD3Trainer, PipelinedVecTD3Trainer
     from plen_ml_walk_amd.vec_env import PlenVecEnv
     from plen_ml_walk_amd.td3 import ReplayBuffer, TD3Agent
     rank, world = setup_distributed()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     torch.manual_seed(100 + rank)                      # DIFFERENT initial parameters per rank: the constructor must broadcast rank 0's
-    env = PlenVecEnv(256, device=dev)
+    envs = [PlenVecEnv(128, device=dev), PlenVecEnv(128, device=dev)] if pipelined else [PlenVecEnv(256, device=dev)]
+    env = envs[0]
     agent = TD3Agent(26, 18, 1.0, device=dev)
     init = torch.cat([p.detach().reshape(-1) for p in list(agent.actor.parameters()) + list(agent.critic.parameters())]).clone()
     replay = ReplayBuffer(20000, device=dev)
-    tr = GraphedVecTD3Trainer(env, agent, replay, start_timesteps=512, batch_size=256, updates_per_step=1, seed=1000 + rank, fused=bool(fused))
-    for _ in range(14):
+    if pipelined:
+        tr = PipelinedVecTD3Trainer(envs, agent, replay, start_timesteps=512, batch_size=256, seed=1000 + rank)
+    else:
+        tr = GraphedVecTD3Trainer(env, agent, replay, start_timesteps=512, batch_size=256, updates_per_step=1, seed=1000 + rank, fused=bool(fused))
+    for _ in range(14 if not pipelined else 24):
         tr.step()
+    if pipelined:
+        tr.sync()
     torch.cuda.synchronize()
     flat = torch.cat([p.detach().reshape(-1) for p in list(agent.actor.parameters()) + list(agent.critic.parameters())])
     tflat = torch.cat([p.detach().reshape(-1) for p in list(agent.actor_target.parameters()) + list(agent.critic_target.parameters())])
@@ -36,7 +43,7 @@ def main():
     tg = [torch.zeros_like(tflat) for _ in range(world)]
     dist.all_gather(tg, tflat)
     states = [torch.zeros(256, 26, device=dev) for _ in range(world)]
-    dist.all_gather(states, tr.state.contiguous())
+    dist.all_gather(states, (torch.cat(tr.state, 0) if pipelined else tr.state).contiguous())
     res = {"rank": rank, "world": world, "allreduce_mode": tr.allreduce_mode, "grad_steps": tr.grad_steps, "env_steps": tr.env_steps,
            "params_equal_across_ranks": bool(all(torch.equal(gathered[0], g) for g in gathered)),
            "targets_equal_across_ranks": bool(all(torch.equal(tg[0], g) for g in tg)),
@@ -46,7 +53,8 @@ def main():
            "graphs": sorted(str(k) for k in tr._graphs)}
     with open("%s.rank%d.json" % (out, rank), "w") as f:
         json.dump(res, f)
-    env.close()
+    for e in envs:
+        e.close()
     dist.barrier()
     dist.destroy_process_group()
 
