@@ -289,6 +289,8 @@ def _td3_run(a, dev, rank, world, dist, steps, warmup, batch):
            "collective": ("RCCL all-reduce of the flat critic (155138 f32) and actor (77330 f32) gradient buckets per update, mode %s" % getattr(tr, "allreduce_mode", None)) if world > 1 else None,
            "critic_loss": float(agent.last_critic_loss) if agent.last_critic_loss is not None else None,
            "workload": "BASELINE.json configs[%d]: %d envs per GPU + TD3 (actor 26-256-256-18, twin critic 44-256-256-1, Adam 3e-4, policy_freq 2), exploration N(0, 0.1)" % (2 if world == 1 else 3, n)}
+    if pipelined:
+        out["episodes_finished_since_start"] = tr.episode_stats()          # device-side bookkeeping of the ring-store kernel (returns of an untrained policy)
     for e in envs:
         e.close()
     return out

@@ -306,11 +306,19 @@ __global__ void k_uniform_actions(const uint64_t *__restrict__ rng, float *__res
 // ---- K14: write one vector step into the replay ring (plen_td3.py:109-113): row (total + e) % capacity = s | a | s2 | r | 1 - done_bool,
 //      done_bool = compute_done() fired AND the time limit did not (PLENVEC_DONE_TERMINAL = 1, _TIMELIMIT = 2)
 __global__ void k_store(float *__restrict__ data, const int64_t *__restrict__ total, int64_t capacity, const float *__restrict__ s, const float *__restrict__ a,
-                        const float *__restrict__ s2, const float *__restrict__ r, const uint8_t *__restrict__ done, uint64_t *rng_bump, int n) {
+                        const float *__restrict__ s2, const float *__restrict__ r, const uint8_t *__restrict__ done, uint64_t *rng_bump,
+                        float *__restrict__ ep_ret, float *stats, int n) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (rng_bump && t == 0) rng_bump[1] += 1;           // this collect step's action draw is done
     const int e = t / TD3_ROW, c = t % TD3_ROW;
     if (e >= n) return;
+    // episode bookkeeping at full speed (the reference prints every episode's return, plen_env.py:616-636): per-env running return; when the
+    // episode ends (any done bit) its return and length go into stats = {sum of returns, episodes, sum of lengths} and the env starts over
+    if (ep_ret && c == 0) {
+        const float ret = ep_ret[2 * e] + r[e], len = ep_ret[2 * e + 1] + 1.f;
+        if (done[e]) { atomicAdd(stats, ret); atomicAdd(stats + 1, 1.f); atomicAdd(stats + 2, len); ep_ret[2 * e] = 0.f; ep_ret[2 * e + 1] = 0.f; }
+        else { ep_ret[2 * e] = ret; ep_ret[2 * e + 1] = len; }
+    }
     const int64_t row = (total[0] + e) % capacity;
     float v;
     if (c < TD3_S) v = s[(size_t)e * TD3_S + c];
@@ -338,8 +346,9 @@ int plentd3_explore(const float *pre, const float *noise, const uint64_t *rng, f
 int plentd3_uniform_actions(const uint64_t *rng, float *a, int n, void *stream) {
     hipLaunchKernelGGL(k_uniform_actions, GRID(n), rng, a, n); CHECK();
 }
-int plentd3_store(float *data, const int64_t *total, int64_t capacity, const float *s, const float *a, const float *s2, const float *r, const uint8_t *done, uint64_t *rng_bump, int n, void *stream) {
-    hipLaunchKernelGGL(k_store, GRID(n * TD3_ROW), data, total, capacity, s, a, s2, r, done, rng_bump, n); CHECK();
+int plentd3_store(float *data, const int64_t *total, int64_t capacity, const float *s, const float *a, const float *s2, const float *r, const uint8_t *done, uint64_t *rng_bump,
+                  float *ep_ret, float *stats, int n, void *stream) {
+    hipLaunchKernelGGL(k_store, GRID(n * TD3_ROW), data, total, capacity, s, a, s2, r, done, rng_bump, ep_ret, stats, n); CHECK();
 }
 int plentd3_wgrad(const float *dH, int dh_stride, const float *X, int x_stride, float *dW, int dw_stride, float *db, int B, int N, int K, void *stream) {
     const int tiles = ((N + 31) / 32) * ((K + 31) / 32);

@@ -39,7 +39,7 @@ def load():
         lib.plentd3_sample_gather.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int64, vp, vp, vp, vp, i, vp]
         lib.plentd3_explore.argtypes = [vp, vp, vp, vp, f, f, i, vp]
         lib.plentd3_uniform_actions.argtypes = [vp, vp, i, vp]
-        lib.plentd3_store.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, i, vp]
+        lib.plentd3_store.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, i, vp]
         lib.plentd3_target_action.argtypes = [vp, vp, vp, vp, vp, f, f, f, i, vp]
         lib.plentd3_q_heads.argtypes = [vp] * 12 + [f, i, i, vp]
         lib.plentd3_dh2.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp]
@@ -141,14 +141,16 @@ class FusedTD3(object):
         _chk(self.lib.plentd3_uniform_actions(_p(rng), _p(a), n * A, self._stream()))
         return a
 
-    def store(self, data, total, state, action, next_obs, reward, done, rng=None):
+    def store(self, data, total, state, action, next_obs, reward, done, rng=None, episodes=None):
         """One vector step into the packed replay ring at positions (total + e) % capacity (plen_td3.py:109-113); `total` = device int64 scalar.
-        rng: the collect stream's random state, whose call counter this kernel advances."""
+        rng: the collect stream's random state, whose call counter this kernel advances.  episodes: (ep_ret [n, 2], stats [3]) float32 device
+        tensors for the episode bookkeeping (running return / length per env; finished episodes summed into stats)."""
         n = int(state.shape[0])
         for t in (state, action, next_obs, reward):
             assert t.dtype == torch.float32 and t.is_contiguous()
         assert done.dtype == torch.uint8 and total.dtype == torch.long
-        _chk(self.lib.plentd3_store(_p(data), _p(total), int(data.shape[0]), _p(state), _p(action), _p(next_obs), _p(reward), _p(done), _p(rng), n, self._stream()))
+        ep, st = episodes if episodes is not None else (None, None)
+        _chk(self.lib.plentd3_store(_p(data), _p(total), int(data.shape[0]), _p(state), _p(action), _p(next_obs), _p(reward), _p(done), _p(rng), _p(ep), _p(st), n, self._stream()))
 
     def critic_backward(self, data, idx, noise=None, total=None, guard=0):
         """Sample, targets, critic forward / loss / backward: gradients land in the critic's flat bucket.  Returns the loss (device scalar).

@@ -125,6 +125,8 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--save", default=None, help="checkpoint prefix (reference 4-file layout)")
     ap.add_argument("--graphs", type=int, default=1, help="capture collect/update in hipGraphs (any number of ranks)")
+    ap.add_argument("--schedule", default="sync", choices=["sync", "pipelined"], help="pipelined: actor/learner overlap on three HIP streams per rank "
+                    "(PipelinedVecTD3Trainer: two half batches + the fused update; needs --graphs 1, --updates-per-step 1, an even --envs)")
     ap.add_argument("--resume", default=None, help="checkpoint prefix to continue from (4-file layout + <prefix>_trainer.json; plen_td3.py:57-69)")
     ap.add_argument("--buffer-path", default=None, help="directory of replay_buffer_<n>.data files (td3.py:128-131)")
     ap.add_argument("--save-replay", type=int, default=None, help="write the rank-local replay buffer as replay_buffer_<n>.data at the end")
@@ -138,7 +140,9 @@ def main(argv=None):
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
     torch.manual_seed(a.seed)                                     # identical init on every rank (then broadcast anyway)
-    env = PlenVecEnv(a.envs, device=dev)
+    pipelined = a.schedule == "pipelined" and a.graphs and a.updates_per_step == 1 and a.envs % 2 == 0
+    envs = [PlenVecEnv(a.envs // 2, device=dev) for _ in range(2)] if pipelined else [PlenVecEnv(a.envs, device=dev)]
+    env = envs[0]
     agent = TD3Agent(26, 18, 1.0, device=dev)
     replay = ReplayBuffer(a.replay, device=dev)
     replay.seed(a.seed + rank)
@@ -148,7 +152,9 @@ def main(argv=None):
     if a.resume:
         resumed = resume_training(agent, replay, a.resume, a.load_replay)
     torch.manual_seed(a.seed + 7919 * (rank + 1))                # from here on the global generator (target-policy smoothing noise) differs per rank
-    if a.graphs:
+    if pipelined:
+        tr = PipelinedVecTD3Trainer(envs, agent, replay, a.start_timesteps, 0.1, a.batch, seed=1000 + rank)
+    elif a.graphs:
         tr = GraphedVecTD3Trainer(env, agent, replay, a.start_timesteps, 0.1, a.batch, a.updates_per_step, seed=1000 + rank)
     else:
         tr = VecTD3Trainer(env, agent, replay, a.start_timesteps, 0.1, a.batch, a.updates_per_step, seed=1000 + rank)
@@ -162,6 +168,8 @@ def main(argv=None):
     e0, g0, t0 = tr.env_steps, tr.grad_steps, time.perf_counter()
     for _ in range(a.steps):
         tr.step()
+    if pipelined:
+        tr.sync()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -170,12 +178,14 @@ def main(argv=None):
         print(json.dumps({"metric": "td3_env_steps_per_sec", "value": world * (tr.env_steps - e0) / dt, "unit": "env-steps/s",
                           "grad_steps_per_sec": (tr.grad_steps - g0) / dt, "n_gpus": world, "envs_per_gpu": a.envs, "batch": a.batch,
                           "updates_per_step": a.updates_per_step, "hip_graphs": bool(a.graphs), "allreduce_mode": getattr(tr, "allreduce_mode", None), "steps": a.steps, "ms_per_step": dt / a.steps * 1e3,
-                          "critic_loss": float(agent.last_critic_loss) if agent.last_critic_loss is not None else None}))
+                          "critic_loss": float(agent.last_critic_loss) if agent.last_critic_loss is not None else None,
+                          "schedule": "pipelined" if pipelined else "sync", "episodes": tr.episode_stats() if pipelined else None}))
         if a.save:
             save_training(agent, tr, a.save)
     if a.save_replay is not None:
         replay.save(a.save_replay)
-    env.close()
+    for e in envs:
+        e.close()
     if world > 1:
         dist.destroy_process_group()
 
@@ -424,6 +434,8 @@ class PipelinedVecTD3Trainer(object):
         self.state = [e.reset().to(torch.float32).clone() for e in envs]
         self.base = [torch.tensor(h * self.nh, dtype=torch.long, device=dev) for h in range(2)]       # next ring row of each half
         self.total_u = torch.zeros((), dtype=torch.long, device=dev)                                  # rows complete before the current step
+        self.ep_ret = [torch.zeros(self.nh, 2, device=dev) for _ in range(2)]                         # running return / length of every env
+        self.ep_stats = torch.zeros(3, device=dev)                                                    # finished episodes: sum of returns, count, sum of lengths
         self._critic_loss = torch.zeros((), device=dev)
         self.t = 0
         self.env_steps = self.grad_steps = 0
@@ -441,7 +453,7 @@ class PipelinedVecTD3Trainer(object):
         else:
             action = self.fused.explore(self.state[h], self.agent.max_action * self.expl_noise, actor=self.behaviour[buf], rng=self.rngs[h])
         next_obs, reward, done, info = env.step(action)
-        self.fused.store(self.replay.data, self.base[h], self.state[h], action, next_obs, reward, done, rng=self.rngs[h])
+        self.fused.store(self.replay.data, self.base[h], self.state[h], action, next_obs, reward, done, rng=self.rngs[h], episodes=(self.ep_ret[h], self.ep_stats))
         self.base[h] += self.n
         self.state[h].copy_(info["obs"])
 
@@ -536,6 +548,26 @@ class PipelinedVecTD3Trainer(object):
     def sync(self):
         for s in self.streams + [self.su]:
             s.synchronize()
+
+    def restore_counters(self, c):
+        """Continue a run: ring position from the (loaded) replay buffer (rounded down to whole vector steps), update cadence from the counters."""
+        r = self.replay
+        done = r.size if r.size < r.max_size else r.max_size + r.ptr
+        self.t = done // self.n
+        self.total_u.fill_(self.t * self.n)
+        for h in range(2):
+            self.base[h].fill_(self.t * self.n + h * self.nh)
+        self.env_steps, self.grad_steps = int(c["env_steps"]), int(c["grad_steps"])
+
+    def episode_stats(self, reset=True):
+        """Mean return and length of the episodes that finished since the last call (the reference prints them per episode, plen_env.py:616-636);
+        accumulated on the device by the ring-store kernel.  Host-synchronous."""
+        self.sync()
+        s = self.ep_stats.tolist()
+        if reset:
+            self.ep_stats.zero_()
+        n = max(s[1], 1.0)
+        return {"episodes": int(s[1]), "mean_return": s[0] / n, "mean_length": s[2] / n}
 
 
 if __name__ == "__main__":

@@ -361,6 +361,11 @@ def test_pipelined_trainer_overlaps_without_races():
                 assert (b[ended, 0:26] == b[ended][0, 0:26]).all()
         assert ok / tot >= 0.9
         assert float(d[:, 26:44].abs().max()) <= 1.0 and (d[(d[:, 71] == 0), 70] < -50).all()
+        # device-side episode bookkeeping: every env-step is either in a finished episode or in a running one
+        st = tr.episode_stats(reset=False)
+        running = sum(float(x[:, 1].sum()) for x in tr.ep_ret)
+        assert st["episodes"] > 0 and abs(st["mean_length"] * st["episodes"] + running - T * n) < 0.5
+        assert -400 < st["mean_return"] < 100 and 5 < st["mean_length"] <= 500
         runs.append(d.clone())
         for e in envs:
             e.close()
