@@ -29,5 +29,6 @@ for name, kw, dr in (("reference config", {}, False), ("joint_act", {"joint_act"
                 and bool(((qn - 1).abs() < 1e-3).all()) and bool((st[:, 2].abs() < 1.0).all()) and bool((st[:, 7:13].abs() <= 100.0).all())
             bad += 0 if ok else 1
     torch.cuda.synchronize()
-    print("%-18s %6d steps x %d envs: %s  (%.1f s, episode ends sampled %d)" % (name, k, n, "OK" if bad == 0 else "%d BAD CHECKS" % bad, time.time() - t0, ends), flush=True)
+    print("%-18s %6d steps x %d envs: %s  (%.1f s, episode ends sampled %d, non-finite guard resets %d)" % (
+        name, k, n, "OK" if bad == 0 else "%d BAD CHECKS" % bad, time.time() - t0, ends, env.nonfinite_count()), flush=True)
     env.close()
