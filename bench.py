@@ -118,12 +118,13 @@ def env_leg(a, dtype_name, dev, rank, world, dist, steps, warmup, dr=None):
     """Random-action rollout of a.envs_per_gpu envs on this rank; returns the timing dict (max over ranks).  dr: per-env domain randomisation
     (BASELINE.json configs[4]); None = as --dr says."""
     dr = a.dr if dr is None else dr
+    groups = a.groups if a.groups > 0 else (2 if dtype_name == "f32" else 4)
     import torch
     from plen_ml_walk_amd import sharding
     from plen_ml_walk_amd.vec_env import PlenVecEnvPipelined
     n = a.envs_per_gpu
     dtype = torch.float32 if dtype_name == "f32" else torch.float64
-    env = PlenVecEnvPipelined(n, groups=a.groups, device=dev, dtype=dtype)
+    env = PlenVecEnvPipelined(n, groups=groups, device=dev, dtype=dtype)
     if dr:
         gd = torch.Generator(device=dev).manual_seed(1000 + rank)
         env.set_params(mass_scale=0.8 + 0.4 * torch.rand(n, generator=gd, device=dev), lateral_friction=0.4 + 0.6 * torch.rand(n, generator=gd, device=dev))
@@ -157,7 +158,7 @@ def env_leg(a, dtype_name, dev, rank, world, dist, steps, warmup, dr=None):
     # the same workload as ONE launch of all envs per step: the mode in which the dominant kernel's own duration is well defined
     # (with overlapping sub-batch launches only a period is)
     single = kernel_ms1 = launches1 = None
-    if a.groups > 1:
+    if groups > 1:
         env1 = PlenVecEnvPipelined(n, groups=1, device=dev, dtype=dtype)
         if dr:
             gd = torch.Generator(device=dev).manual_seed(1000 + rank)
@@ -186,8 +187,8 @@ def env_leg(a, dtype_name, dev, rank, world, dist, steps, warmup, dr=None):
         launch1_ms = sharding.max_over_ranks(kernel_ms1 / max(launches1, 1), dev)
     else:
         launch1_ms = None
-    n_sub = n // a.groups
-    launch_ms, n_launch = (launch1_ms, n) if a.groups > 1 else (slot_ms, n)
+    n_sub = n // groups
+    launch_ms, n_launch = (launch1_ms, n) if groups > 1 else (slot_ms, n)
     real_size = 4 if dtype_name == "f32" else 8
     ab = algo_bytes_per_env_step(real_size)
     achieved = n_launch * ab / (launch_ms * 1e-3) / 1e9
@@ -206,7 +207,7 @@ def env_leg(a, dtype_name, dev, rank, world, dist, steps, warmup, dr=None):
     return {
         "value": value, "unit": "env-steps/s", "dtype": dtype_name, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
         "sub_batches": "%d x %d envs per GPU on %d HIP streams: every env advances one control step per bench step, sub-batches are not "
-                       "synchronised with each other between steps (PlenVecEnvPipelined); --groups 1 = one launch per step" % (a.groups, n_sub, a.groups),
+                       "synchronised with each other between steps (PlenVecEnvPipelined); --groups 1 = one launch per step" % (groups, n_sub, groups),
         "one_launch_per_step": None if single is None else {"ms_per_step": single * 1e3, "value": world * n / single},
         "kernel_ms_per_launch": launch_ms, "pipelined_ms_per_launch_slot": slot_ms,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -306,7 +307,8 @@ def main():
     ap.add_argument("--legs", default="f64,f32,td3,dr", help="comma list of legs to run besides the headline one (f64, f32, td3, dr)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dr", action="store_true", help="BASELINE.json configs[4]: per-env link-mass scale U[0.8,1.2] and foot friction U[0.4,1.0], seed 1000+rank")
-    ap.add_argument("--groups", type=int, default=2, help="independent sub-batches per GPU, one HIP stream each (1 = a single launch per step)")
+    ap.add_argument("--groups", type=int, default=0, help="independent sub-batches per GPU, one HIP stream each (1 = a single launch per step; "
+                    "0 = the measured best: 2 for f32 (4 waves per SIMD: 2 x 2048 envs fill the chip), 4 for f64 (2 waves per SIMD))")
     ap.add_argument("--td3-batch", type=int, default=4096)
     ap.add_argument("--td3-updates", type=int, default=1)
     ap.add_argument("--td3-steps", type=int, default=200)
