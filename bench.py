@@ -247,15 +247,16 @@ def _td3_run(a, dev, rank, world, dist, steps, warmup, batch):
     replay.seed(rank)
     # actor / learner overlap (two half batches + the update on three streams per rank; with several ranks the gradient all-reduces sit between
     # the update's graph segments), or --td3-schedule sync: the synchronous graph trainer
-    pipelined = a.td3_updates == 1 and a.td3_schedule == "pipelined" and n % 2 == 0
+    H = a.td3_parts
+    pipelined = a.td3_updates == 1 and a.td3_schedule == "pipelined" and n % H == 0
     if pipelined:
-        envs = [PlenVecEnv(n // 2, device=dev) for _ in range(2)]
+        envs = [PlenVecEnv(n // H, device=dev) for _ in range(H)]
         env = envs[0]
         if a.dr:
             gd = torch.Generator(device=dev).manual_seed(1000 + rank)
             ms, mu = 0.8 + 0.4 * torch.rand(n, generator=gd, device=dev), 0.4 + 0.6 * torch.rand(n, generator=gd, device=dev)
             for h, e in enumerate(envs):
-                e.set_params(mass_scale=ms[h * n // 2:(h + 1) * n // 2], lateral_friction=mu[h * n // 2:(h + 1) * n // 2])
+                e.set_params(mass_scale=ms[h * n // H:(h + 1) * n // H], lateral_friction=mu[h * n // H:(h + 1) * n // H])
         tr = PipelinedVecTD3Trainer(envs, agent, replay, start_timesteps=10000, expl_noise=0.1, batch_size=batch, seed=1000 + rank)
     else:
         envs = [PlenVecEnv(n, device=dev)]
@@ -285,7 +286,7 @@ def _td3_run(a, dev, rank, world, dist, steps, warmup, batch):
            "update_to_data": "%d gradient step(s) of batch %d per vector step of %d env-steps per rank (samples drawn per env-step: %.3f; the reference "
                              "does 1 step of batch 100 per single env-step, plen_td3.py:119-120)" % (a.td3_updates, batch, n, a.td3_updates * batch / n),
            "hip_graphs": True,
-           "schedule": ("actor/learner overlap: 2 half batches of %d envs and the update on three HIP streams, acting policy two updates old (train_vec.PipelinedVecTD3Trainer)" % (n // 2))
+           "schedule": ("actor/learner overlap: %d sub-batches of %d envs and the update on %d HIP streams, acting policy two updates old (train_vec.PipelinedVecTD3Trainer)" % (H, n // H, H + 1))
                        if pipelined else "synchronous: collect all envs, then update (train_vec.GraphedVecTD3Trainer)",
            "collective": ("RCCL all-reduce of the flat critic (155138 f32) and actor (77330 f32) gradient buckets per update, mode %s" % getattr(tr, "allreduce_mode", None)) if world > 1 else None,
            "critic_loss": float(agent.last_critic_loss) if agent.last_critic_loss is not None else None,
@@ -312,6 +313,7 @@ def main():
     ap.add_argument("--td3-batch", type=int, default=4096)
     ap.add_argument("--td3-updates", type=int, default=1)
     ap.add_argument("--td3-steps", type=int, default=200)
+    ap.add_argument("--td3-parts", type=int, default=2, help="sub-batches of the pipelined TD3 loop (collector streams)")
     ap.add_argument("--td3-schedule", default="pipelined", choices=["pipelined", "sync"], help="actor/learner overlap on three streams per rank, or the synchronous graph loop")
     a = ap.parse_args()
 

@@ -411,30 +411,31 @@ class PipelinedVecTD3Trainer(object):
         import torch.distributed as dist
         from . import td3 as T
         from .td3_fused import FusedTD3
-        assert len(envs) == 2 and envs[0].num_envs == envs[1].num_envs and agent.device.type == "cuda"
+        assert len(envs) >= 2 and all(e.num_envs == envs[0].num_envs for e in envs) and agent.device.type == "cuda"
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         self.allreduce_mode = None if self.world == 1 else "eager-between-graphs"
         self.envs, self.agent, self.replay = envs, agent, replay
         self.nh = envs[0].num_envs
-        self.n = 2 * self.nh
+        self.H = len(envs)                     # sub-batches ("halves" in the comments: 2 is the measured best, bench.py / DESIGN.md section 10)
+        self.n = self.H * self.nh
         self.start_timesteps, self.expl_noise, self.batch_size = start_timesteps, expl_noise, batch_size
         dev = agent.device
         assert replay.max_size >= 4 * self.n, "the ring must hold more than the rows in flight"
         self.fused = FusedTD3(agent, seed=seed)
-        self.rngs = [FusedTD3.new_rng(dev, seed + 7919 * (h + 1)) for h in range(2)]              # one random stream per collector
+        self.rngs = [FusedTD3.new_rng(dev, seed + 7919 * (h + 1)) for h in range(self.H)]         # one random stream per collector
         torch.manual_seed(seed)
         agent.actor_optimizer = GraphedVecTD3Trainer._capturable_adam(agent.actor_optimizer, agent.actor)
         agent.critic_optimizer = GraphedVecTD3Trainer._capturable_adam(agent.critic_optimizer, agent.critic)
         # behaviour actors: 3 copies of the actor whose parameters are views of their own flat buffers
         self.behaviour = [copy.deepcopy(agent.actor) for _ in range(3)]
         self.bflat = [T._FlatParams(b) for b in self.behaviour]
-        self.streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.H)]
         # the update is ~50 short kernels that must slip in beside two long env launches: give its stream dispatch priority
         self.su = torch.cuda.Stream(device=dev, priority=int(os.environ.get("PLEN_TD3_UPDATE_PRIORITY", "-1")))
         self.state = [e.reset().to(torch.float32).clone() for e in envs]
-        self.base = [torch.tensor(h * self.nh, dtype=torch.long, device=dev) for h in range(2)]       # next ring row of each half
+        self.base = [torch.tensor(h * self.nh, dtype=torch.long, device=dev) for h in range(self.H)]  # next ring row of each sub-batch
         self.total_u = torch.zeros((), dtype=torch.long, device=dev)                                  # rows complete before the current step
-        self.ep_ret = [torch.zeros(self.nh, 2, device=dev) for _ in range(2)]                         # running return / length of every env
+        self.ep_ret = [torch.zeros(self.nh, 2, device=dev) for _ in range(self.H)]                    # running return / length of every env
         self.ep_stats = torch.zeros(3, device=dev)                                                    # finished episodes: sum of returns, count, sum of lengths
         self._critic_loss = torch.zeros((), device=dev)
         self.t = 0
@@ -502,7 +503,7 @@ class PipelinedVecTD3Trainer(object):
         t, n = self.t, self.n
         warm = t * n < self.start_timesteps                    # uniform random actions until the ring holds start_timesteps transitions
         learn = not warm and t >= 1
-        for h in range(2):
+        for h in range(self.H):
             s = self.streams[h]
             ev = self._ev_upd.get(t - 2)
             if ev is not None:
@@ -510,7 +511,7 @@ class PipelinedVecTD3Trainer(object):
             self._run(("collect", h, warm, (t - 1) % 3), s, self._collect, h, warm, (t - 1) % 3)
             e = torch.cuda.Event(); e.record(s); self._ev_col[(h, t)] = e
         su = self.su
-        for h in range(2):
+        for h in range(self.H):
             ev = self._ev_col.get((h, t - 1))
             if ev is not None:
                 su.wait_event(ev)
@@ -555,7 +556,7 @@ class PipelinedVecTD3Trainer(object):
         done = r.size if r.size < r.max_size else r.max_size + r.ptr
         self.t = done // self.n
         self.total_u.fill_(self.t * self.n)
-        for h in range(2):
+        for h in range(self.H):
             self.base[h].fill_(self.t * self.n + h * self.nh)
         self.env_steps, self.grad_steps = int(c["env_steps"]), int(c["grad_steps"])
 
