@@ -126,13 +126,35 @@ __device__ inline float sin_(float x) { return sinf(x); }
 #else
 __device__ inline float sin_(float x) { return __sinf(x); }
 #endif
-__device__ inline double sin_(double x) { return sin(x); }
+// f64 sine / cosine for the BOUNDED arguments of this kernel (joint angles |q| <= ~1.8 rad, half rotation angles < pi/8): Cody-Waite
+// reduction by multiples of pi/2 (|k| <= 2: the two-part constant is exact enough for < 1 ulp) and fdlibm's __kernel_sin / __kernel_cos
+// minimax polynomials.  The library routines are ~3x the instructions (Payne-Hanek path for huge arguments) and, worse, the compiler hoists
+// their ~20 polynomial coefficients out of the substep loop into VGPRs that then stay reserved for the whole kernel (that was the f64
+// kernel's scratch: 8 spilled VGPRs); here every coefficient is laundered through a scalar register at its use.
+__device__ __forceinline__ double kc_(double c) { asm volatile("" : "+s"(c)); return c; }
+__device__ __forceinline__ void sincos_bounded(double x, double &sn, double &cs) {
+    const double k = __builtin_rint(x * kc_(0.63661977236758138243));              // 2/pi
+    const double r = __builtin_fma(-k, kc_(6.12323399573676603587e-17), __builtin_fma(-k, kc_(1.57079632679489655800), x));     // x - k pi/2 (hi, lo)
+    const double z = r * r;
+    const double ps = kc_(8.33333333332248946124e-03) + z * (kc_(-1.98412698298579493134e-04) + z * (kc_(2.75573137070700676789e-06) +
+                      z * (kc_(-2.50507602534068634195e-08) + z * kc_(1.58969099521155010221e-10))));
+    const double s0 = r + (z * r) * (kc_(-1.66666666666666324348e-01) + z * ps);
+    const double pc = z * (kc_(4.16666666666666019037e-02) + z * (kc_(-1.38888888888741095749e-03) + z * (kc_(2.48015872894767294178e-05) +
+                      z * (kc_(-2.75573143513906633035e-07) + z * (kc_(2.08757232129817482790e-09) + z * kc_(-1.13596475577881948265e-11))))));
+    const double hz = 0.5 * z, w = 1.0 - hz;
+    const double c0 = w + (((1.0 - w) - hz) + z * pc);
+    const int q = (int)k & 3;                                                        // quadrant: sin/cos of r + k pi/2
+    sn = (q == 0) ? s0 : (q == 1) ? c0 : (q == 2) ? -s0 : -c0;
+    cs = (q == 0) ? c0 : (q == 1) ? -s0 : (q == 2) ? -c0 : s0;
+}
+__device__ inline double sin_(double x) { double s_, c_; sincos_bounded(x, s_, c_); return s_; }
 #ifdef PLENVEC_EXACT_MATH
 __device__ inline float cos_(float x) { return cosf(x); }
 #else
 __device__ inline float cos_(float x) { return __cosf(x); }
 #endif
-__device__ inline double cos_(double x) { return cos(x); }
+__device__ inline double cos_(double x) { double s_, c_; sincos_bounded(x, s_, c_); return c_; }
+__device__ __forceinline__ void sincos_bounded(float x, float &sn, float &cs) { sn = sin_(x); cs = cos_(x); }
 __device__ inline float atan2_(float y, float x) { return atan2f(y, x); }
 __device__ inline double atan2_(double y, double x) { return atan2(y, x); }
 __device__ inline float asin_(float x) { return asinf(x); }
@@ -685,7 +707,9 @@ __device__ __forceinline__ void kinematics(Smem<real> &s, const DevParams<real> 
         const real q = s.st[13 + b - 1];
         qd = s.st[31 + b - 1];
         const real a0 = MDL(12), a1 = MDL(13), a2 = MDL(14);
-        const real cq = cos_(q), sn = sin_(q), t = 1 - cq;
+        real cq, sn;
+        sincos_bounded(q, sn, cq);
+        const real t = 1 - cq;
         const real Rq[9] = {cq + a0 * a0 * t, a0 * a1 * t - a2 * sn, a0 * a2 * t + a1 * sn,
                             a1 * a0 * t + a2 * sn, cq + a1 * a1 * t, a1 * a2 * t - a0 * sn,
                             a2 * a0 * t - a1 * sn, a2 * a1 * t + a0 * sn, cq + a2 * a2 * t};
@@ -1585,8 +1609,10 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         if (fa * P.dt > (real)0.5 * HALF_PI) fa = (real)0.5 * HALF_PI * P.inv_dt;
         real kk;
         if (fa < (real)0.001) kk = (real)0.5 * P.dt - (P.dt * P.dt * P.dt) * (real)0.020833333333 * fa * fa;
-        else kk = sin_((real)0.5 * fa * P.dt) * rcp_(fa);
-        const real dq[4] = {w0 * kk, w1 * kk, w2 * kk, cos_(fa * P.dt * (real)0.5)};
+        real s_half, c_half;
+        sincos_bounded((real)0.5 * fa * P.dt, s_half, c_half);
+        if (!(fa < (real)0.001)) kk = s_half * rcp_(fa);
+        const real dq[4] = {w0 * kk, w1 * kk, w2 * kk, c_half};
         const real q0[4] = {s.st[3], s.st[4], s.st[5], s.st[6]};
         real rq[4];
         rq[3] = dq[3] * q0[3] - dq[0] * q0[0] - dq[1] * q0[1] - dq[2] * q0[2];
