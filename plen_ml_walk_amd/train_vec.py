@@ -242,7 +242,8 @@ class GraphedVecTD3Trainer(object):
         self.host_total = 0
         self._graphs = {}
         self._eager_runs = {}
-        self._side = torch.cuda.Stream(device=dev)
+        from .vec_env import worker_stream
+        self._side = worker_stream(dev, "side")
         self._critic_loss = torch.zeros((), device=dev)
         self._batch = None          # the sampled batch of the update in flight (static tensors once captured)
 
@@ -429,9 +430,9 @@ class PipelinedVecTD3Trainer(object):
         # behaviour actors: 3 copies of the actor whose parameters are views of their own flat buffers
         self.behaviour = [copy.deepcopy(agent.actor) for _ in range(3)]
         self.bflat = [T._FlatParams(b) for b in self.behaviour]
-        self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.H)]
-        # the update is ~50 short kernels that must slip in beside two long env launches: give its stream dispatch priority
-        self.su = torch.cuda.Stream(device=dev, priority=int(os.environ.get("PLEN_TD3_UPDATE_PRIORITY", "-1")))
+        from .vec_env import worker_stream
+        self.streams = [worker_stream(dev, h) for h in range(self.H)]
+        self.su = worker_stream(dev, "update")
         self.state = [e.reset().to(torch.float32).clone() for e in envs]
         self.base = [torch.tensor(h * self.nh, dtype=torch.long, device=dev) for h in range(self.H)]  # next ring row of each sub-batch
         self.total_u = torch.zeros((), dtype=torch.long, device=dev)                                  # rows complete before the current step

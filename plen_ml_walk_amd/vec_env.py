@@ -150,6 +150,43 @@ class PlenVecEnv(object):
         return ms.value, n.value
 
 
+_WORKER_STREAMS = {}
+# first-use order of the role streams of a device (PLEN_STREAM_ROLE_ORDER overrides it for experiments; "x" = a throw-away stream)
+_ROLE_ORDER = "2,3,0,1,update,side"
+_ROLE_PRIORITY = {"update": -1}
+
+
+def worker_stream(device, role):
+    """The process-wide HIP stream of one concurrent role: sub-batch k of a pipelined env / collector k of a trainer (role k = 0, 1, ...), the
+    trainer's update ("update", dispatch priority -1: ~50 short kernels that must slip in beside two long env launches) and its side stream.
+
+    Why roles instead of torch.cuda.Stream() per object (measured with scripts/gpu_queue_map.py and gpu_stream_reuse_probe.py):
+    * the HIP runtime gives a stream its hardware queue at FIRST USE, GPU_MAX_HW_QUEUES (16 here, one of them the null stream's) in all, and streams
+      that share a queue serialise; torch hands streams out round-robin from a pool of 32, so a process that builds several pipelined envs /
+      trainers one after the other (bench.py's legs) ends up with two concurrently used streams on one queue (4 x 1024 f64 envs: 1.46 instead
+      of 0.98 ms per step);
+    * queues are spread over the 4 compute pipes in creation order, and a pipe serves its queues one at a time: the high-priority update queue on
+      the pipe of a collector's queue takes the pipelined trainer from 0.74 to 1.9 ms per step, two collectors on one pipe cost 20%.
+    So the role streams of a device are created and first used together, in an order that puts {0, 1, 2, 3} on four different pipes and
+    {0, 1, update} on three (update shares 2's: a 4-sub-batch env and a trainer's update never run together), whatever was created before."""
+    device = torch.device(device)
+    di = device.index if device.index is not None else torch.cuda.current_device()
+    device = torch.device("cuda", di)
+    if (di, "0") not in _WORKER_STREAMS:
+        import os
+        for tok in os.environ.get("PLEN_STREAM_ROLE_ORDER", _ROLE_ORDER).split(","):
+            st = torch.cuda.Stream(device=device, priority=_ROLE_PRIORITY.get(tok, 0))
+            with torch.cuda.stream(st):
+                torch.zeros(1, device=device)              # first use: the hardware queue is assigned now
+            _WORKER_STREAMS[(di, tok)] = st if tok != "x" else None
+        torch.cuda.synchronize(device)
+    key = (di, str(role))
+    st = _WORKER_STREAMS.get(key)
+    if st is None:
+        st = _WORKER_STREAMS[key] = torch.cuda.Stream(device=device, priority=_ROLE_PRIORITY.get(str(role), 0))
+    return st
+
+
 class PlenVecEnvPipelined(object):
     """`num_envs` environments as `groups` independent sub-batches, each with its own libplenvec handle and HIP stream.
 
@@ -177,7 +214,7 @@ class PlenVecEnvPipelined(object):
         self._slices = sl
         self.envs = [PlenVecEnv(self.n_sub, device=dev, dtype=dtype, out_buffers=(self._next_obs[s], self._cur_obs[s], self._reward[s], self._done[s]), **kw)
                      for s in sl]
-        self.streams = [torch.cuda.Stream(device=dev) for _ in range(g)]
+        self.streams = [worker_stream(dev, k) for k in range(g)]
         self._ev_in = torch.cuda.Event()
         self._ev_out = [torch.cuda.Event() for _ in range(g)]
         self.max_episode_steps = self.envs[0].max_episode_steps
