@@ -64,6 +64,9 @@ int plentd3_dtanh(const float *dsa, const float *a, float *dz, float max_a, int 
 int plentd3_bias_relu(float *h, const float *bias, int B, int n, void *stream);
 /* td3.py:348-356: target = tau param + (1 - tau) target over a flat parameter buffer */
 int plentd3_polyak(float *target, const float *param, float tau, int n, void *stream);
+/* development: table[(*counter / div) % ring][idx] = the device's constant-rate clock (wall_clock64, 100 MHz) at this point of the stream (table is
+ * [ring][nslots] uint64; counter NULL = row 0).  A graph node like the rest: successive replays fill successive rows, no profiler in the way */
+int plentd3_stamp(uint64_t *table, const int64_t *counter, int64_t div, int ring, int nslots, int idx, void *stream);
 const char *plentd3_version(void);
 
 #ifdef __cplusplus

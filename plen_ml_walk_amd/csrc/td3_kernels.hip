@@ -9,6 +9,7 @@
 // Layout conventions: activations are row-major [B][n]; a "strided" operand has an explicit row stride (it is a column slice of a wider
 // row-major matrix, e.g. the action columns 26..43 of a [B][44] state-action matrix, or one column of the packed replay rows).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 #include "../../include/plentd3.h"
 
@@ -329,6 +330,15 @@ __global__ void k_store(float *__restrict__ data, const int64_t *__restrict__ to
     data[(size_t)row * TD3_ROW + c] = v;
 }
 
+// ---- K16: timeline probe: slot[0] = the GPU's constant-rate clock (100 MHz) when this one-lane kernel runs.  A node in a captured graph like any
+//      other, so the pipelined trainer's schedule can be read without a profiler serialising it.
+//      Row (*counter / div) % ring of a [ring][nslots] table, column idx: counter is one of the trainer's device-side step counters, so replays of one
+//      graph fill successive rows.
+__global__ void k_stamp(uint64_t *table, const int64_t *counter, int64_t div, int ring, int nslots, int idx) {
+    const int64_t row = counter ? (counter[0] / div) % ring : 0;
+    table[row * nslots + idx] = wall_clock64();
+}
+
 #define GRID(n_) dim3(((n_) + 255) / 256), dim3(256), 0, (hipStream_t)stream
 #define CHECK() do { hipError_t e_ = hipGetLastError(); return e_ == hipSuccess ? 0 : -(int)e_; } while (0)
 
@@ -394,6 +404,9 @@ int plentd3_bias_relu(float *h, const float *bias, int B, int n, void *stream) {
 }
 int plentd3_polyak(float *target, const float *param, float tau, int n, void *stream) {
     hipLaunchKernelGGL(k_polyak, GRID(n), target, param, tau, n); CHECK();
+}
+int plentd3_stamp(uint64_t *table, const int64_t *counter, int64_t div, int ring, int nslots, int idx, void *stream) {
+    hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, (hipStream_t)stream, table, counter, div, ring, nslots, idx); CHECK();
 }
 const char *plentd3_version(void) { return "plentd3 0.1 (gfx950)"; }
 

@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libplentd3.so")
 EXPORTS = ["plentd3_gather", "plentd3_sample_gather", "plentd3_explore", "plentd3_uniform_actions", "plentd3_store", "plentd3_target_action", "plentd3_q_heads", "plentd3_dh2", "plentd3_relu_mask", "plentd3_colsum", "plentd3_wgrad",
-           "plentd3_tanh_out", "plentd3_dtanh", "plentd3_bias_relu", "plentd3_polyak", "plentd3_version"]
+           "plentd3_tanh_out", "plentd3_dtanh", "plentd3_bias_relu", "plentd3_polyak", "plentd3_stamp", "plentd3_version"]
 ROW, S, A, SA, H = 72, 26, 18, 44, 256
 _lib = None
 
@@ -50,6 +50,7 @@ def load():
         lib.plentd3_dtanh.argtypes = [vp, vp, vp, f, i, vp]
         lib.plentd3_bias_relu.argtypes = [vp, vp, i, i, vp]
         lib.plentd3_polyak.argtypes = [vp, vp, f, i, vp]
+        lib.plentd3_stamp.argtypes = [vp, vp, C.c_int64, i, i, i, vp]
         _lib = lib
     return _lib
 
@@ -75,6 +76,7 @@ class FusedTD3(object):
         self.lib = load()
         self.dev = agent.device
         # does the GEMM library fuse bias + ReLU into the epilogue here?  (hipBLASLt: yes; verified numerically once)
+        self.probe = None
         self.epilogue = False
         try:
             x = torch.randn(8, 12, device=self.dev); w = torch.randn(5, 12, device=self.dev); b = torch.randn(5, device=self.dev)
@@ -97,6 +99,15 @@ class FusedTD3(object):
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def _probe(self, k):
+        """Timeline hook (train_vec.PipelinedVecTD3Trainer.enable_timeline): stamp point k of the update; nothing unless a probe is installed."""
+        if self.probe is not None:
+            self.probe(k)
+
+    def stamp(self, table, counter, div, idx):
+        """Timeline probe: table[(counter // div) % rows][idx] = device clock (100 MHz ticks) here on the current stream."""
+        _chk(self.lib.plentd3_stamp(_p(table), _p(counter), int(div), int(table.shape[0]), int(table.shape[1]), int(idx), self._stream()))
 
     def _lin_relu(self, x, w, b, out=None):
         if self.epilogue:
@@ -170,6 +181,7 @@ class FusedTD3(object):
             _chk(lib.plentd3_gather(_p(data), _p(idx), _p(batch), _p(sa_pi), _p(loss), B, st))
         s, sa, s2 = batch[:, :S], batch[:, :SA], batch[:, SA:SA + S]
         relu_both = not self.epilogue
+        self._probe(1)
         with torch.no_grad():
             # ---- target policy smoothing + clipped double-Q target (td3.py:277-309) ----
             at, ct = ag.actor_target, ag.critic_target
@@ -189,6 +201,7 @@ class FusedTD3(object):
             y = new(B)
             _chk(lib.plentd3_q_heads(_p(h2), _p(ct.fc3.weight), _p(ct.fc3.bias), _p(ct.fc6.weight), _p(ct.fc6.bias), _p(batch), _p(y), None, None, None, None, None,
                                      float(ag.discount), B, 0, st))
+            self._probe(2)
             # ---- critic forward, loss, backward (td3.py:312-331) ----
             cr = ag.critic
             cv, gv = ag._critic_flat.views, ag._critic_grads.views
@@ -202,6 +215,7 @@ class FusedTD3(object):
             dq = new(B, 2)
             _chk(lib.plentd3_q_heads(_p(c2), _p(cr.fc3.weight), _p(cr.fc3.bias), _p(cr.fc6.weight), _p(cr.fc6.bias), _p(batch), _p(y), _p(dq), _p(loss),
                                      _p(cr.fc3.bias.grad), _p(cr.fc6.bias.grad), _p(self.rng), float(ag.discount), B, 1, st))
+            self._probe(3)
             # last layer weight gradients: dW3_c = h2_c^T dq_c
             _chk(lib.plentd3_colsum(_p(c2), 2 * H, _p(dq), 2, _p(cr.fc3.weight.grad), B, H, st))
             _chk(lib.plentd3_colsum(C.c_void_p(c2.data_ptr() + 4 * H), 2 * H, C.c_void_p(dq.data_ptr() + 4), 2, _p(cr.fc6.weight.grad), B, H, st))
@@ -215,6 +229,7 @@ class FusedTD3(object):
             _chk(lib.plentd3_relu_mask(_p(dh1), _p(c1), B, 2 * H, 2 * H, st))
             self._wgrad(dh1, sa, gv["W14"], gv["b14"])
         self._saved = (s, sa_pi, B)
+        self._probe(4)
         return loss[0]
 
     def policy_backward(self):

@@ -444,24 +444,44 @@ class PipelinedVecTD3Trainer(object):
         self._graphs, self._eager_runs = {}, {}
         self._ev_col = {}
         self._ev_upd = {}
+        self.timeline = None
         torch.cuda.synchronize(dev)
+
+    def enable_timeline(self, rows=64):
+        """Development: device-clock stamps (td3_fused.stamp, 100 MHz ticks) at the ends of every collect and update, row = vector step % rows,
+        columns = [collector h: start, env launch, env done, end] * H + [update: start, sampled, targets, critic forward, critic backward, end].
+        Call before the graphs are captured."""
+        assert not self._graphs, "enable_timeline() before the first captured step"
+        self.timeline = torch.zeros(rows, 4 * self.H + 6, dtype=torch.long, device=self.agent.device)
+        self.fused.probe = lambda k: self._stamp(self.total_u, 4 * self.H + k)
+        return self.timeline
+
+    def _stamp(self, counter, idx):
+        if self.timeline is not None:
+            self.fused.stamp(self.timeline, counter, self.n, idx)
 
     # one half-batch vector step: act, step the envs, store (all on the current stream)
     def _collect(self, h, random_actions, buf):
         env, nh = self.envs[h], self.nh
         dev = self.agent.device
+        self._stamp(self.base[h], 4 * h)
         if random_actions:
             action = self.fused.uniform_actions(nh, self.rngs[h])
         else:
             action = self.fused.explore(self.state[h], self.agent.max_action * self.expl_noise, actor=self.behaviour[buf], rng=self.rngs[h])
+        self._stamp(self.base[h], 4 * h + 1)
         next_obs, reward, done, info = env.step(action)
+        self._stamp(self.base[h], 4 * h + 2)
         self.fused.store(self.replay.data, self.base[h], self.state[h], action, next_obs, reward, done, rng=self.rngs[h], episodes=(self.ep_ret[h], self.ep_stats))
+        self._stamp(self.base[h], 4 * h + 3)
         self.base[h] += self.n
         self.state[h].copy_(info["obs"])
 
     def _update(self, with_policy, buf_out):
+        self._stamp(self.total_u, 4 * self.H)
         loss = self.fused.update(self.replay.data, self.batch_size, with_policy, all_reduce=False, total=self.total_u, guard=2 * self.n)
         self._critic_loss.copy_(loss)
+        self._stamp(self.total_u, 4 * self.H + 5)
         self._finish(buf_out)
 
     def _finish(self, buf_out):
