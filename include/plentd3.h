@@ -52,10 +52,12 @@ int plentd3_dh2(const float *dq, const float *w3a, const float *w3b, const float
 /* ReLU backward in place: g *= (h > 0) */
 int plentd3_relu_mask(float *g, const float *h, int B, int n, int h_stride, void *stream);
 /* out[j] += sum_b w[b] g[b][j] (w NULL: bias gradient; w = dq column, g = h2_c: the last layer's weight gradient); out zeroed by the caller */
-int plentd3_colsum(const float *g, int g_stride, const float *w, int w_stride, float *out, int B, int n, void *stream);
+int plentd3_colsum(const float *g, int g_stride, const float *w, int w_stride, float *out, int B, int n, int single_wave, void *stream);
 /* nn.Linear backward (td3.py:323, :341): dW[n][k] += sum_b dH[b][n] X[b][k] and (db non-NULL) db[n] += sum_b dH[b][n]; split over the batch on
- * the matrix cores (v_mfma_f32_32x32x2_f32), partial tiles added with float atomics: dW / db must be zeroed by the caller.  Strides in floats. */
-int plentd3_wgrad(const float *dH, int dh_stride, const float *X, int x_stride, float *dW, int dw_stride, float *db, int B, int N, int K, void *stream);
+ * the matrix cores (v_mfma_f32_32x32x2_f32), partial tiles added with float atomics: dW / db must be zeroed by the caller.  Strides in floats.
+ * single_wave (here and in plentd3_colsum): 64-thread workgroups without LDS instead of 256-thread ones -- each can start in any single free wave
+ * slot, which matters when the update runs beside env launches that hold every slot of the chip (same sums, other summation order). */
+int plentd3_wgrad(const float *dH, int dh_stride, const float *X, int x_stride, float *dW, int dw_stride, float *db, int B, int N, int K, int single_wave, void *stream);
 /* td3.py:57: a = max_a tanh(pre), also written into sa_pi[:, 26:44] */
 int plentd3_tanh_out(const float *pre, float *a, float *sa_pi, float max_a, int B, void *stream);
 /* its backward: dz = dsa[:, 26:44] (max_a - a^2 / max_a) */
@@ -64,6 +66,57 @@ int plentd3_dtanh(const float *dsa, const float *a, float *dz, float max_a, int 
 int plentd3_bias_relu(float *h, const float *bias, int B, int n, void *stream);
 /* td3.py:348-356: target = tau param + (1 - tau) target over a flat parameter buffer */
 int plentd3_polyak(float *target, const float *param, float tau, int n, void *stream);
+/* td3.py:236-247 / :326-331 / :343-345 optimizer.step() of torch.optim.Adam (no weight decay, no amsgrad) over a network's flat parameter, gradient and
+ * moment buffers of n floats: step[0] += 1 (float32 device scalar, torch's capturable `step`); m, v, p updated with torch's bias corrections.
+ * Optional extras of the same pass: zero_grad (g = 0 for the next backward), target != NULL (td3.py:348-356: target = tau p + (1 - tau) target),
+ * copy_out != NULL (a copy of the new parameters).  done_count: device int, zero before the first call. */
+int plentd3_adam(float *p, float *g, float *m, float *v, float *step, int *done_count, int n, double lr, double beta1, double beta2, float eps, int zero_grad,
+                 float *target, float tau, float *copy_out, void *stream);
+
+/* td3.py:277-331 without the weight gradients, as ONE launch of single-wave workgroups (16 batch rows each, dense layers on the matrix cores,
+ * csrc/td3_rows.hip): sample + gather (as plentd3_sample_gather, u = NULL), target action (as plentd3_target_action, noise = NULL), twin target
+ * critics -> y, twin critics -> q, loss, dq, and back to dh2 = dq w3 (h2 > 0), dh1 = (dh2 W2)(h1 > 0).  Row-major outputs left for the weight-gradient kernels
+ * (plentd3_colsum, plentd3_wgrad): batch [B][72], sa_pi [B][44] (state columns), c1 / c2 / dh2 / dh1 [B][512] (critic a | critic b), dq [B][2];
+ * loss[0] += critic loss, db3a / db3b += last-layer bias gradients (zeroed by the caller); t0, t1 [B][512] and sa2 [B][44] are scratch;
+ * done_count = device int, zero before the first call (the last workgroup to finish bumps rng_bump[1] and resets it).
+ * Weights are nn.Linear layouts [out][in]; *_w14 = [fc1.weight; fc4.weight] (512 x 44), *_b14 likewise; every matrix 16-byte aligned. */
+typedef struct PlenTd3CriticRows {
+    const float *data; const uint64_t *rng; const int64_t *total; int64_t capacity, guard;
+    const float *at_w1, *at_b1, *at_w2, *at_b2, *at_w3, *at_b3;
+    const float *ct_w14, *ct_b14, *ct_w2, *ct_b2, *ct_w5, *ct_b5, *ct_w3, *ct_b3, *ct_w6, *ct_b6;
+    const float *c_w14, *c_b14, *c_w2, *c_b2, *c_w5, *c_b5, *c_w3, *c_b3, *c_w6, *c_b6;
+    float *batch, *sa_pi, *t0, *t1, *sa2, *c1, *c2, *dh2, *dh1, *dq;
+    float *loss, *db3a, *db3b;
+    int *done_count; uint64_t *rng_bump;
+    float sigma, clip, max_a, gamma;
+    int B;
+} PlenTd3CriticRows;
+int plentd3_critic_rows(const PlenTd3CriticRows *args, void *stream);
+
+/* td3.py:334-341 without the weight gradients, as plentd3_critic_rows: actor(s) -> a = max_a tanh(.) -> critic.Q1(s, a) -> the gradient of
+ * -mean Q1 back to the actor's first hidden layer.  In: sa_pi [B][44] with the state columns filled (plentd3_critic_rows / plentd3_gather); its
+ * action columns are written here.  Out for plentd3_wgrad: p1, p2 [B][256] (actor activations), dz [B][18], dp2, dp1 [B][256]; a_pi [B][18],
+ * g1, dg2, dg1 [B][256] are scratch.  c_w1 / c_b1 = critic fc1 (the first 256 rows of W14), c_w2 / c_b2 = fc2, c_w3 = fc3.weight. */
+typedef struct PlenTd3PolicyRows {
+    const float *a_w1, *a_b1, *a_w2, *a_b2, *a_w3, *a_b3;
+    const float *c_w1, *c_b1, *c_w2, *c_b2, *c_w3;
+    float *sa_pi, *a_pi, *p1, *p2, *g1, *dg2, *dg1, *dz, *dp2, *dp1;
+    float max_a;
+    int B;
+} PlenTd3PolicyRows;
+int plentd3_policy_rows(const PlenTd3PolicyRows *args, void *stream);
+
+/* plen_td3.py:101-104 for a whole vector step as one launch: action [B][18] = clamp(actor(state [B][26]) + N(0, sigma), +-max_a), the noise drawn as
+ * plentd3_explore draws it (rng, bumped by the plentd3_store that follows); p1, p2 [B][256] are scratch. */
+typedef struct PlenTd3ActorRows {
+    const float *a_w1, *a_b1, *a_w2, *a_b2, *a_w3, *a_b3;
+    const float *state; const uint64_t *rng;
+    float *p1, *p2, *action;
+    float sigma, max_a;
+    int B;
+} PlenTd3ActorRows;
+int plentd3_actor_rows(const PlenTd3ActorRows *args, void *stream);
+
 /* development: table[(*counter / div) % ring][idx] = the device's constant-rate clock (wall_clock64, 100 MHz) at this point of the stream (table is
  * [ring][nslots] uint64; counter NULL = row 0).  A graph node like the rest: successive replays fill successive rows, no profiler in the way */
 int plentd3_stamp(uint64_t *table, const int64_t *counter, int64_t div, int ring, int nslots, int idx, void *stream);

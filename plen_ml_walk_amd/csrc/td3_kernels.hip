@@ -161,17 +161,25 @@ __global__ void k_relu_mask(float *__restrict__ g, const float *__restrict__ h, 
 // ---- K7: column sums over the batch (bias gradients):  out[j] += sum_b w[b] * g[b][j]   (w == nullptr: plain sum).  With w = dq column c and
 //      g = h2_c this is also the last layer's weight gradient dW3_c = h2_c^T dq_c (td3.py:323 critic_loss.backward()).
 //      Workgroup = 64 columns x 4 row-groups; grid.y splits the batch; one atomic per column and workgroup.  out must be zeroed beforehand.
-__global__ void k_colsum(const float *__restrict__ g, int gs, const float *__restrict__ w, int ws, float *__restrict__ out, int B, int n) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_colsum(const float *__restrict__ g, int gs, const float *__restrict__ w, int ws, float *__restrict__ out, int B, int n) {
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
     const int rows_per = (B + gridDim.y - 1) / gridDim.y;
     const int r0 = blockIdx.y * rows_per, r1 = min(B, r0 + rows_per);
     float s = 0.f;
     if (col < n)
-        for (int b = r0 + rg; b < r1; b += 4) s += (w ? w[(size_t)b * ws] : 1.f) * g[(size_t)b * gs + col];
-    __shared__ float red[4][64];
-    red[rg][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (rg == 0 && col < n) atomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+        for (int b = r0 + rg; b < r1; b += NW) s += (w ? w[(size_t)b * ws] : 1.f) * g[(size_t)b * gs + col];
+    if constexpr (NW > 1) {
+        __shared__ float red[NW][64];
+        red[rg][threadIdx.x & 63] = s;
+        __syncthreads();
+        if (rg == 0 && col < n) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < NW; k++) t += red[k][threadIdx.x];
+            atomicAdd(out + col, t);
+        }
+    } else if (col < n) atomicAdd(out + col, s);            // single-wave workgroup: no LDS, starts in any one free wave slot
 }
 
 // ---- K8: the actor's output nonlinearity (td3.py:57): a = max_a * tanh(pre), stored densely and into the action columns of sa_pi
@@ -214,12 +222,14 @@ __global__ void k_polyak(float *__restrict__ t, const float *__restrict__ p, flo
 //      two coalesced 128-byte row segments per operand and step, no transpose, no LDS -- and the partial tiles are added into dW (zeroed by
 //      the caller) with float atomics.  Waves of the first column tile also sum their dH operand: the bias gradient comes for free.
 typedef float floatx16 __attribute__((ext_vector_type(16)));
-__global__ __launch_bounds__(256) void k_wgrad(const float *__restrict__ dH, int ds, const float *__restrict__ X, int xs, float *__restrict__ dW, int dws,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_wgrad(const float *__restrict__ dH, int ds, const float *__restrict__ X, int xs, float *__restrict__ dW, int dws,
                                                float *__restrict__ db, int B, int N, int K, int rows_per_chunk) {
-    // workgroup = one (32 x 32 output tile, batch chunk); its 4 waves take every 4th pair of batch rows and are summed through LDS, so that a
-    // tile costs one set of 1024 atomics per chunk instead of four
-    __shared__ float red[3][64][17];
-    __shared__ float bred[3][32];
+    // workgroup = one (32 x 32 output tile, batch chunk).  NW = 4: its waves take every 4th pair of batch rows and are summed through LDS, so that a
+    // tile costs one set of 1024 atomics per chunk instead of four.  NW = 1: one wave, no LDS -- a workgroup that starts in any single free wave
+    // slot (the update beside resident env launches, td3_rows.hip), at the price of shorter chunks' worth of atomics.
+    __shared__ float red[NW > 1 ? NW - 1 : 1][NW > 1 ? 64 : 1][NW > 1 ? 17 : 1];
+    __shared__ float bred[NW > 1 ? NW - 1 : 1][NW > 1 ? 32 : 1];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nt = (N + 31) / 32, kt = (K + 31) / 32;
     const int tile = blockIdx.x % (nt * kt), chunk = blockIdx.x / (nt * kt);
@@ -229,42 +239,52 @@ __global__ __launch_bounds__(256) void k_wgrad(const float *__restrict__ dH, int
     const bool na = n0 + col < N, ka = k0 + col < K;
     floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     float bsum = 0.f;
-    // wave w: row pairs b0 + 2 (4 u + w), in groups of 8 pairs (16 loads in flight before the first MFMA needs its operands)
+    // wave w: row pairs b0 + 2 (NW u + w), in groups of 8 pairs (16 loads in flight before the first MFMA needs its operands)
     int b = b0 + 2 * w;
 #pragma unroll 1
-    for (; b + 2 * 4 * 7 + 1 < b1; b += 2 * 4 * 8) {
+    for (; b + 2 * NW * 7 + 1 < b1; b += 2 * NW * 8) {
         float av[8], bv[8];
         const float *pa = dH + (size_t)(b + half) * ds + n0 + col, *pb = X + (size_t)(b + half) * xs + k0 + col;
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            av[u] = na ? pa[(size_t)(8 * u) * ds] : 0.f;
-            bv[u] = ka ? pb[(size_t)(8 * u) * xs] : 0.f;
+            av[u] = na ? pa[(size_t)(2 * NW * u) * ds] : 0.f;
+            bv[u] = ka ? pb[(size_t)(2 * NW * u) * xs] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) { acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0); bsum += av[u]; }
     }
-    for (; b < b1; b += 8) {                          // ragged tail (also an odd last row)
+    for (; b < b1; b += 2 * NW) {                     // ragged tail (also an odd last row)
         const bool ra = b + half < b1;
         const float a = (na && ra) ? dH[(size_t)(b + half) * ds + n0 + col] : 0.f, x = (ka && ra) ? X[(size_t)(b + half) * xs + k0 + col] : 0.f;
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x, acc, 0, 0, 0); bsum += a;
     }
     bsum += __shfl_xor(bsum, 32);
-    if (w > 0) {
+    if constexpr (NW > 1) {
+        if (w > 0) {
 #pragma unroll
-        for (int v = 0; v < 16; v++) red[w - 1][lane][v] = acc[v];
-        if (half == 0) bred[w - 1][col] = bsum;
+            for (int v = 0; v < 16; v++) red[w - 1][lane][v] = acc[v];
+            if (half == 0) bred[w - 1][col] = bsum;
+        }
+        __syncthreads();
+        if (w == 0) {
+#pragma unroll
+            for (int k = 0; k < NW - 1; k++) {
+#pragma unroll
+                for (int v = 0; v < 16; v++) acc[v] += red[k][lane][v];
+                bsum += bred[k][col];
+            }
+        }
     }
-    __syncthreads();
     if (w == 0) {
         // result layout of the 32x32 MFMA: lane l holds column j = l % 32 and rows i = 8 * (v / 4) + 4 * (l / 32) + v % 4, v = 0..15
         if (ka) {
 #pragma unroll
             for (int v = 0; v < 16; v++) {
                 const int i = 8 * (v / 4) + 4 * half + (v % 4);
-                if (n0 + i < N) atomicAdd(dW + (size_t)(n0 + i) * dws + k0 + col, acc[v] + red[0][lane][v] + red[1][lane][v] + red[2][lane][v]);
+                if (n0 + i < N) atomicAdd(dW + (size_t)(n0 + i) * dws + k0 + col, acc[v]);
             }
         }
-        if (db && k0 == 0 && half == 0 && na) atomicAdd(db + n0 + col, bsum + bred[0][col] + bred[1][col] + bred[2][col]);
+        if (db && k0 == 0 && half == 0 && na) atomicAdd(db + n0 + col, bsum);
     }
 }
 
@@ -330,6 +350,43 @@ __global__ void k_store(float *__restrict__ data, const int64_t *__restrict__ to
     data[(size_t)row * TD3_ROW + c] = v;
 }
 
+// ---- K17: one Adam step over a network's flat parameter / gradient buffers (torch.optim.Adam as td3.py:236-247 configures it: no weight decay, no
+//      amsgrad), optionally with what follows it in the iteration: the gradient bucket zeroed for the next backward pass, the Polyak update of
+//      the target network (td3.py:348-356) and a copy of the new parameters (the pipelined trainer's behaviour actor).  torch's fused Adam is two
+//      multi-tensor launches of 41 + 5 us for these 12 tensors; this is one pass of single-wave workgroups.
+//      step = float32 device scalar (torch's capturable `step`): read by every workgroup, advanced by the last one to finish.
+__global__ __launch_bounds__(64) void k_adam(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, float *step, int *done_count, int n,
+                                             double lr, double b1d, double b2d, float eps, int zero_grad, float *__restrict__ target, float tau, float *__restrict__ copy_out) {
+    // the hyper-parameters arrive as the doubles torch holds them in and are rounded where torch's kernel rounds them: 1 - beta2 = 0.001 computed
+    // in float would be off by 5e-5 relative, and so would the second moment
+    const float t = step[0] + 1.f;
+    const double bc1 = 1.0 - pow(b1d, (double)t), bc2 = 1.0 - pow(b2d, (double)t);
+    const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    const float b2 = (float)b2d, w1 = (float)(1.0 - b1d), w2 = (float)(1.0 - b2d);
+    const int i0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int i = i0 + j;
+        if (i < n) {
+            const float gi = g[i];
+            const float mi = m[i] + (gi - m[i]) * w1;
+            const float vi = v[i] * b2 + w2 * gi * gi;
+            const float denom = sqrtf(vi) / bc2_sqrt + eps;
+            const float pi = p[i] - step_size * mi / denom;
+            m[i] = mi; v[i] = vi; p[i] = pi;
+            if (zero_grad) g[i] = 0.f;
+            if (target) target[i] = tau * pi + (1.f - tau) * target[i];
+            if (copy_out) copy_out[i] = pi;
+        }
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(done_count, 1) == (int)gridDim.x - 1) { done_count[0] = 0; step[0] = t; }
+    }
+}
+
+#include "td3_rows.hip"
+
 // ---- K16: timeline probe: slot[0] = the GPU's constant-rate clock (100 MHz) when this one-lane kernel runs.  A node in a captured graph like any
 //      other, so the pipelined trainer's schedule can be read without a profiler serialising it.
 //      Row (*counter / div) % ring of a [ring][nslots] table, column idx: counter is one of the trainer's device-side step counters, so replays of one
@@ -360,16 +417,19 @@ int plentd3_store(float *data, const int64_t *total, int64_t capacity, const flo
                   float *ep_ret, float *stats, int n, void *stream) {
     hipLaunchKernelGGL(k_store, GRID(n * TD3_ROW), data, total, capacity, s, a, s2, r, done, rng_bump, ep_ret, stats, n); CHECK();
 }
-int plentd3_wgrad(const float *dH, int dh_stride, const float *X, int x_stride, float *dW, int dw_stride, float *db, int B, int N, int K, void *stream) {
+int plentd3_wgrad(const float *dH, int dh_stride, const float *X, int x_stride, float *dW, int dw_stride, float *db, int B, int N, int K, int single_wave, void *stream) {
     const int tiles = ((N + 31) / 32) * ((K + 31) / 32);
-    // batch chunks so that about 256-512 workgroups (4 waves each) run, at least 256 rows per workgroup
-    int chunks = (384 + tiles - 1) / tiles;
-    if (chunks > (B + 255) / 256) chunks = (B + 255) / 256;
+    // batch chunks so that about 256-512 workgroups of 4 waves run, at least 256 rows per workgroup (single-wave workgroups: 1024, at least 128 rows)
+    const int want = single_wave ? 1024 : 384, min_rows = single_wave ? 128 : 256;
+    int chunks = (want + tiles - 1) / tiles;
+    if (chunks > (B + min_rows - 1) / min_rows) chunks = (B + min_rows - 1) / min_rows;
     if (chunks < 1) chunks = 1;
     int rows = (B + chunks - 1) / chunks;
     rows = (rows + 63) / 64 * 64;
     chunks = (B + rows - 1) / rows;
-    hipLaunchKernelGGL(k_wgrad, dim3(tiles * chunks), dim3(256), 0, (hipStream_t)stream, dH, dh_stride, X, x_stride, dW, dw_stride, db, B, N, K, rows); CHECK();
+    if (single_wave) hipLaunchKernelGGL(k_wgrad<1>, dim3(tiles * chunks), dim3(64), 0, (hipStream_t)stream, dH, dh_stride, X, x_stride, dW, dw_stride, db, B, N, K, rows);
+    else hipLaunchKernelGGL(k_wgrad<4>, dim3(tiles * chunks), dim3(256), 0, (hipStream_t)stream, dH, dh_stride, X, x_stride, dW, dw_stride, db, B, N, K, rows);
+    CHECK();
 }
 int plentd3_target_action(const float *pre, const float *noise, const uint64_t *rng, const float *batch, float *sa2, float sigma, float clip, float max_a, int B, void *stream) {
     hipLaunchKernelGGL(k_target_action, GRID(B * TD3_SA), pre, noise, rng, batch, sa2, sigma, clip, max_a, B); CHECK();
@@ -384,14 +444,16 @@ int plentd3_dh2(const float *dq, const float *w3a, const float *w3b, const float
 int plentd3_relu_mask(float *g, const float *h, int B, int n, int h_stride, void *stream) {
     hipLaunchKernelGGL(k_relu_mask, GRID(B * n), g, h, B, n, h_stride); CHECK();
 }
-int plentd3_colsum(const float *g, int g_stride, const float *w, int w_stride, float *out, int B, int n, void *stream) {
+int plentd3_colsum(const float *g, int g_stride, const float *w, int w_stride, float *out, int B, int n, int single_wave, void *stream) {
     // enough workgroups to fill the chip (>= 512), at least 16 rows each
     const int cb = (n + 63) / 64;
     int splits = (512 + cb - 1) / cb;
     if (splits > B / 16) splits = B / 16;
     if (splits > 128) splits = 128;
     if (splits < 1) splits = 1;
-    hipLaunchKernelGGL(k_colsum, dim3((n + 63) / 64, splits), dim3(256), 0, (hipStream_t)stream, g, g_stride, w, w_stride, out, B, n); CHECK();
+    if (single_wave) hipLaunchKernelGGL(k_colsum<1>, dim3((n + 63) / 64, splits), dim3(64), 0, (hipStream_t)stream, g, g_stride, w, w_stride, out, B, n);
+    else hipLaunchKernelGGL(k_colsum<4>, dim3((n + 63) / 64, splits), dim3(256), 0, (hipStream_t)stream, g, g_stride, w, w_stride, out, B, n);
+    CHECK();
 }
 int plentd3_tanh_out(const float *pre, float *a, float *sa_pi, float max_a, int B, void *stream) {
     hipLaunchKernelGGL(k_tanh_out, GRID(B * TD3_A), pre, a, sa_pi, max_a, B); CHECK();
@@ -404,6 +466,22 @@ int plentd3_bias_relu(float *h, const float *bias, int B, int n, void *stream) {
 }
 int plentd3_polyak(float *target, const float *param, float tau, int n, void *stream) {
     hipLaunchKernelGGL(k_polyak, GRID(n), target, param, tau, n); CHECK();
+}
+int plentd3_adam(float *p, float *g, float *m, float *v, float *step, int *done_count, int n, double lr, double beta1, double beta2, float eps, int zero_grad,
+                 float *target, float tau, float *copy_out, void *stream) {
+    hipLaunchKernelGGL(k_adam, dim3((n + 255) / 256), dim3(64), 0, (hipStream_t)stream, p, g, m, v, step, done_count, n, lr, beta1, beta2, eps, zero_grad, target, tau, copy_out); CHECK();
+}
+int plentd3_critic_rows(const PlenTd3CriticRows *args, void *stream) {
+    if (!args || args->B <= 0) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_critic_rows, dim3((args->B + RB - 1) / RB), dim3(64), 0, (hipStream_t)stream, *args); CHECK();
+}
+int plentd3_policy_rows(const PlenTd3PolicyRows *args, void *stream) {
+    if (!args || args->B <= 0) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_policy_rows, dim3((args->B + RB - 1) / RB), dim3(64), 0, (hipStream_t)stream, *args); CHECK();
+}
+int plentd3_actor_rows(const PlenTd3ActorRows *args, void *stream) {
+    if (!args || args->B <= 0) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_actor_rows, dim3((args->B + RB - 1) / RB), dim3(64), 0, (hipStream_t)stream, *args); CHECK();
 }
 int plentd3_stamp(uint64_t *table, const int64_t *counter, int64_t div, int ring, int nslots, int idx, void *stream) {
     hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, (hipStream_t)stream, table, counter, div, ring, nslots, idx); CHECK();

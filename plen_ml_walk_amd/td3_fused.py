@@ -16,13 +16,36 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libplentd3.so")
 EXPORTS = ["plentd3_gather", "plentd3_sample_gather", "plentd3_explore", "plentd3_uniform_actions", "plentd3_store", "plentd3_target_action", "plentd3_q_heads", "plentd3_dh2", "plentd3_relu_mask", "plentd3_colsum", "plentd3_wgrad",
-           "plentd3_tanh_out", "plentd3_dtanh", "plentd3_bias_relu", "plentd3_polyak", "plentd3_stamp", "plentd3_version"]
+           "plentd3_tanh_out", "plentd3_dtanh", "plentd3_bias_relu", "plentd3_polyak", "plentd3_adam", "plentd3_critic_rows", "plentd3_policy_rows", "plentd3_actor_rows", "plentd3_stamp", "plentd3_version"]
 ROW, S, A, SA, H = 72, 26, 18, 44, 256
 _lib = None
 
 
 class PlenTd3Error(RuntimeError):
     pass
+
+
+class CriticRowsArgs(C.Structure):
+    """Mirror of PlenTd3CriticRows (include/plentd3.h)."""
+    _fields_ = ([("data", C.c_void_p), ("rng", C.c_void_p), ("total", C.c_void_p), ("capacity", C.c_int64), ("guard", C.c_int64)]
+                + [(n, C.c_void_p) for n in ("at_w1", "at_b1", "at_w2", "at_b2", "at_w3", "at_b3",
+                                             "ct_w14", "ct_b14", "ct_w2", "ct_b2", "ct_w5", "ct_b5", "ct_w3", "ct_b3", "ct_w6", "ct_b6",
+                                             "c_w14", "c_b14", "c_w2", "c_b2", "c_w5", "c_b5", "c_w3", "c_b3", "c_w6", "c_b6",
+                                             "batch", "sa_pi", "t0", "t1", "sa2", "c1", "c2", "dh2", "dh1", "dq", "loss", "db3a", "db3b", "done_count", "rng_bump")]
+                + [("sigma", C.c_float), ("clip", C.c_float), ("max_a", C.c_float), ("gamma", C.c_float), ("B", C.c_int)])
+
+
+class PolicyRowsArgs(C.Structure):
+    """Mirror of PlenTd3PolicyRows (include/plentd3.h)."""
+    _fields_ = ([(n, C.c_void_p) for n in ("a_w1", "a_b1", "a_w2", "a_b2", "a_w3", "a_b3", "c_w1", "c_b1", "c_w2", "c_b2", "c_w3",
+                                           "sa_pi", "a_pi", "p1", "p2", "g1", "dg2", "dg1", "dz", "dp2", "dp1")]
+                + [("max_a", C.c_float), ("B", C.c_int)])
+
+
+class ActorRowsArgs(C.Structure):
+    """Mirror of PlenTd3ActorRows (include/plentd3.h)."""
+    _fields_ = ([(n, C.c_void_p) for n in ("a_w1", "a_b1", "a_w2", "a_b2", "a_w3", "a_b3", "state", "rng", "p1", "p2", "action")]
+                + [("sigma", C.c_float), ("max_a", C.c_float), ("B", C.c_int)])
 
 
 def load():
@@ -44,13 +67,17 @@ def load():
         lib.plentd3_q_heads.argtypes = [vp] * 12 + [f, i, i, vp]
         lib.plentd3_dh2.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp]
         lib.plentd3_relu_mask.argtypes = [vp, vp, i, i, i, vp]
-        lib.plentd3_colsum.argtypes = [vp, i, vp, i, vp, i, i, vp]
-        lib.plentd3_wgrad.argtypes = [vp, i, vp, i, vp, i, vp, i, i, i, vp]
+        lib.plentd3_colsum.argtypes = [vp, i, vp, i, vp, i, i, i, vp]
+        lib.plentd3_wgrad.argtypes = [vp, i, vp, i, vp, i, vp, i, i, i, i, vp]
         lib.plentd3_tanh_out.argtypes = [vp, vp, vp, f, i, vp]
         lib.plentd3_dtanh.argtypes = [vp, vp, vp, f, i, vp]
         lib.plentd3_bias_relu.argtypes = [vp, vp, i, i, vp]
         lib.plentd3_polyak.argtypes = [vp, vp, f, i, vp]
         lib.plentd3_stamp.argtypes = [vp, vp, C.c_int64, i, i, i, vp]
+        lib.plentd3_critic_rows.argtypes = [C.POINTER(CriticRowsArgs), vp]
+        lib.plentd3_policy_rows.argtypes = [C.POINTER(PolicyRowsArgs), vp]
+        lib.plentd3_actor_rows.argtypes = [C.POINTER(ActorRowsArgs), vp]
+        lib.plentd3_adam.argtypes = [vp, vp, vp, vp, vp, vp, i, C.c_double, C.c_double, C.c_double, f, i, vp, f, vp, vp]
         _lib = lib
     return _lib
 
@@ -62,6 +89,42 @@ def _p(t):
 def _chk(rc):
     if rc != 0:
         raise PlenTd3Error("libplentd3 kernel launch failed: HIP error %d" % -rc)
+
+
+class FlatAdam(object):
+    """optimizer.step() of a torch.optim.Adam (td3.py:236-247: no weight decay, no amsgrad) as ONE kernel over the network's flat parameter /
+    gradient buffers (plentd3_adam) instead of torch's two multi-tensor launches.  The moments live in flat buffers of the same layout; the
+    optimizer's own state entries (exp_avg, exp_avg_sq, step) are re-pointed at views of them, so optimizer.state_dict() / checkpoints keep
+    working, and optimizer.step is replaced by this step so that no code path can apply torch's update to the shared step counter."""
+
+    def __init__(self, lib, optimizer, module, flat_params, flat_grads):
+        from .td3 import _flat_order
+        g = optimizer.param_groups[0]
+        assert len(optimizer.param_groups) == 1 and g["weight_decay"] == 0 and not g.get("amsgrad", False) and not g.get("maximize", False)
+        self.lib, self.opt, self.p, self.g = lib, optimizer, flat_params.flat, flat_grads.flat
+        self.lr, (self.b1, self.b2), self.eps = float(g["lr"]), g["betas"], float(g["eps"])
+        dev, n = self.p.device, self.p.numel()
+        self.m, self.v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        self.step_t = torch.zeros((), device=dev, dtype=torch.float32)
+        self.done = torch.zeros(1, device=dev, dtype=torch.int32)
+        off, steps = 0, set()
+        for q in _flat_order(module):
+            k = q.numel()
+            mv, vv = self.m[off:off + k].view_as(q), self.v[off:off + k].view_as(q)
+            st = optimizer.state.get(q)
+            if st:                                        # continue the optimiser's history (resumed run)
+                mv.copy_(st["exp_avg"]); vv.copy_(st["exp_avg_sq"]); steps.add(float(st["step"]))
+            optimizer.state[q] = {"step": self.step_t, "exp_avg": mv, "exp_avg_sq": vv}
+            off += k
+        assert off == n and len(steps) <= 1
+        if steps:
+            self.step_t.fill_(steps.pop())
+        optimizer.step = lambda closure=None: self.step()
+
+    def step(self, zero_grad=False, target=None, tau=0.0, copy_out=None):
+        st = C.c_void_p(torch.cuda.current_stream(self.p.device).cuda_stream)
+        _chk(self.lib.plentd3_adam(_p(self.p), _p(self.g), _p(self.m), _p(self.v), _p(self.step_t), _p(self.done), self.p.numel(), self.lr, float(self.b1), float(self.b2),
+                                   self.eps, int(zero_grad), _p(target), float(tau), _p(copy_out), st))
 
 
 class FusedTD3(object):
@@ -77,6 +140,10 @@ class FusedTD3(object):
         self.dev = agent.device
         # does the GEMM library fuse bias + ReLU into the epilogue here?  (hipBLASLt: yes; verified numerically once)
         self.probe = None
+        self.rows = os.environ.get("PLEN_TD3_ROWS", "1") == "1"      # row-block kernels (csrc/td3_rows.hip) for the in-kernel-sampled update
+        self._done_count = None
+        self._critic_adam = self._actor_adam = None
+        self._zeroed = {}
         self.epilogue = False
         try:
             x = torch.randn(8, 12, device=self.dev); w = torch.randn(5, 12, device=self.dev); b = torch.randn(5, device=self.dev)
@@ -90,7 +157,7 @@ class FusedTD3(object):
         B, N = dh.shape
         K = x.shape[1]
         assert dh.stride(1) == 1 and x.stride(1) == 1 and gw.is_contiguous() and gw.shape == (N, K)
-        _chk(self.lib.plentd3_wgrad(_p(dh), dh.stride(0), _p(x), x.stride(0), _p(gw), K, _p(gb), B, N, K, self._stream()))
+        _chk(self.lib.plentd3_wgrad(_p(dh), dh.stride(0), _p(x), x.stride(0), _p(gw), K, _p(gb), B, N, K, int(self.rows), self._stream()))
 
     @staticmethod
     def new_rng(device, seed):
@@ -99,6 +166,22 @@ class FusedTD3(object):
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def enable_flat_adam(self):
+        """Both optimisers' steps as single kernels over the flat buffers (FlatAdam), with the gradient zeroing and the Polyak updates folded in by
+        update().  Call after the agent's optimisers are final (the trainers replace them with capturable ones first)."""
+        ag = self.agent
+        self._critic_adam = FlatAdam(self.lib, ag.critic_optimizer, ag.critic, ag._critic_flat, ag._critic_grads)
+        self._actor_adam = FlatAdam(self.lib, ag.actor_optimizer, ag.actor, ag._actor_flat, ag._actor_grads)
+        ag._critic_grads.zero(); ag._actor_grads.zero()
+        self._zeroed = {"critic": True, "actor": True}            # gradient buckets known to be zero (left so by the last fused Adam step)
+
+    def _zero_grads(self, which):
+        """Zero a gradient bucket before a backward pass unless the last Adam step already did."""
+        if self._zeroed.get(which):
+            self._zeroed[which] = False
+            return
+        (self.agent._critic_grads if which == "critic" else self.agent._actor_grads).zero()
 
     def _probe(self, k):
         """Timeline hook (train_vec.PipelinedVecTD3Trainer.enable_timeline): stamp point k of the update; nothing unless a probe is installed."""
@@ -118,18 +201,30 @@ class FusedTD3(object):
     def update(self, data, idx, with_policy, noise=None, all_reduce=True, total=None, guard=0):
         """The whole iteration; with torch.distributed initialised the two gradient buckets are averaged over ranks before their Adam steps."""
         ag = self.agent
-        loss = self.critic_backward(data, idx, noise, total, guard)
+        if self.rows and isinstance(idx, int) and noise is None:
+            loss = self.critic_backward_rows(data, idx, total, guard)
+        else:
+            loss = self.critic_backward(data, idx, noise, total, guard)
         if all_reduce:
             ag._critic_grads.all_reduce_mean()
-        ag.critic_optimizer.step()
+        flat = self._critic_adam is not None
+        if flat:       # Adam + zeroed bucket (+ the critic's Polyak update, which nothing reads before the iteration's end: td3.py:348-352) in one pass
+            self._critic_adam.step(zero_grad=True, target=ag._critic_target_flat.flat if with_policy else None, tau=ag.tau)
+            self._zeroed["critic"] = True
+        else:
+            ag.critic_optimizer.step()
         ag.last_critic_loss = loss
         if with_policy:
             self.policy_backward()
             if all_reduce:
                 ag._actor_grads.all_reduce_mean()
-            ag.actor_optimizer.step()
             ag.last_actor_loss = None          # (-mean Q1 itself is not needed for the update; the autograd path reports it)
-            self.polyak()
+            if flat:
+                self._actor_adam.step(zero_grad=True, target=ag._actor_target_flat.flat, tau=ag.tau)
+                self._zeroed["actor"] = True
+            else:
+                ag.actor_optimizer.step()
+                self.polyak()
         return loss
 
     def explore(self, state, sigma, actor=None, rng=None):
@@ -138,6 +233,17 @@ class FusedTD3(object):
         actor; the pipelined trainer passes a behaviour copy).  rng None: torch.randn (autograd-path compatible)."""
         ag = self.agent
         ac = ag.actor if actor is None else actor
+        if self.rows and rng is not None:
+            n = int(state.shape[0])
+            assert state.dtype == torch.float32 and state.is_contiguous() and state.shape[1] == S
+            new = lambda *shape: torch.empty(*shape, device=self.dev, dtype=torch.float32)
+            p1, p2, act = new(n, H), new(n, H), new(n, A)
+            a = ActorRowsArgs()
+            a.a_w1, a.a_b1, a.a_w2, a.a_b2, a.a_w3, a.a_b3 = (t.data_ptr() for t in (ac.fc1.weight, ac.fc1.bias, ac.fc2.weight, ac.fc2.bias, ac.fc3.weight, ac.fc3.bias))
+            a.state, a.rng, a.p1, a.p2, a.action = state.data_ptr(), rng.data_ptr(), p1.data_ptr(), p2.data_ptr(), act.data_ptr()
+            a.sigma, a.max_a, a.B = float(sigma), float(ag.max_action), n
+            _chk(self.lib.plentd3_actor_rows(C.byref(a), self._stream()))
+            return act
         with torch.no_grad():
             p2 = self._lin_relu(self._lin_relu(state, ac.fc1.weight, ac.fc1.bias), ac.fc2.weight, ac.fc2.bias)
             pre = torch.addmm(ac.fc3.bias, p2, ac.fc3.weight.t())
@@ -205,7 +311,7 @@ class FusedTD3(object):
             # ---- critic forward, loss, backward (td3.py:312-331) ----
             cr = ag.critic
             cv, gv = ag._critic_flat.views, ag._critic_grads.views
-            ag._critic_grads.zero()
+            self._zero_grads("critic")
             c1 = self._lin_relu(sa, cv["W14"], cv["b14"])
             c2 = new(B, 2 * H)
             self._lin_relu(c1[:, :H], cr.fc2.weight, cr.fc2.bias, out=c2[:, :H])
@@ -217,8 +323,8 @@ class FusedTD3(object):
                                      _p(cr.fc3.bias.grad), _p(cr.fc6.bias.grad), _p(self.rng), float(ag.discount), B, 1, st))
             self._probe(3)
             # last layer weight gradients: dW3_c = h2_c^T dq_c
-            _chk(lib.plentd3_colsum(_p(c2), 2 * H, _p(dq), 2, _p(cr.fc3.weight.grad), B, H, st))
-            _chk(lib.plentd3_colsum(C.c_void_p(c2.data_ptr() + 4 * H), 2 * H, C.c_void_p(dq.data_ptr() + 4), 2, _p(cr.fc6.weight.grad), B, H, st))
+            _chk(lib.plentd3_colsum(_p(c2), 2 * H, _p(dq), 2, _p(cr.fc3.weight.grad), B, H, int(self.rows), st))
+            _chk(lib.plentd3_colsum(C.c_void_p(c2.data_ptr() + 4 * H), 2 * H, C.c_void_p(dq.data_ptr() + 4), 2, _p(cr.fc6.weight.grad), B, H, int(self.rows), st))
             dh2 = new(B, 2 * H)
             _chk(lib.plentd3_dh2(_p(dq), _p(cr.fc3.weight), _p(cr.fc6.weight), _p(c2), _p(dh2), B, 2, 2 * H, st))
             self._wgrad(dh2[:, :H], c1[:, :H], cr.fc2.weight.grad, cr.fc2.bias.grad)
@@ -232,6 +338,50 @@ class FusedTD3(object):
         self._probe(4)
         return loss[0]
 
+    def critic_backward_rows(self, data, B, total, guard=0):
+        """critic_backward() with everything between the sampling and the weight gradients in ONE launch of single-wave workgroups
+        (plentd3_critic_rows, csrc/td3_rows.hip): 8 kernels per critic update instead of ~35, and none of them needs more than one free wave slot
+        per workgroup to start, which is what the update lacks beside two resident env launches.  Draws its random numbers in-kernel
+        (self.rng), so it takes no idx / noise arguments."""
+        ag, lib, st = self.agent, self.lib, self._stream()
+        dev = self.dev
+        assert data.dtype == torch.float32 and data.is_contiguous() and data.shape[1] == ROW and total is not None
+        new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            at, ct, cr = ag.actor_target, ag.critic_target, ag.critic
+            tv, cv, gv = ag._critic_target_flat.views, ag._critic_flat.views, ag._critic_grads.views
+            batch, sa_pi, sa2, dq = new(B, ROW), new(B, SA), new(B, SA), new(B, 2)
+            t0, t1, c1, c2, dh2, dh1 = (new(B, 2 * H) for _ in range(6))
+            loss = torch.zeros(2, device=dev, dtype=torch.float32)
+            self._zero_grads("critic")
+            if self._done_count is None:
+                self._done_count = torch.zeros(1, device=dev, dtype=torch.int32)
+            a = CriticRowsArgs()
+            a.data, a.rng, a.total, a.capacity, a.guard = data.data_ptr(), self.rng.data_ptr(), total.data_ptr(), int(data.shape[0]), int(guard)
+            for pre, net in (("at", at),):
+                a.at_w1, a.at_b1, a.at_w2, a.at_b2, a.at_w3, a.at_b3 = (t.data_ptr() for t in (net.fc1.weight, net.fc1.bias, net.fc2.weight, net.fc2.bias, net.fc3.weight, net.fc3.bias))
+            a.ct_w14, a.ct_b14 = tv["W14"].data_ptr(), tv["b14"].data_ptr()
+            a.ct_w2, a.ct_b2, a.ct_w5, a.ct_b5, a.ct_w3, a.ct_b3, a.ct_w6, a.ct_b6 = (t.data_ptr() for t in (ct.fc2.weight, ct.fc2.bias, ct.fc5.weight, ct.fc5.bias, ct.fc3.weight, ct.fc3.bias, ct.fc6.weight, ct.fc6.bias))
+            a.c_w14, a.c_b14 = cv["W14"].data_ptr(), cv["b14"].data_ptr()
+            a.c_w2, a.c_b2, a.c_w5, a.c_b5, a.c_w3, a.c_b3, a.c_w6, a.c_b6 = (t.data_ptr() for t in (cr.fc2.weight, cr.fc2.bias, cr.fc5.weight, cr.fc5.bias, cr.fc3.weight, cr.fc3.bias, cr.fc6.weight, cr.fc6.bias))
+            a.batch, a.sa_pi, a.t0, a.t1, a.sa2, a.c1, a.c2, a.dh2, a.dh1, a.dq = (t.data_ptr() for t in (batch, sa_pi, t0, t1, sa2, c1, c2, dh2, dh1, dq))
+            a.loss, a.db3a, a.db3b = loss.data_ptr(), cr.fc3.bias.grad.data_ptr(), cr.fc6.bias.grad.data_ptr()
+            a.done_count, a.rng_bump = self._done_count.data_ptr(), self.rng.data_ptr()
+            a.sigma, a.clip, a.max_a, a.gamma, a.B = float(ag.policy_noise), float(ag.noise_clip), float(ag.max_action), float(ag.discount), int(B)
+            self._probe(1)
+            self._probe(2)
+            _chk(lib.plentd3_critic_rows(C.byref(a), st))
+            self._probe(3)
+            # weight gradients (reductions over the batch): last layers, second layers, stacked first layers
+            _chk(lib.plentd3_colsum(_p(c2), 2 * H, _p(dq), 2, _p(cr.fc3.weight.grad), B, H, int(self.rows), st))
+            _chk(lib.plentd3_colsum(C.c_void_p(c2.data_ptr() + 4 * H), 2 * H, C.c_void_p(dq.data_ptr() + 4), 2, _p(cr.fc6.weight.grad), B, H, int(self.rows), st))
+            self._wgrad(dh2[:, :H], c1[:, :H], cr.fc2.weight.grad, cr.fc2.bias.grad)
+            self._wgrad(dh2[:, H:], c1[:, H:], cr.fc5.weight.grad, cr.fc5.bias.grad)
+            self._wgrad(dh1, batch[:, :SA], gv["W14"], gv["b14"])
+        self._saved = (batch[:, :S], sa_pi, B)
+        self._probe(4)
+        return loss[0]
+
     def policy_backward(self):
         """Delayed policy gradient through the (already updated) critic's Q1 (td3.py:334-345): gradients land in the actor's flat bucket."""
         ag, lib, st = self.agent, self.lib, self._stream()
@@ -239,10 +389,25 @@ class FusedTD3(object):
         s, sa_pi, B = self._saved
         new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
         cr = ag.critic
-        if True:
+        if self.rows:
             with torch.no_grad():
                 ac = ag.actor
-                ag._actor_grads.zero()
+                self._zero_grads("actor")
+                a_pi, dz = new(B, A), new(B, A)
+                p1, p2, g1, dg2, dg1, dp2, dp1 = (new(B, H) for _ in range(7))
+                a = PolicyRowsArgs()
+                a.a_w1, a.a_b1, a.a_w2, a.a_b2, a.a_w3, a.a_b3 = (t.data_ptr() for t in (ac.fc1.weight, ac.fc1.bias, ac.fc2.weight, ac.fc2.bias, ac.fc3.weight, ac.fc3.bias))
+                a.c_w1, a.c_b1, a.c_w2, a.c_b2, a.c_w3 = (t.data_ptr() for t in (cr.fc1.weight, cr.fc1.bias, cr.fc2.weight, cr.fc2.bias, cr.fc3.weight))
+                a.sa_pi, a.a_pi, a.p1, a.p2, a.g1, a.dg2, a.dg1, a.dz, a.dp2, a.dp1 = (t.data_ptr() for t in (sa_pi, a_pi, p1, p2, g1, dg2, dg1, dz, dp2, dp1))
+                a.max_a, a.B = float(ag.max_action), int(B)
+                _chk(lib.plentd3_policy_rows(C.byref(a), st))
+                self._wgrad(dz, p2, ac.fc3.weight.grad, ac.fc3.bias.grad)
+                self._wgrad(dp2, p1, ac.fc2.weight.grad, ac.fc2.bias.grad)
+                self._wgrad(dp1, s, ac.fc1.weight.grad, ac.fc1.bias.grad)
+        else:
+            with torch.no_grad():
+                ac = ag.actor
+                self._zero_grads("actor")
                 p1 = self._lin_relu(s, ac.fc1.weight, ac.fc1.bias)
                 p2 = self._lin_relu(p1, ac.fc2.weight, ac.fc2.bias)
                 pre = torch.addmm(ac.fc3.bias, p2, ac.fc3.weight.t())

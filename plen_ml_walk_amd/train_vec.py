@@ -427,6 +427,8 @@ class PipelinedVecTD3Trainer(object):
         torch.manual_seed(seed)
         agent.actor_optimizer = GraphedVecTD3Trainer._capturable_adam(agent.actor_optimizer, agent.actor)
         agent.critic_optimizer = GraphedVecTD3Trainer._capturable_adam(agent.critic_optimizer, agent.critic)
+        if self.fused.rows:
+            self.fused.enable_flat_adam()
         # behaviour actors: 3 copies of the actor whose parameters are views of their own flat buffers
         self.behaviour = [copy.deepcopy(agent.actor) for _ in range(3)]
         self.bflat = [T._FlatParams(b) for b in self.behaviour]

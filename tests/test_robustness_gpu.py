@@ -246,6 +246,133 @@ def test_fused_td3_update_matches_the_reference_golden_iterations(golden_dir):
         _check_against_golden(g, a, k)
 
 
+@pytest.mark.parametrize("B,total", [(4096, 50000), (100, 700), (16, 40)])
+def test_critic_rows_kernel_equals_the_layer_by_layer_update(B, total):
+    """plentd3_critic_rows (one launch, 16 batch rows per wave through sampling, targets, critic forward and backward on the matrix cores) against
+    FusedTD3.critic_backward (library GEMMs + one kernel per step) from the same random state: same sampled rows, same smoothing noise (both draw
+    Philox numbers from the same counter), so the loss and every critic gradient agree to f32 summation order; the call counter advances once."""
+    from plen_ml_walk_amd import td3 as T
+    from plen_ml_walk_amd.td3_fused import FusedTD3
+    torch.manual_seed(11)
+    ag = T.TD3Agent(26, 18, 1.0, data_parallel=False)
+    for net in (ag.actor_target, ag.critic_target, ag.critic):            # away from the all-equal initial targets
+        for p_ in net.parameters():
+            p_.data.add_(0.05 * torch.randn_like(p_))
+    fz = FusedTD3(ag, seed=9)
+    data = torch.randn(1000, 72, device="cuda")
+    data[:, 70] = torch.rand(1000, device="cuda")                         # reward
+    data[:, 71] = (torch.rand(1000, device="cuda") > 0.1).float()         # not_done
+    tot = torch.tensor(total, dtype=torch.long, device="cuda")
+    rng0 = fz.rng.clone()
+    loss_a = fz.critic_backward(data, B, total=tot, guard=64).clone()
+    grads_a = ag._critic_grads.flat.clone()
+    saved_a = [t.clone() for t in fz._saved[:2]]
+    assert int(fz.rng[1]) == int(rng0[1]) + 1
+    fz.rng.copy_(rng0)
+    loss_b = fz.critic_backward_rows(data, B, total=tot, guard=64).clone()
+    grads_b = ag._critic_grads.flat.clone()
+    torch.cuda.synchronize()
+    assert int(fz.rng[1]) == int(rng0[1]) + 1 and int(fz._done_count) == 0
+    assert torch.equal(saved_a[0], fz._saved[0]) and torch.equal(saved_a[1][:, :26], fz._saved[1][:, :26])       # the same replay rows were drawn
+    assert torch.isfinite(loss_b) and abs(float(loss_a) - float(loss_b)) <= 2e-5 * max(1.0, abs(float(loss_a)))
+    scale = float(grads_a.abs().max())
+    assert scale > 0 and float((grads_a - grads_b).abs().max()) <= 2e-5 * scale
+    # and per layer, so that a wrong small block cannot hide behind a large one
+    off = 0
+    for p_ in T._flat_order(ag.critic):
+        n = p_.numel()
+        ga, gb = grads_a[off:off + n], grads_b[off:off + n]
+        assert float((ga - gb).abs().max()) <= 1e-4 * max(float(ga.abs().max()), 1e-6), tuple(p_.shape)
+        off += n
+
+
+@pytest.mark.parametrize("B", [4096, 100])
+def test_policy_rows_kernel_equals_the_layer_by_layer_policy_gradient(B):
+    """plentd3_policy_rows (actor forward, Q1 forward, the gradient of -mean Q1 back through critic and actor, one launch) + the three weight-gradient
+    launches against FusedTD3.policy_backward's layer-by-layer path on the same batch: every actor gradient agrees to f32 summation order."""
+    from plen_ml_walk_amd import td3 as T
+    from plen_ml_walk_amd.td3_fused import FusedTD3
+    torch.manual_seed(12)
+    ag = T.TD3Agent(26, 18, 1.0, data_parallel=False)
+    for net in (ag.actor, ag.critic):
+        for p_ in net.parameters():
+            p_.data.add_(0.05 * torch.randn_like(p_))
+    fz = FusedTD3(ag, seed=3)
+    data = torch.randn(500, 72, device="cuda")
+    idx = torch.randint(0, 500, (B,), device="cuda")
+    out = {}
+    for rows in (False, True):
+        fz.rows = False
+        fz.critic_backward(data, idx, noise=torch.zeros(B, 18, device="cuda"))
+        fz.rows = rows
+        fz.policy_backward()
+        torch.cuda.synchronize()
+        out[rows] = ag._actor_grads.flat.clone()
+    off = 0
+    for p_ in T._flat_order(ag.actor):
+        n = p_.numel()
+        ga, gb = out[False][off:off + n], out[True][off:off + n]
+        assert float(ga.abs().max()) > 0 and float((ga - gb).abs().max()) <= 1e-4 * float(ga.abs().max()), tuple(p_.shape)
+        off += n
+
+
+@pytest.mark.parametrize("n", [2048, 37])
+def test_actor_rows_kernel_equals_the_layer_by_layer_exploration_action(n):
+    """plentd3_actor_rows (the collect phase's actor forward + exploration noise + clip in one launch) against FusedTD3.explore's GEMMs + plentd3_explore
+    from the same random state: same Philox draws, so the actions agree to f32 summation order in the three layers."""
+    from plen_ml_walk_amd import td3 as T
+    from plen_ml_walk_amd.td3_fused import FusedTD3
+    torch.manual_seed(13)
+    ag = T.TD3Agent(26, 18, 1.0, data_parallel=False)
+    fz = FusedTD3(ag, seed=4)
+    rng = FusedTD3.new_rng("cuda", 77)
+    state = torch.randn(n, 26, device="cuda")
+    fz.rows = False
+    a0 = fz.explore(state, 0.1, rng=rng).clone()
+    fz.rows = True
+    a1 = fz.explore(state, 0.1, rng=rng).clone()
+    torch.cuda.synchronize()
+    assert a0.shape == a1.shape == (n, 18) and float(a0.abs().max()) <= 1.0 and float(a1.abs().max()) <= 1.0
+    assert float((a0 - a1).abs().max()) <= 2e-5
+
+
+def test_flat_adam_kernel_equals_torch_adam():
+    """plentd3_adam (one kernel over the flat buffers, with the fused gradient zeroing and Polyak update) against torch.optim.Adam on the same
+    gradients for 5 steps: parameters, both moments and the step counter agree; optimizer.state_dict() still describes the state."""
+    from plen_ml_walk_amd import td3 as T
+    from plen_ml_walk_amd.td3_fused import FusedTD3
+    from plen_ml_walk_amd.train_vec import GraphedVecTD3Trainer
+    torch.manual_seed(2)
+    ref = T.TD3Agent(26, 18, 1.0, data_parallel=False)
+    new = T.TD3Agent(26, 18, 1.0, data_parallel=False)
+    for dst, src in ((new.actor, ref.actor), (new.critic, ref.critic), (new.actor_target, ref.actor_target), (new.critic_target, ref.critic_target)):
+        dst.load_state_dict(src.state_dict())
+    new.critic_optimizer = GraphedVecTD3Trainer._capturable_adam(new.critic_optimizer, new.critic)
+    new.actor_optimizer = GraphedVecTD3Trainer._capturable_adam(new.actor_optimizer, new.actor)
+    fz = FusedTD3(new)
+    fz.enable_flat_adam()
+    tgt0 = new._critic_target_flat.flat.clone()
+    for k in range(5):
+        g = torch.randn_like(ref._critic_grads.flat) * (10.0 ** (k - 2))
+        ref._critic_grads.flat.copy_(g); new._critic_grads.flat.copy_(g)
+        ref.critic_optimizer.step()
+        if k == 4:
+            fz._critic_adam.step(zero_grad=True, target=new._critic_target_flat.flat, tau=0.005)
+        else:
+            new.critic_optimizer.step()                      # the patched step(): the same kernel, no extras
+    torch.cuda.synchronize()
+    a, b = ref._critic_flat.flat, new._critic_flat.flat
+    assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(a.abs().max()))
+    assert float(new._critic_grads.flat.abs().max()) == 0.0 and float(fz._critic_adam.step_t) == 5.0
+    assert torch.allclose(new._critic_target_flat.flat, 0.005 * b + 0.995 * tgt0, atol=1e-7)
+    rs, ns = ref.critic_optimizer.state_dict()["state"], new.critic_optimizer.state_dict()["state"]
+    # state entries are indexed by parameter order of module.parameters() in both optimisers
+    for i in rs:
+        assert float(ns[i]["step"]) == 5.0
+        for k in ("exp_avg", "exp_avg_sq"):
+            assert float((rs[i][k] - ns[i][k]).abs().max()) <= 1e-6 * float(rs[i][k].abs().max()), k
+
+
 @pytest.mark.parametrize("B", [256, 4096])
 def test_fused_td3_update_equals_autograd_update(B):
     """Same random problem through td3.td3_update (autograd) and FusedTD3.update: loss, every gradient and every parameter / target after a
