@@ -130,7 +130,7 @@ class FlatAdam(object):
 class FusedTD3(object):
     """update(data, idx, with_policy) == td3.td3_update(agent, (data rows idx split into s, a, s2, r, not_done), with_policy)."""
 
-    def __init__(self, agent, seed=0):
+    def __init__(self, agent, seed=0, rows=None):
         if agent.device.type != "cuda":
             raise PlenTd3Error("FusedTD3 needs the agent on a HIP device")
         self.agent = agent
@@ -140,7 +140,9 @@ class FusedTD3(object):
         self.dev = agent.device
         # does the GEMM library fuse bias + ReLU into the epilogue here?  (hipBLASLt: yes; verified numerically once)
         self.probe = None
-        self.rows = os.environ.get("PLEN_TD3_ROWS", "1") == "1"      # row-block kernels (csrc/td3_rows.hip) for the in-kernel-sampled update
+        # row-block kernels (csrc/td3_rows.hip) + single-wave weight-gradient workgroups: what the update needs when it shares the chip with resident env
+        # launches (PipelinedVecTD3Trainer: 0.73 -> 0.66 ms per step); on an otherwise idle GPU the library GEMMs are faster (critic pass 239 vs 315 us)
+        self.rows = (os.environ.get("PLEN_TD3_ROWS", "0") == "1") if rows is None else bool(rows)
         self._done_count = None
         self._critic_adam = self._actor_adam = None
         self._zeroed = {}
@@ -201,10 +203,7 @@ class FusedTD3(object):
     def update(self, data, idx, with_policy, noise=None, all_reduce=True, total=None, guard=0):
         """The whole iteration; with torch.distributed initialised the two gradient buckets are averaged over ranks before their Adam steps."""
         ag = self.agent
-        if self.rows and isinstance(idx, int) and noise is None:
-            loss = self.critic_backward_rows(data, idx, total, guard)
-        else:
-            loss = self.critic_backward(data, idx, noise, total, guard)
+        loss = self.critic_backward(data, idx, noise, total, guard)
         if all_reduce:
             ag._critic_grads.all_reduce_mean()
         flat = self._critic_adam is not None
@@ -271,7 +270,10 @@ class FusedTD3(object):
 
     def critic_backward(self, data, idx, noise=None, total=None, guard=0):
         """Sample, targets, critic forward / loss / backward: gradients land in the critic's flat bucket.  Returns the loss (device scalar).
-        idx: LongTensor [B] of replay rows, or an int B with `total` (device int64 scalar: transitions written so far) to draw them here."""
+        idx: LongTensor [B] of replay rows, or an int B with `total` (device int64 scalar: transitions written so far) to draw them here
+        (then, with self.rows, everything up to the weight gradients runs as one row-block kernel: critic_backward_rows)."""
+        if self.rows and isinstance(idx, int) and noise is None:
+            return self.critic_backward_rows(data, idx, total, guard)
         ag, lib, st = self.agent, self.lib, self._stream()
         dev = self.dev
         assert data.dtype == torch.float32 and data.is_contiguous() and data.shape[1] == ROW

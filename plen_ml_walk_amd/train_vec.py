@@ -234,6 +234,8 @@ class GraphedVecTD3Trainer(object):
         # carried over (a resumed run must not restart Adam)
         agent.actor_optimizer = self._capturable_adam(agent.actor_optimizer, agent.actor)
         agent.critic_optimizer = self._capturable_adam(agent.critic_optimizer, agent.critic)
+        if self.fused is not None:
+            self.fused.enable_flat_adam()
         self.state = env.reset().to(torch.float32).clone()
         self.total_t = torch.zeros((), dtype=torch.long, device=dev)        # transitions written so far
         self.arange_n = torch.arange(n, device=dev)
@@ -422,13 +424,12 @@ class PipelinedVecTD3Trainer(object):
         self.start_timesteps, self.expl_noise, self.batch_size = start_timesteps, expl_noise, batch_size
         dev = agent.device
         assert replay.max_size >= 4 * self.n, "the ring must hold more than the rows in flight"
-        self.fused = FusedTD3(agent, seed=seed)
+        self.fused = FusedTD3(agent, seed=seed, rows=None if "PLEN_TD3_ROWS" in os.environ else True)      # beside resident env launches: single-wave workgroups
         self.rngs = [FusedTD3.new_rng(dev, seed + 7919 * (h + 1)) for h in range(self.H)]         # one random stream per collector
         torch.manual_seed(seed)
         agent.actor_optimizer = GraphedVecTD3Trainer._capturable_adam(agent.actor_optimizer, agent.actor)
         agent.critic_optimizer = GraphedVecTD3Trainer._capturable_adam(agent.critic_optimizer, agent.critic)
-        if self.fused.rows:
-            self.fused.enable_flat_adam()
+        self.fused.enable_flat_adam()
         # behaviour actors: 3 copies of the actor whose parameters are views of their own flat buffers
         self.behaviour = [copy.deepcopy(agent.actor) for _ in range(3)]
         self.bflat = [T._FlatParams(b) for b in self.behaviour]

@@ -15,7 +15,9 @@ def main():
     data = torch.randn(100000, 72, device="cuda")
     tot = torch.tensor(100000, dtype=torch.long, device="cuda")
     s = torch.cuda.Stream()
-    for name, fn in (("layer by layer", lambda: fz.critic_backward(data, B, total=tot)), ("row blocks", lambda: fz.critic_backward_rows(data, B, total=tot))):
+    for name, rows in (("layer by layer", False), ("row blocks", True)):
+        fz.rows = rows
+        fn = lambda: fz.critic_backward(data, B, total=tot)
         with torch.cuda.stream(s):
             fn(); fn()
             g = torch.cuda.CUDAGraph()

@@ -264,12 +264,14 @@ def test_critic_rows_kernel_equals_the_layer_by_layer_update(B, total):
     data[:, 71] = (torch.rand(1000, device="cuda") > 0.1).float()         # not_done
     tot = torch.tensor(total, dtype=torch.long, device="cuda")
     rng0 = fz.rng.clone()
+    fz.rows = False                                                        # layer by layer
     loss_a = fz.critic_backward(data, B, total=tot, guard=64).clone()
     grads_a = ag._critic_grads.flat.clone()
     saved_a = [t.clone() for t in fz._saved[:2]]
     assert int(fz.rng[1]) == int(rng0[1]) + 1
     fz.rng.copy_(rng0)
-    loss_b = fz.critic_backward_rows(data, B, total=tot, guard=64).clone()
+    fz.rows = True
+    loss_b = fz.critic_backward(data, B, total=tot, guard=64).clone()
     grads_b = ag._critic_grads.flat.clone()
     torch.cuda.synchronize()
     assert int(fz.rng[1]) == int(rng0[1]) + 1 and int(fz._done_count) == 0
