@@ -286,7 +286,8 @@ def _td3_run(a, dev, rank, world, dist, steps, warmup, batch):
            "update_to_data": "%d gradient step(s) of batch %d per vector step of %d env-steps per rank (samples drawn per env-step: %.3f; the reference "
                              "does 1 step of batch 100 per single env-step, plen_td3.py:119-120)" % (a.td3_updates, batch, n, a.td3_updates * batch / n),
            "hip_graphs": True,
-           "schedule": ("actor/learner overlap: %d sub-batches of %d envs and the update on %d HIP streams, acting policy two updates old (train_vec.PipelinedVecTD3Trainer)" % (H, n // H, H + 1))
+           "schedule": ("actor/learner overlap: %d sub-batches of %d envs and the update on %d HIP streams, acting policy two updates old (train_vec.PipelinedVecTD3Trainer); "
+                        "update and actor forward as row-block MFMA kernels of single-wave workgroups (csrc/td3_rows.hip), flat Adam kernel" % (H, n // H, H + 1))
                        if pipelined else "synchronous: collect all envs, then update (train_vec.GraphedVecTD3Trainer)",
            "collective": ("RCCL all-reduce of the flat critic (155138 f32) and actor (77330 f32) gradient buckets per update, mode %s" % getattr(tr, "allreduce_mode", None)) if world > 1 else None,
            "critic_loss": float(agent.last_critic_loss) if agent.last_critic_loss is not None else None,
