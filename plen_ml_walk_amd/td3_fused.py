@@ -102,7 +102,6 @@ class FlatAdam(object):
         g = optimizer.param_groups[0]
         assert len(optimizer.param_groups) == 1 and g["weight_decay"] == 0 and not g.get("amsgrad", False) and not g.get("maximize", False)
         self.lib, self.opt, self.p, self.g = lib, optimizer, flat_params.flat, flat_grads.flat
-        self.lr, (self.b1, self.b2), self.eps = float(g["lr"]), g["betas"], float(g["eps"])
         dev, n = self.p.device, self.p.numel()
         self.m, self.v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
         self.step_t = torch.zeros((), device=dev, dtype=torch.float32)
@@ -123,8 +122,9 @@ class FlatAdam(object):
 
     def step(self, zero_grad=False, target=None, tau=0.0, copy_out=None):
         st = C.c_void_p(torch.cuda.current_stream(self.p.device).cuda_stream)
-        _chk(self.lib.plentd3_adam(_p(self.p), _p(self.g), _p(self.m), _p(self.v), _p(self.step_t), _p(self.done), self.p.numel(), self.lr, float(self.b1), float(self.b2),
-                                   self.eps, int(zero_grad), _p(target), float(tau), _p(copy_out), st))
+        g = self.opt.param_groups[0]                       # hyper-parameters as they are now (a captured graph keeps the values of its capture)
+        _chk(self.lib.plentd3_adam(_p(self.p), _p(self.g), _p(self.m), _p(self.v), _p(self.step_t), _p(self.done), self.p.numel(), float(g["lr"]), float(g["betas"][0]),
+                                   float(g["betas"][1]), float(g["eps"]), int(zero_grad), _p(target), float(tau), _p(copy_out), st))
 
 
 class FusedTD3(object):
@@ -173,6 +173,8 @@ class FusedTD3(object):
         """Both optimisers' steps as single kernels over the flat buffers (FlatAdam), with the gradient zeroing and the Polyak updates folded in by
         update().  Call after the agent's optimisers are final (the trainers replace them with capturable ones first)."""
         ag = self.agent
+        if os.environ.get("PLEN_TD3_FLAT_ADAM", "1") != "1":          # development: keep torch's fused Adam
+            return
         self._critic_adam = FlatAdam(self.lib, ag.critic_optimizer, ag.critic, ag._critic_flat, ag._critic_grads)
         self._actor_adam = FlatAdam(self.lib, ag.actor_optimizer, ag.actor, ag._actor_flat, ag._actor_grads)
         ag._critic_grads.zero(); ag._actor_grads.zero()

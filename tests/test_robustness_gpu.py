@@ -228,6 +228,27 @@ def test_graphed_trainer_cadence_and_resumed_optimizer_state(tmp_path):
     env2.close()
 
 
+def test_worker_streams_are_one_per_role_and_device():
+    """vec_env.worker_stream: the same role always gets the same stream (a second pipelined env / trainer must not walk on through torch's stream pool
+    onto shared hardware queues), different roles get different streams, and the update stream is the high-priority one."""
+    from plen_ml_walk_amd.vec_env import worker_stream, PlenVecEnvPipelined
+    dev = torch.device("cuda", 0)
+    roles = [0, 1, 2, 3, "update", "side"]
+    st = {r: worker_stream(dev, r) for r in roles}
+    assert len({s.cuda_stream for s in st.values()}) == len(roles)
+    assert all(worker_stream(dev, r).cuda_stream == st[r].cuda_stream for r in roles)
+    assert st["update"].priority < st[0].priority and all(s.cuda_stream != torch.cuda.default_stream(dev).cuda_stream for s in st.values())
+    e1 = PlenVecEnvPipelined(64, groups=2, device=dev)
+    e2 = PlenVecEnvPipelined(64, groups=4, device=dev)
+    assert [s.cuda_stream for s in e1.streams] == [st[0].cuda_stream, st[1].cuda_stream]
+    assert [s.cuda_stream for s in e2.streams] == [st[k].cuda_stream for k in range(4)]
+    a = torch.zeros(64, 18, device=dev)
+    o1 = e1.step(a)[0].clone(); o2 = e2.step(a)[0].clone()          # two envs sharing role streams still step independently and identically
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2)
+    e1.close(); e2.close()
+
+
 # ------------------------------------------------------------------------------------------------ fused TD3 update (td3_fused.py + csrc/td3_kernels.hip)
 def test_fused_td3_update_matches_the_reference_golden_iterations(golden_dir):
     """The hand-derived update (library GEMMs + the HIP kernels of libplentd3.so) on the reference's golden problem: same initial parameters,
