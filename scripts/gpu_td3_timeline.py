@@ -1,5 +1,5 @@
 """Steady-state schedule of the pipelined TD3 trainer read from device-clock stamps inside its graphs (no profiler: rocprofv3's kernel trace
-serialises dispatches and slows the host enough to change the picture).   usage: python scripts/gpu_td3_timeline.py [batch] [rows]"""
+serialises dispatches and slows the host enough to change the picture).   usage: python scripts/gpu_td3_timeline.py [batch] [rows] [start_timesteps]"""
 import os
 import sys
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
@@ -10,6 +10,7 @@ import torch
 def main():
     batch = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     rows = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    start = int(sys.argv[3]) if len(sys.argv) > 3 else 10000          # start_timesteps: huge = collectors only (uniform random actions, no update)
     dev = torch.device("cuda", 0)
     from plen_ml_walk_amd.vec_env import PlenVecEnv
     from plen_ml_walk_amd.td3 import ReplayBuffer, TD3Agent
@@ -19,7 +20,7 @@ def main():
     agent = TD3Agent(26, 18, 1.0, device=dev)
     replay = ReplayBuffer(1000000, device=dev)
     envs = [PlenVecEnv(n // H, device=dev) for _ in range(H)]
-    tr = PipelinedVecTD3Trainer(envs, agent, replay, start_timesteps=10000, expl_noise=0.1, batch_size=batch, seed=1000)
+    tr = PipelinedVecTD3Trainer(envs, agent, replay, start_timesteps=start, expl_noise=0.1, batch_size=batch, seed=1000)
     tl = tr.enable_timeline(64)
     for _ in range(64 * 3 + 7):
         tr.step()
