@@ -39,12 +39,14 @@ static __device__ __forceinline__ void mm_nt(rsrc_t rx, uint32_t xoff, rsrc_t rw
     const uint32_t woff = (uint32_t)((n0 + r) * ldw + 4 * g) * 4u;
     auto load = [&](int k0, floatx4 &a, floatx4 (&b)[NT]) {
         a = bload4(rx, xoff, 4u * (uint32_t)k0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) b[t] = bload4(rw, woff, 4u * (uint32_t)(16 * t * ldw + k0));
+    };
+    auto guard = [&](int k0, floatx4 &a) {            // at the point of use, not of the load (a select right after the load would wait for it)
         if constexpr (KGUARD) {
 #pragma unroll
             for (int j = 0; j < 4; j++) a[j] = k0 + 4 * g + j < K ? a[j] : 0.f;
         }
-#pragma unroll
-        for (int t = 0; t < NT; t++) b[t] = bload4(rw, woff, 4u * (uint32_t)(16 * t * ldw + k0));
     };
     // two stages in flight: the loads of the next 16 k are issued BEFORE the 32 MFMAs of the current ones (the compiler, left alone, sinks them to
     // their first use and exposes the whole L2 latency every step: hence the scheduling barriers).  Loads past K are harmless (zero-guarded A,
@@ -55,6 +57,7 @@ static __device__ __forceinline__ void mm_nt(rsrc_t rx, uint32_t xoff, rsrc_t rw
     for (int k0 = 0; k0 < K; k0 += 32) {
         load(k0 + 16, a1, b1);
         __builtin_amdgcn_sched_barrier(0);
+        guard(k0, a0);
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -62,6 +65,7 @@ static __device__ __forceinline__ void mm_nt(rsrc_t rx, uint32_t xoff, rsrc_t rw
         __builtin_amdgcn_sched_barrier(0);
         load(k0 + 32, a0, b0);
         __builtin_amdgcn_sched_barrier(0);
+        guard(k0 + 16, a1);
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -75,12 +79,14 @@ static __device__ __forceinline__ void mm_nt(rsrc_t rx, uint32_t xoff, rsrc_t rw
 template <int NT, bool KGUARD>
 static __device__ __forceinline__ void mm_nn(rsrc_t rg, uint32_t goff, rsrc_t rw, int ldw, int j0, int Kc, floatx4 (&acc)[NT], int r, int g) {
     const uint32_t woff = (uint32_t)(4 * g * ldw + j0 + r) * 4u;
-    auto load = [&](int n0, floatx4 &a, floatx4 (&b)[NT]) {
-        a = bload4(rg, goff, 4u * (uint32_t)n0);
+    auto guard = [&](int n0, floatx4 &a) {
         if constexpr (KGUARD) {
 #pragma unroll
             for (int j = 0; j < 4; j++) a[j] = n0 + 4 * g + j < Kc ? a[j] : 0.f;
         }
+    };
+    auto load = [&](int n0, floatx4 &a, floatx4 (&b)[NT]) {
+        a = bload4(rg, goff, 4u * (uint32_t)n0);
 #pragma unroll
         for (int t = 0; t < NT; t++)
 #pragma unroll
@@ -92,6 +98,7 @@ static __device__ __forceinline__ void mm_nn(rsrc_t rg, uint32_t goff, rsrc_t rw
     for (int n0 = 0; n0 < Kc; n0 += 32) {
         load(n0 + 16, a1, b1);
         __builtin_amdgcn_sched_barrier(0);
+        guard(n0, a0);
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -99,6 +106,7 @@ static __device__ __forceinline__ void mm_nn(rsrc_t rg, uint32_t goff, rsrc_t rw
         __builtin_amdgcn_sched_barrier(0);
         load(n0 + 32, a0, b0);
         __builtin_amdgcn_sched_barrier(0);
+        guard(n0 + 16, a1);
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -108,13 +116,22 @@ static __device__ __forceinline__ void mm_nn(rsrc_t rg, uint32_t goff, rsrc_t rw
 }
 
 // Result layout of the 16x16 MFMA: lane (r, g) holds rows 4 g + i (i = 0..3) of column 16 t + r in acc[t][i].
-// Geometry of the wave's row block, shared by every phase
+// Geometry of the wave's row block.  Every phase builds its own from an opaque lane id (fresh_rows): lane-derived offsets and pointers are then not
+// common subexpressions of the whole kernel, computed once at its top and kept alive -- spilled into scratch, in the k loops too -- across all phases.
 struct RowBlock {
-    int b0, B, r, g, brow;
+    int b0, B, r, g, brow, lane;
     // byte offset of element [b0 + 4 g][r] of a row-major [B][ld] matrix (stores), and of [brow][4 g] (A-operand loads)
     __device__ __forceinline__ uint32_t soff(int ld) const { return (uint32_t)((b0 + 4 * g) * ld + r) * 4u; }
     __device__ __forceinline__ uint32_t aoff(int ld, int col0 = 0) const { return (uint32_t)(brow * ld + col0 + 4 * g) * 4u; }
 };
+
+static __device__ __forceinline__ RowBlock fresh_rows(int b0, int B) {
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    const int r = lane & 15;
+    return RowBlock{b0, B, r, lane >> 4, min(b0 + r, B - 1), lane};
+}
+#define PHASE() const RowBlock rb = fresh_rows(b0, B); const int r = rb.r, g = rb.g, lane = rb.lane, brow = rb.brow; (void)r; (void)g; (void)lane; (void)brow
 
 // Y[b0 + row][n0 + (0..16 NT)] = relu(X W^T + bias): one column block of a hidden layer, stored row-major (rows beyond B fall outside ry: dropped)
 template <int NT, bool KGUARD>
@@ -173,6 +190,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const int brow = min(b0 + r, B - 1);                 // the batch row whose activations this lane feeds to the matrix cores
     // ---- sample 16 rows of the replay ring (td3.py:166-193; same draw as k_sample_gather) and gather them ----
     {
+        PHASE();
         int64_t idx = 0;
         if (lane < RB) {
             const int b = min(b0 + lane, B - 1);
@@ -201,7 +219,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
     }
     FENCE();
-    const RowBlock rb{b0, B, r, g, brow};
+    const RowBlock rb{b0, B, r, g, brow, lane};
     const size_t Bz = (size_t)B;
     const rsrc_t r_batch = mkrs(A.batch, Bz * TD3_ROW * 4), r_t0 = mkrs(A.t0, Bz * 2 * TD3_H * 4), r_t1 = mkrs(A.t1, Bz * 2 * TD3_H * 4), r_sa2 = mkrs(A.sa2, Bz * TD3_SA * 4);
     const rsrc_t r_c1 = mkrs(A.c1, Bz * 2 * TD3_H * 4), r_c2 = mkrs(A.c2, Bz * 2 * TD3_H * 4);
@@ -209,18 +227,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     // ---- target policy smoothing (td3.py:299-304): actor_target(s2) -> noisy clipped action -> sa2 = [s2 | a2] ----
     // (t0 / t1: scratch rows of 512 floats private to the wave's batch rows -- one row stride for every use, so no two waves ever share a line)
     {
+        PHASE();
         const rsrc_t rw = mkrs(A.at_w1, (size_t)TD3_H * TD3_S * 4);
 #pragma unroll 1
         for (int n0 = 0; n0 < TD3_H; n0 += 128) dense_relu<8, true>(r_batch, rb.aoff(TD3_ROW, TD3_SA), TD3_S, rw, TD3_S, A.at_b1, n0, r_t0, 2 * TD3_H, rb);
     }
     FENCE();
     {
+        PHASE();
         const rsrc_t rw = mkrs(A.at_w2, (size_t)TD3_H * TD3_H * 4);
 #pragma unroll 1
         for (int n0 = 0; n0 < TD3_H; n0 += 128) dense_relu<8, false>(r_t0, rb.aoff(2 * TD3_H), TD3_H, rw, TD3_H, A.at_b2, n0, r_t1, 2 * TD3_H, rb);
     }
     FENCE();
     {
+        PHASE();
         floatx4 acc[2] = {floatx4{0, 0, 0, 0}, floatx4{0, 0, 0, 0}};
         mm_nt<2, false>(r_t1, rb.aoff(2 * TD3_H), mkrs(A.at_w3, (size_t)TD3_A * TD3_H * 4), TD3_H, 0, TD3_H, acc, r, g);
 #pragma unroll
@@ -249,74 +270,87 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     FENCE();
     // ---- clipped double-Q target (td3.py:306-309): both target critics' first layers stacked (W14 = [fc1.w; fc4.w]) ----
     {
+        PHASE();
         const rsrc_t rw = mkrs(A.ct_w14, (size_t)2 * TD3_H * TD3_SA * 4);
 #pragma unroll 1
         for (int n0 = 0; n0 < 2 * TD3_H; n0 += 128) dense_relu<8, true>(r_sa2, rb.aoff(TD3_SA), TD3_SA, rw, TD3_SA, A.ct_b14, n0, r_t0, 2 * TD3_H, rb);
     }
     FENCE();
-    float y[4];
+    // (values that would have to survive the next matrix products in registers -- y, dq -- go through memory instead: the products' two load stages
+    // and accumulators leave no room, and spills inside the k loops cost more than these few loads)
     {
+        PHASE();
         float qa[4], qb[4];
         critic_l2_head<false>(r_t0, rb.aoff(2 * TD3_H), A.ct_w2, A.ct_b2, A.ct_w3, A.ct_b3, r_t0, 0, 0, rb, qa);
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (r == 0) A.t1[(size_t)min(b0 + 4 * g + i, B - 1) * 2 * TD3_H] = qa[i];            // park q_a (t1 is free by now)
         critic_l2_head<false>(r_t0, rb.aoff(2 * TD3_H, TD3_H), A.ct_w5, A.ct_b5, A.ct_w6, A.ct_b6, r_t0, 0, 0, rb, qb);
+        FENCE();
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const float *row = A.batch + (size_t)min(b0 + 4 * g + i, B - 1) * TD3_ROW;
-            y[i] = row[TD3_ROW - 2] + row[TD3_ROW - 1] * A.gamma * fminf(qa[i], qb[i]);
+            const int bb = min(b0 + 4 * g + i, B - 1);
+            const float *row = A.batch + (size_t)bb * TD3_ROW;
+            const float y = row[TD3_ROW - 2] + row[TD3_ROW - 1] * A.gamma * fminf(A.t1[(size_t)bb * 2 * TD3_H], qb[i]);
+            if (r == 0) A.t1[(size_t)bb * 2 * TD3_H + 1] = y;                                                          // y[b] for the loss below
         }
     }
     // ---- critic forward, loss, and its gradient down to the hidden layers (td3.py:312-323) ----
     {
+        PHASE();
         const rsrc_t rw = mkrs(A.c_w14, (size_t)2 * TD3_H * TD3_SA * 4);
 #pragma unroll 1
         for (int n0 = 0; n0 < 2 * TD3_H; n0 += 128) dense_relu<8, true>(r_batch, rb.aoff(TD3_ROW), TD3_SA, rw, TD3_SA, A.c_b14, n0, r_c1, 2 * TD3_H, rb);
     }
     FENCE();
-    float dqa[4], dqb[4];
     {
-        float qa[4], qb[4];
-        critic_l2_head<true>(r_c1, rb.aoff(2 * TD3_H), A.c_w2, A.c_b2, A.c_w3, A.c_b3, r_c2, 2 * TD3_H, 0, rb, qa);
-        critic_l2_head<true>(r_c1, rb.aoff(2 * TD3_H, TD3_H), A.c_w5, A.c_b5, A.c_w6, A.c_b6, r_c2, 2 * TD3_H, TD3_H, rb, qb);
+        PHASE();
         const float inv = 1.f / (float)B;
-        float lsum = 0.f, ga = 0.f, gb = 0.f;
+        float lsum = 0.f, gsum[2] = {0.f, 0.f};
+#pragma unroll 1
+        for (int c = 0; c < 2; c++) {
+            float q[4];
+            critic_l2_head<true>(r_c1, rb.aoff(2 * TD3_H, c * TD3_H), c ? A.c_w5 : A.c_w2, c ? A.c_b5 : A.c_b2, c ? A.c_w6 : A.c_w3, c ? A.c_b6 : A.c_b3, r_c2, 2 * TD3_H, c * TD3_H, rb, q);
+            float gs = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int b = b0 + 4 * g + i;
-            const float ea = qa[i] - y[i], eb = qb[i] - y[i];
-            dqa[i] = 2.f * ea * inv; dqb[i] = 2.f * eb * inv;
-            if (r == 0 && b < B) {
-                A.dq[2 * b] = dqa[i]; A.dq[2 * b + 1] = dqb[i];
-                lsum += (ea * ea + eb * eb) * inv; ga += dqa[i]; gb += dqb[i];
+            for (int i = 0; i < 4; i++) {
+                const int b = b0 + 4 * g + i;
+                if (r == 0 && b < B) {
+                    const float e = q[i] - A.t1[(size_t)b * 2 * TD3_H + 1], d = 2.f * e * inv;
+                    A.dq[2 * b + c] = d;
+                    lsum += e * e * inv; gs += d;
+                }
             }
+            gsum[c] = gs;
         }
-        lsum = wave_sum(lsum); ga = wave_sum(ga); gb = wave_sum(gb);
+        lsum = wave_sum(lsum);
+        const float ga = wave_sum(gsum[0]), gb = wave_sum(gsum[1]);
         if (lane == 0) { atomicAdd(A.loss, lsum); atomicAdd(A.db3a, ga); atomicAdd(A.db3b, gb); }
     }
     FENCE();
     // dh2 = dq (x) w3 where the hidden unit was active: rows of this wave, 4 columns per lane and critic
+    {
+        PHASE();
 #pragma unroll 1
     for (int c = 0; c < 2; c++) {
         const floatx4 wv = *reinterpret_cast<const floatx4 *>((c ? A.c_w6 : A.c_w3) + 4 * lane);
-#pragma unroll 1
-        for (int gi = 0; gi < 4; gi++) {
+#pragma unroll 4
+        for (int i = 0; i < RB; i++) {
+            const int b = b0 + i;
+            if (b >= B) break;
+            const float d = A.dq[2 * b + c];
+            const size_t o = (size_t)b * 2 * TD3_H + c * TD3_H + 4 * lane;
+            const floatx4 h = *reinterpret_cast<const floatx4 *>(A.c2 + o);
+            floatx4 dv;
 #pragma unroll
-            for (int ii = 0; ii < 4; ii++) {
-                const int b = b0 + 4 * gi + ii;                                            // row 4 gi + ii lives in lane group gi, slot ii
-                const float d = __shfl(c ? dqb[ii] : dqa[ii], 16 * gi);
-                if (b < B) {
-                    const size_t o = (size_t)b * 2 * TD3_H + c * TD3_H + 4 * lane;
-                    const floatx4 h = *reinterpret_cast<const floatx4 *>(A.c2 + o);
-                    floatx4 dv;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) dv[j] = h[j] > 0.f ? d * wv[j] : 0.f;
-                    *reinterpret_cast<floatx4 *>(A.dh2 + o) = dv;
-                }
-            }
+            for (int j = 0; j < 4; j++) dv[j] = h[j] > 0.f ? d * wv[j] : 0.f;
+            *reinterpret_cast<floatx4 *>(A.dh2 + o) = dv;
         }
+    }
     }
     FENCE();
     // dh1_c = (dh2_c W2_c) where c1_c was active
     {
+        PHASE();
         const rsrc_t r_dh2 = mkrs(A.dh2, Bz * 2 * TD3_H * 4), r_dh1 = mkrs(A.dh1, Bz * 2 * TD3_H * 4);
         const uint32_t ooff = rb.soff(2 * TD3_H);
 #pragma unroll 1
@@ -350,7 +384,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_policy_rows(PlenTd3PolicyRows A) {
     const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
     const int B = A.B, b0 = blockIdx.x * RB;
-    const RowBlock rb{b0, B, r, g, min(b0 + r, B - 1)};
+    const RowBlock rb{b0, B, r, g, min(b0 + r, B - 1), lane};
     const size_t Bz = (size_t)B;
     const rsrc_t r_sa = mkrs(A.sa_pi, Bz * TD3_SA * 4), r_p1 = mkrs(A.p1, Bz * TD3_H * 4), r_p2 = mkrs(A.p2, Bz * TD3_H * 4), r_g1 = mkrs(A.g1, Bz * TD3_H * 4);
     const rsrc_t r_dg2 = mkrs(A.dg2, Bz * TD3_H * 4), r_dg1 = mkrs(A.dg1, Bz * TD3_H * 4), r_dp2 = mkrs(A.dp2, Bz * TD3_H * 4), r_dp1 = mkrs(A.dp1, Bz * TD3_H * 4);
@@ -358,18 +392,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const uint32_t hoff = rb.soff(TD3_H);
     // actor forward: s = state columns of sa_pi (left there by the critic pass)
     {
+        PHASE();
         const rsrc_t rw = mkrs(A.a_w1, (size_t)TD3_H * TD3_S * 4);
 #pragma unroll 1
         for (int n0 = 0; n0 < TD3_H; n0 += 128) dense_relu<8, true>(r_sa, rb.aoff(TD3_SA), TD3_S, rw, TD3_S, A.a_b1, n0, r_p1, TD3_H, rb);
     }
     FENCE();
     {
+        PHASE();
         const rsrc_t rw = mkrs(A.a_w2, (size_t)TD3_H * TD3_H * 4);
 #pragma unroll 1
         for (int n0 = 0; n0 < TD3_H; n0 += 128) dense_relu<8, false>(r_p1, rb.aoff(TD3_H), TD3_H, rw, TD3_H, A.a_b2, n0, r_p2, TD3_H, rb);
     }
     FENCE();
     {
+        PHASE();
         floatx4 acc[2] = {floatx4{0, 0, 0, 0}, floatx4{0, 0, 0, 0}};
         mm_nt<2, false>(r_p2, rb.aoff(TD3_H), mkrs(A.a_w3, (size_t)TD3_A * TD3_H * 4), TD3_H, 0, TD3_H, acc, r, g);
 #pragma unroll
@@ -392,12 +429,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     FENCE();
     // critic.Q1 forward (fc1 = the first 256 rows of W14) and the gradient of -mean Q1 at its second hidden layer: dg2 = -(1/B) w3 (g2 > 0)
     {
+        PHASE();
         const rsrc_t rw = mkrs(A.c_w1, (size_t)TD3_H * TD3_SA * 4);
 #pragma unroll 1
         for (int n0 = 0; n0 < TD3_H; n0 += 128) dense_relu<8, true>(r_sa, rb.aoff(TD3_SA), TD3_SA, rw, TD3_SA, A.c_b1, n0, r_g1, TD3_H, rb);
     }
     FENCE();
     {
+        PHASE();
         const rsrc_t rw = mkrs(A.c_w2, (size_t)TD3_H * TD3_H * 4);
         const float ginv = -1.f / (float)B;
 #pragma unroll 1
@@ -418,6 +457,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     FENCE();
     // dg1 = (dg2 W2)(g1 > 0)
     {
+        PHASE();
         const rsrc_t rw = mkrs(A.c_w2, (size_t)TD3_H * TD3_H * 4);
 #pragma unroll 1
         for (int j0 = 0; j0 < TD3_H; j0 += 128) {
@@ -437,6 +477,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     FENCE();
     // d/d action = (dg1 W1)[:, 26:44], through the tanh: dz = that * (max_a - a^2 / max_a)
     {
+        PHASE();
         floatx4 acc[2] = {floatx4{0, 0, 0, 0}, floatx4{0, 0, 0, 0}};
         mm_nn<2, false>(r_dg1, rb.aoff(TD3_H), mkrs(A.c_w1, (size_t)TD3_H * TD3_SA * 4), TD3_SA, TD3_S, TD3_H, acc, r, g);
 #pragma unroll
@@ -457,6 +498,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     FENCE();
     // back through the actor: dp2 = (dz W3)(p2 > 0), dp1 = (dp2 W2)(p1 > 0)
     {
+        PHASE();
         const rsrc_t rw = mkrs(A.a_w3, (size_t)TD3_A * TD3_H * 4);
 #pragma unroll 1
         for (int j0 = 0; j0 < TD3_H; j0 += 128) {
@@ -475,6 +517,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
     FENCE();
     {
+        PHASE();
         const rsrc_t rw = mkrs(A.a_w2, (size_t)TD3_H * TD3_H * 4);
 #pragma unroll 1
         for (int j0 = 0; j0 < TD3_H; j0 += 128) {
@@ -497,34 +540,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_actor_rows(PlenTd3ActorRows A) {
     const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
     const int B = A.B, b0 = blockIdx.x * RB;
-    const RowBlock rb{b0, B, r, g, min(b0 + r, B - 1)};
+    const RowBlock rb{b0, B, r, g, min(b0 + r, B - 1), lane};
     const size_t Bz = (size_t)B;
     const rsrc_t r_s = mkrs(A.state, Bz * TD3_S * 4), r_p1 = mkrs(A.p1, Bz * TD3_H * 4), r_p2 = mkrs(A.p2, Bz * TD3_H * 4);
     {
+        PHASE();
         const rsrc_t rw = mkrs(A.a_w1, (size_t)TD3_H * TD3_S * 4);
 #pragma unroll 1
         for (int n0 = 0; n0 < TD3_H; n0 += 128) dense_relu<8, true>(r_s, rb.aoff(TD3_S), TD3_S, rw, TD3_S, A.a_b1, n0, r_p1, TD3_H, rb);
     }
     FENCE();
     {
+        PHASE();
         const rsrc_t rw = mkrs(A.a_w2, (size_t)TD3_H * TD3_H * 4);
 #pragma unroll 1
         for (int n0 = 0; n0 < TD3_H; n0 += 128) dense_relu<8, false>(r_p1, rb.aoff(TD3_H), TD3_H, rw, TD3_H, A.a_b2, n0, r_p2, TD3_H, rb);
     }
     FENCE();
-    floatx4 acc[2] = {floatx4{0, 0, 0, 0}, floatx4{0, 0, 0, 0}};
-    mm_nt<2, false>(r_p2, rb.aoff(TD3_H), mkrs(A.a_w3, (size_t)TD3_A * TD3_H * 4), TD3_H, 0, TD3_H, acc, r, g);
+    {
+        PHASE();
+        floatx4 acc[2] = {floatx4{0, 0, 0, 0}, floatx4{0, 0, 0, 0}};
+        mm_nt<2, false>(r_p2, rb.aoff(TD3_H), mkrs(A.a_w3, (size_t)TD3_A * TD3_H * 4), TD3_H, 0, TD3_H, acc, r, g);
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const int j = 16 * t + r;
-        if (j < TD3_A) {
-            const float bv = A.a_b3[j];
+        for (int t = 0; t < 2; t++) {
+            const int j = 16 * t + r;
+            if (j < TD3_A) {
+                const float bv = A.a_b3[j];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int b = b0 + 4 * g + i;
-                if (b < B) {
-                    const int e = b * TD3_A + j;
-                    A.action[e] = fminf(fmaxf(A.max_a * tanhf(acc[t][i] + bv) + rng_normal(A.rng, 2u, (uint32_t)e) * A.sigma, -A.max_a), A.max_a);
+                for (int i = 0; i < 4; i++) {
+                    const int b = b0 + 4 * g + i;
+                    if (b < B) {
+                        const int e = b * TD3_A + j;
+                        A.action[e] = fminf(fmaxf(A.max_a * tanhf(acc[t][i] + bv) + rng_normal(A.rng, 2u, (uint32_t)e) * A.sigma, -A.max_a), A.max_a);
+                    }
                 }
             }
         }
