@@ -267,7 +267,7 @@ def test_fused_td3_update_matches_the_reference_golden_iterations(golden_dir):
         _check_against_golden(g, a, k)
 
 
-@pytest.mark.parametrize("B,total", [(4096, 50000), (100, 700), (16, 40)])
+@pytest.mark.parametrize("B,total", [(4096, 50000), (100, 700), (16, 40), (3, 5)])
 def test_critic_rows_kernel_equals_the_layer_by_layer_update(B, total):
     """plentd3_critic_rows (one launch, 16 batch rows per wave through sampling, targets, critic forward and backward on the matrix cores) against
     FusedTD3.critic_backward (library GEMMs + one kernel per step) from the same random state: same sampled rows, same smoothing noise (both draw
@@ -309,7 +309,7 @@ def test_critic_rows_kernel_equals_the_layer_by_layer_update(B, total):
         off += n
 
 
-@pytest.mark.parametrize("B", [4096, 100])
+@pytest.mark.parametrize("B", [4096, 100, 3])
 def test_policy_rows_kernel_equals_the_layer_by_layer_policy_gradient(B):
     """plentd3_policy_rows (actor forward, Q1 forward, the gradient of -mean Q1 back through critic and actor, one launch) + the three weight-gradient
     launches against FusedTD3.policy_backward's layer-by-layer path on the same batch: every actor gradient agrees to f32 summation order."""
