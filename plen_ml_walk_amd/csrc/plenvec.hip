@@ -110,13 +110,33 @@ __device__ inline float rcp_(float x) { return 1.0f / x; }
 #else
 __device__ inline float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
 #endif
+// f64: the compiler's correctly rounded division / square root are 12 / 15 dependent instructions.  v_rcp_f64 / v_rsq_f64 + two Newton steps are 5 / 9
+// and agree with them to 0 / 1.7 ulp over 1e6 arguments spanning e^+-30 (measured on the MI355X) -- far inside what separates the kernel from the
+// oracle anyway (different summation orders).  PLENVEC_EXACT_MATH keeps the divisions.
+#ifdef PLENVEC_EXACT_MATH
 __device__ inline double rcp_(double x) { return 1.0 / x; }
+#else
+__device__ __forceinline__ double rcp_(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    return __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+}
+#endif
 #ifdef PLENVEC_EXACT_MATH
 __device__ inline float rsqrt_(float x) { return 1.0f / sqrtf(x); }
 #else
 __device__ inline float rsqrt_(float x) { return __builtin_amdgcn_rsqf(x); }
 #endif
+#ifdef PLENVEC_EXACT_MATH
 __device__ inline double rsqrt_(double x) { return 1.0 / sqrt(x); }
+#else
+__device__ __forceinline__ double rsqrt_(double x) {
+    const double h = 0.5 * x;
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * __builtin_fma(-(h * y), y, 1.5);
+    return y * __builtin_fma(-(h * y), y, 1.5);
+}
+#endif
 __device__ inline float sqrt_(float x) { return sqrtf(x); }
 __device__ inline double sqrt_(double x) { return sqrt(x); }
 // f32: the hardware sine/cosine (v_sin_f32 / v_cos_f32 on x / 2pi).  Arguments here are joint angles (|q| < pi) and half rotation
@@ -610,7 +630,20 @@ __device__ __forceinline__ void pgs_cone(real &e, const real u, real &dvec, cons
     real scale;
     // Bullet clamps row A to |lim*sin(atan2(sA,sB))| and row B to |lim*cos(..)|: a radial projection onto the circle
     if constexpr (sizeof(real) == 4) scale = min_(1.0f, lmv * rsqrt_(len2));                   // v_rsq_f32; 0*inf = NaN -> 1 (s == 0 then); 1 ulp, f32 path only
-    else scale = len2 >= lmv * lmv ? (len2 > 0 ? lmv / sqrt_(len2) : (real)0) : (real)1;
+    else {
+#ifdef PLENVEC_EXACT_MATH
+        scale = len2 >= lmv * lmv ? (len2 > 0 ? lmv / sqrt_(len2) : (real)0) : (real)1;
+#else
+        // f64: a correctly rounded square root and division are ~28 instructions of the ~55 this pair costs.  (1) a pair inside its friction circle
+        // needs neither (scale = 1): only the pair's own two lanes decide, so one scalar test skips them; (2) a sliding pair gets
+        // lmv * rsqrt_(len2) (v_rsq_f64 and two Newton steps, < 2 ulp of lmv / sqrt(len2); 10 instructions).
+        const bool slide = len2 >= lmv * lmv;
+        scale = (real)1;
+        if (__ballot(slide) & ((1ull << LA) | (1ull << LB))) {
+            scale = slide ? (len2 > 0 ? lmv * rsqrt_(len2) : (real)0) : (real)1;
+        }
+#endif
+    }
     const real d = fma_(w, scale, -u);              // deltaVel of this lane's row
     const real dA = bcast(d, LA), dB = bcast(d, LB);
     dvec = wrlane<LA>(dvec, dA, lane); dvec = wrlane<LB>(dvec, dB, lane);     // u += dvec after the pass (no lane masks kept alive)
@@ -1085,8 +1118,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         constexpr int K = NV - 1 - decltype(kc)::value;
         const real piv = bcast(Lr[K], K);
         real rd;
-        if constexpr (sizeof(real) == 4) rd = rsqrt_(piv);                      // v_rsq_f32, 1 ulp; f32 path only
-        else rd = (real)1 / sqrt_(piv);
+        rd = rsqrt_(piv);                                  // f32: v_rsq_f32, 1 ulp; f64: v_rsq_f64 + two Newton steps, < 2 ulp
         if (lane == 0) s.col[K] = rd;                      // collected below: every lane needs its own 1/L[k][k]
         const real lik = lane < K ? Lr[K] * rd : (real)0;      // L[K][i] in lane i < K; zero on and below the diagonal of L^T
         Lr[K] = lik;
