@@ -235,6 +235,17 @@ __device__ __forceinline__ double wrlane(double dst, double val, int lane) {
     asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4" : "+v"(lo), "+v"(hi) : "s"(slo), "s"(shi), "i"(L));
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
+// f64 rows: the commit placed AFTER the row's fma in program order.  The next row's clamp waits for that fma anyway (e is the dependent chain),
+// so the two v_writelane fill its latency instead of sitting -- with their wait states -- between the broadcast and the fma.  One wait state
+// is left of the VALU-wrote-SGPR -> v_writelane hazard (the fma has issued in between).
+template <int L>
+__device__ __forceinline__ double wrlane_late(double dst, double val) {
+    const long long d = __builtin_bit_cast(long long, dst), v = __builtin_bit_cast(long long, val);
+    int lo = (int)(d & 0xffffffffLL), hi = (int)(d >> 32);
+    const int slo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffLL)), shi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+    asm volatile("s_nop 0\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4" : "+v"(lo), "+v"(hi) : "s"(slo), "s"(shi), "i"(L));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
 // compiler-path commit of a row's delta into lane L of the per-pass vector: f32 keeps the select (bit-identical to the asm path's
 // v_writelane and what the NO_ASM build is there to check), f64 uses the writelane form above
 template <int L>
@@ -344,8 +355,14 @@ __device__ __forceinline__ void pgs_row2d(real &e, const real blo, const real bh
 #pragma clang fp contract(off)
         const real d = min_(max_(-e, blo), bhi);
         const real db = bcast(d, lane_of_port(PP));
-        dvec = commit_lane<lane_of_port(PP)>(dvec, db, lane);
-        e = fma_(db, acol, e);
+        if constexpr (sizeof(real) == 8) {
+            e = fma_(db, acol, e);
+            __builtin_amdgcn_sched_barrier(0);
+            dvec = wrlane_late<lane_of_port(PP)>(dvec, db);
+        } else {
+            dvec = commit_lane<lane_of_port(PP)>(dvec, db, lane);
+            e = fma_(db, acol, e);
+        }
     }
 }
 // The 18 motor rows of one pass as ONE software-pipelined block (f32 fast path): the v_writelane that commits
@@ -580,8 +597,14 @@ __device__ __forceinline__ void pgs_rowTd(real &e, const real nt1, const real t2
 #pragma clang fp contract(off)
         const real d = min_(max_(-e, nt1), t2);
         const real db = bcast(d, lane_of_port(PP));
-        dvec = commit_lane<lane_of_port(PP)>(dvec, db, lane);
-        e = fma_(db, acol, e);
+        if constexpr (sizeof(real) == 8) {
+            e = fma_(db, acol, e);
+            __builtin_amdgcn_sched_barrier(0);
+            dvec = wrlane_late<lane_of_port(PP)>(dvec, db);
+        } else {
+            dvec = commit_lane<lane_of_port(PP)>(dvec, db, lane);
+            e = fma_(db, acol, e);
+        }
     }
 }
 

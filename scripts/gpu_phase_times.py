@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 from plen_ml_walk_amd.vec_env import PlenVecEnv
 names = ["kinematics", "body_dyn+subtree", "S,M,tau", "cholesky", "v* solve", "collision+J+Y", "A build", "rows setup", "PGS+apply", "integrate"]
-for dtype in (torch.float32,):
+for dtype in (torch.float32, torch.float64):
     for n, air in ((64, False), (64, True), (4096, False)):
         env = PlenVecEnv(n, dtype=dtype); env.reset()
         if air:
