@@ -1,4 +1,4 @@
-"""Profiling build (-DPGS_STAMPS) only: shader-clock stamps inside PGS iterations 3 (odd) and 4 (even)."""
+"""Profiling build (-DPGS_STAMPS) only: shader-clock stamps inside PGS iterations 3 (odd) and 4 (even).  usage: python scripts/gpu_pgs_stamps.py [f32|f64]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,8 +8,9 @@ from plen_ml_walk_amd.build import build_variant
 os.environ["PLENVEC_LIB"] = build_variant("stamps", ["-DPGS_STAMPS"])
 from plen_ml_walk_amd.vec_env import PlenVecEnv
 names = ["motors(+limits)", "normals", "tors bounds", "spin rows", "roll rows", "cone pairs", "wave max"]
+dtype = torch.float64 if len(sys.argv) > 1 and sys.argv[1] == "f64" else torch.float32
 for n in (64, 4096):
-    env = PlenVecEnv(n); env.reset()
+    env = PlenVecEnv(n, dtype=dtype); env.reset()
     tg = torch.zeros(n, 18)
     for _ in range(40): env.debug_substeps(tg, nsub=1, dump=False)     # settle onto the ground
     d = env.debug_substeps(tg, nsub=1, dump=True)
