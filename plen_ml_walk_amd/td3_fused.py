@@ -106,21 +106,31 @@ class FlatAdam(object):
         self.m, self.v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
         self.step_t = torch.zeros((), device=dev, dtype=torch.float32)
         self.done = torch.zeros(1, device=dev, dtype=torch.int32)
-        off, steps = 0, set()
-        for q in _flat_order(module):
-            k = q.numel()
-            mv, vv = self.m[off:off + k].view_as(q), self.v[off:off + k].view_as(q)
-            st = optimizer.state.get(q)
-            if st:                                        # continue the optimiser's history (resumed run)
-                mv.copy_(st["exp_avg"]); vv.copy_(st["exp_avg_sq"]); steps.add(float(st["step"]))
-            optimizer.state[q] = {"step": self.step_t, "exp_avg": mv, "exp_avg_sq": vv}
-            off += k
-        assert off == n and len(steps) <= 1
-        if steps:
-            self.step_t.fill_(steps.pop())
+        self.params = _flat_order(module)
+        self.bind()
         optimizer.step = lambda closure=None: self.step()
 
+    def bind(self):
+        """Take over whatever state the optimiser holds (a fresh one: nothing; a resumed one / after load_state_dict: moments and step count are
+        copied into the flat buffers) and point its state entries at views of the flat buffers."""
+        off, steps = 0, set()
+        for q in self.params:
+            k = q.numel()
+            mv, vv = self.m[off:off + k].view_as(q), self.v[off:off + k].view_as(q)
+            st = self.opt.state.get(q)
+            if st and st["exp_avg"].data_ptr() != mv.data_ptr():
+                mv.copy_(st["exp_avg"]); vv.copy_(st["exp_avg_sq"]); steps.add(float(st["step"]))
+            self.opt.state[q] = {"step": self.step_t, "exp_avg": mv, "exp_avg_sq": vv}
+            off += k
+        assert off == self.p.numel() and len(steps) <= 1
+        if steps:
+            self.step_t.fill_(steps.pop())
+
     def step(self, zero_grad=False, target=None, tau=0.0, copy_out=None):
+        st0 = self.opt.state.get(self.params[0])
+        if (not st0 or st0["exp_avg"].data_ptr() != self.m.data_ptr()) and not torch.cuda.is_current_stream_capturing():
+            self.bind()              # optimizer.load_state_dict() replaced the state tensors: carry them over (a replayed graph never gets here:
+                                     # load checkpoints before the trainers capture their graphs)
         st = C.c_void_p(torch.cuda.current_stream(self.p.device).cuda_stream)
         g = self.opt.param_groups[0]                       # hyper-parameters as they are now (a captured graph keeps the values of its capture)
         _chk(self.lib.plentd3_adam(_p(self.p), _p(self.g), _p(self.m), _p(self.v), _p(self.step_t), _p(self.done), self.p.numel(), float(g["lr"]), float(g["betas"][0]),

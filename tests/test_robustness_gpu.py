@@ -388,6 +388,14 @@ def test_flat_adam_kernel_equals_torch_adam():
     assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(a.abs().max()))
     assert float(new._critic_grads.flat.abs().max()) == 0.0 and float(fz._critic_adam.step_t) == 5.0
     assert torch.allclose(new._critic_target_flat.flat, 0.005 * b + 0.995 * tgt0, atol=1e-7)
+    # a checkpoint loaded into the live optimiser is carried over into the flat buffers at the next step
+    sd = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in new.critic_optimizer.state_dict().items()}
+    sd["state"] = {i: {k: v.clone() for k, v in st.items()} for i, st in new.critic_optimizer.state_dict()["state"].items()}
+    m_before = fz._critic_adam.m.clone()
+    fz._critic_adam.m.zero_(); fz._critic_adam.step_t.fill_(99.0)
+    new.critic_optimizer.load_state_dict(sd)
+    fz._critic_adam.bind()
+    assert torch.equal(fz._critic_adam.m, m_before) and float(fz._critic_adam.step_t) == 5.0
     rs, ns = ref.critic_optimizer.state_dict()["state"], new.critic_optimizer.state_dict()["state"]
     # state entries are indexed by parameter order of module.parameters() in both optimisers
     for i in rs:
