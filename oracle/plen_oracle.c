@@ -36,8 +36,8 @@
  * The 31 box colliders of the other links (plen.urdf:504-1274) collide with the ground too (Bullet:
  * btBoxBoxDetector against plane.urdf's box -> the penetrating corners of the face turned to the
  * ground): a box corner is a contact point while its height is below the link's breaking threshold.
- * The solver has 8 contact-point slots (the HIP kernel's port layout): a foot point always sits in
- * its home slot; box corners, deepest first, take the slots whose foot point is inactive; corners
+ * The solver has 8 contact-point slots (the HIP kernel's port layout): a foot's points take its lowest
+ * slots in diagonal order; box corners, deepest first, take the slots whose foot point is inactive; corners
  * beyond that are dropped (both feet flat AND other links on the ground: see DESIGN.md).
  * Self-collision is off in the reference.
  *
@@ -504,7 +504,7 @@ static void collide(Oracle *o) {
         }
         /* manifold reduction: per sole diagonal k the in-range vertex extreme along it (first in-range entry of the precomputed order);
          * a vertex already chosen for an earlier diagonal is not repeated.  Whole sole in range -> the four corner-most vertices. */
-        int chosen[4] = {-1, -1, -1, -1};
+        int chosen[4] = {-1, -1, -1, -1}, nfoot = 0;     /* the foot's points take its lowest slots, in diagonal order (row order unchanged; as the kernel) */
         for (int k = 0; k < 4; k++) {
             const int *ord = f == 0 ? RAW_RFOOT_SOLE_ORDER[k] : RAW_LFOOT_SOLE_ORDER[k];
             int win = -1;
@@ -512,7 +512,7 @@ static void collide(Oracle *o) {
             for (int k2 = 0; k2 < k; k2++) if (win >= 0 && chosen[k2] == win) win = -1;
             chosen[k] = win;
             if (win < 0) continue;
-            int c = 4 * f + k;
+            int c = 4 * f + nfoot++;
             real dist = wv[win][2] - (real)RAW_MARGIN;
             slot[c].used = 1; slot[c].foot = f; slot[c].link = link; slot[c].box = -1; slot[c].dist = dist;
             v3set(slot[c].pos, wv[win][0], wv[win][1], dist);   /* position on the robot (sphere-swept vertex) */

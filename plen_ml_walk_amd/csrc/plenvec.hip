@@ -302,7 +302,17 @@ __device__ __forceinline__ void for_foot_points(unsigned act, F &&row) {
     static_for<2>([&](auto fc_) {
         constexpr int f = decltype(fc_)::value;
         const unsigned nib = (act >> (4 * f)) & 0xfu;
-        if (nib) static_for<4>([&](auto kc) { if (__builtin_expect((nib & (1u << decltype(kc)::value)) != 0, 1)) row(fc_, kc); });
+        // the occupied slots of a foot are a prefix (phase E packs them): nested tests, a single taken branch ends the foot
+        if (nib & 1u) {
+            row(fc_, std::integral_constant<int, 0>{});
+            if (nib & 2u) {
+                row(fc_, std::integral_constant<int, 1>{});
+                if (nib & 4u) {
+                    row(fc_, std::integral_constant<int, 2>{});
+                    if (nib & 8u) row(fc_, std::integral_constant<int, 3>{});
+                }
+            }
+        }
     });
 }
 
@@ -1245,6 +1255,21 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                     if (!dup) { act |= 1u << (4 * f2 + kk); wp[f2] = (wp[f2] & ~(0xffu << (8 * kk))) | (v << (8 * kk)); }
                 }
             }
+        }
+        // A foot's points are packed into its lowest slots (in diagonal order, so the order of the solver's rows is unchanged): the occupied slots of a
+        // foot are then always a PREFIX -- also after box corners have taken the free slots in slot order -- and the solver's per-point tests
+        // nest (for_foot_points): one taken branch per foot and pass instead of one per empty slot (2.0 -> 0.9 per touching foot in the
+        // benchmark's rollouts, scripts/gpu_slot_distribution.py; a taken scalar branch is ~35-50 cycles of a latency-bound wave).
+#pragma unroll
+        for (int f2 = 0; f2 < 2; f2++) {
+            const unsigned nib = (act >> (4 * f2)) & 0xfu, w = wp[f2];
+            unsigned nw = P.corner_pack[f2];
+            int cnt = 0;
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++)
+                if ((nib >> kk) & 1u) { nw = (nw & ~(0xffu << (8 * cnt))) | (((w >> (8 * kk)) & 0xffu) << (8 * cnt)); cnt++; }
+            wp[f2] = nw;
+            act = (act & ~(0xfu << (4 * f2))) | (((1u << cnt) - 1u) << (4 * f2));
         }
         wpack0 = wp[0]; wpack1 = wp[1];
     }

@@ -233,6 +233,9 @@ def port_jacobians(kin, pos, body_contacts=True):
             if win in chosen:
                 win = None
             chosen.append(win)
+        packed = [w_ for w_ in chosen if w_ is not None]              # the foot's points take its lowest slots, in diagonal order
+        for k in range(4):
+            win = packed[k] if k < len(packed) else None
             foot_active[f, k] = win is not None
             w = wv[win] if win is not None else O[fb] + R[fb] @ FOOT_POINTS[f][k]        # (an unused slot keeps the corner point: its rows do not exist)
             dist[f, k] = w[2] - MARGIN
