@@ -1,5 +1,6 @@
+"""Contact points in range per foot in random-action rollouts of 4096 envs, and the per-point branch count that follows."""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 from plen_ml_walk_amd.vec_env import PlenVecEnv
 n = 4096
