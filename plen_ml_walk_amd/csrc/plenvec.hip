@@ -292,7 +292,9 @@ __device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_in
 // every point is tested: at 4 waves per SIMD the kernel is VALU-issue bound (PMC: one VALU instruction per
 // 4 cycles, ~66% busy), so a taken scalar branch (latency only) is cheaper than a wasted no-op row, and
 // a separate straight-line copy for "all four points in range" only added register spills (measured).
-template <typename F>
+// FEET: which feet are known to touch (bit f), or 0 = test at run time.  The solver picks the copy of its contact section that matches the
+// iteration's touching feet ONCE per iteration, so a foot in the air costs no taken branch in each of the four passes.
+template <int FEET = 0, typename F>
 __device__ __forceinline__ void for_foot_points(unsigned act, F &&row) {
     // `act` is laundered through an empty asm: loop-invariant, the compiler otherwise hoists the eight point tests out of
     // the solver loop as 64-bit lane masks and lays the rows out as two interleaved copies in which a planted foot takes
@@ -301,15 +303,17 @@ __device__ __forceinline__ void for_foot_points(unsigned act, F &&row) {
     asm volatile("" : "+s"(act));
     static_for<2>([&](auto fc_) {
         constexpr int f = decltype(fc_)::value;
-        const unsigned nib = (act >> (4 * f)) & 0xfu;
-        // the occupied slots of a foot are a prefix (phase E packs them): nested tests, a single taken branch ends the foot
-        if (nib & 1u) {
-            row(fc_, std::integral_constant<int, 0>{});
-            if (nib & 2u) {
-                row(fc_, std::integral_constant<int, 1>{});
-                if (nib & 4u) {
-                    row(fc_, std::integral_constant<int, 2>{});
-                    if (nib & 8u) row(fc_, std::integral_constant<int, 3>{});
+        if constexpr (FEET == 0 || ((FEET >> f) & 1)) {
+            const unsigned nib = (act >> (4 * f)) & 0xfu;
+            // the occupied slots of a foot are a prefix (phase E packs them): nested tests, a single taken branch ends the foot
+            if (FEET != 0 || (nib & 1u)) {
+                row(fc_, std::integral_constant<int, 0>{});
+                if (nib & 2u) {
+                    row(fc_, std::integral_constant<int, 1>{});
+                    if (nib & 4u) {
+                        row(fc_, std::integral_constant<int, 2>{});
+                        if (nib & 8u) row(fc_, std::integral_constant<int, 3>{});
+                    }
                 }
             }
         }
@@ -1571,11 +1575,15 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         }
         ISTAMP(1);
         if (act) {     // airborne: one branch skips every contact row
+            // One copy of the contact section per set of touching feet (right, left, both), chosen here once per iteration: inside a copy
+            // no pass has to find out again that a foot is in the air (that was a taken branch per airborne foot in each of the four passes).
+            auto contact_passes = [&](auto feet_c) {
+                constexpr int FEET = decltype(feet_c)::value;
             // Bullet's order is type-major: all normals, all spinning, all rolling, all lateral pairs.  Taken
             // scalar branches cost ~30 cycles each, so inactive points are skipped a whole foot at a time.
             // -- normal rows (manifold order: right foot points, then left foot points) --
             // (points out of range carry blo = bhi = 0 and mu*lambda_n = 0: their rows would be exact no-ops)
-            for_foot_points(act, [&](auto fc_, auto kc) {
+            for_foot_points<FEET>(act, [&](auto fc_, auto kc) {
                 constexpr int PP = port_normal(4 * decltype(fc_)::value + decltype(kc)::value);
                 pgs_row2d<FAST, PP>(e, blo, bhi, dvec, Ar[PP], lane);
             });
@@ -1598,7 +1606,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                 real dv0 = 0, dv1 = 0, dv2 = 0, dv3 = 0;
                 ISTAMP(3);
                 if (has_spin) {
-                    for_foot_points(act, [&](auto fc_, auto kc) {
+                    for_foot_points<FEET>(act, [&](auto fc_, auto kc) {
                         constexpr int k = decltype(kc)::value, PP = 18 + 15 * decltype(fc_)::value;
                         pgs_rowTd<FAST, PP>(e, k == 0 ? nt10 : k == 1 ? nt11 : k == 2 ? nt12 : nt13, k == 0 ? t20 : k == 1 ? t21 : k == 2 ? t22 : t23,
                                             k == 0 ? dv0 : k == 1 ? dv1 : k == 2 ? dv2 : dv3, Ar[PP], lane);
@@ -1606,7 +1614,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                 }
                 ISTAMP(4);
                 if (has_roll) {
-                    for_foot_points(act, [&](auto fc_, auto kc) {
+                    for_foot_points<FEET>(act, [&](auto fc_, auto kc) {
                         constexpr int k = decltype(kc)::value, PP = 18 + 15 * decltype(fc_)::value;
                         pgs_rowTd<FAST, PP + 1>(e, k == 0 ? nt10 : k == 1 ? nt11 : k == 2 ? nt12 : nt13, k == 0 ? t20 : k == 1 ? t21 : k == 2 ? t22 : t23,
                                                 k == 0 ? dv0 : k == 1 ? dv1 : k == 2 ? dv2 : dv3, Ar[PP + 1], lane);
@@ -1622,7 +1630,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             {
                 // mu * lambda_n of each point: from its normal lane (lane 0 of the point's quad) to the whole quad
                 const real lmv = quad_bcast0(mul_rn_(nfcn, blo));
-                for_foot_points(act, [&](auto fc_, auto kc) {
+                for_foot_points<FEET>(act, [&](auto fc_, auto kc) {
                     constexpr int PN = port_normal(4 * decltype(fc_)::value + decltype(kc)::value);
                     pgs_cone<PN>(e, u0, dvec, lmv, jdi, Ar[PN + 1], Ar[PN + 2], lane);
                 });
@@ -1631,6 +1639,11 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             // so one DPP add forms all the sums at once in the A lanes (instead of two VALU ops per pair)
             exceed |= OVER((dvec + shift_down1(dvec)) * selA);
             u0 += dvec; dvec = 0;
+                    };
+            const unsigned a_ = act;
+            if ((a_ & 0xfu) && (a_ & 0xf0u)) contact_passes(std::integral_constant<int, 3>{});
+            else if (a_ & 0xfu) contact_passes(std::integral_constant<int, 1>{});
+            else contact_passes(std::integral_constant<int, 2>{});
         }
         ISTAMP(6);
         ISTAMP(7);
