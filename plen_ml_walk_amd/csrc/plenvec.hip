@@ -1557,14 +1557,14 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         if (it & 1) {
             pgs_motor_pass<FAST, false>(e, blo, bhi, dvec, Ar, lane);
             blo -= dvec; bhi -= dvec; exceed |= OVER(dvec); dvec = 0;
-            if (lim_mask) {
+            if (__builtin_expect(lim_mask != 0, 0)) {      // rare: kept out of the hot loop's instruction stream
                 static_for<ND>([&](auto ic) {
                     constexpr int PP = NC_ORDER[decltype(ic)::value];
                     if (lim_mask & (1u << PP)) pgs_row_signed<PP>(s.lim, e, diag, Ar[PP], lane, res_i);
                 });
             }
         } else {
-            if (lim_mask) {
+            if (__builtin_expect(lim_mask != 0, 0)) {      // rare: kept out of the hot loop's instruction stream
                 static_for<ND>([&](auto ic) {
                     constexpr int PP = NC_ORDER[ND - 1 - decltype(ic)::value];
                     if (lim_mask & (1u << PP)) pgs_row_signed<PP>(s.lim, e, diag, Ar[PP], lane, res_i);
