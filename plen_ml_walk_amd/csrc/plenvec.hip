@@ -677,7 +677,8 @@ __device__ __forceinline__ void pgs_cone(real &e, const real u, real &dvec, cons
         const bool slide = len2 >= lmv * lmv;
         scale = (real)1;
         if (__ballot(slide) & ((1ull << LA) | (1ull << LB))) {
-            scale = slide ? (len2 > 0 ? lmv * rsqrt_(len2) : (real)0) : (real)1;
+            const real t = lmv * rsqrt_(len2);                // for every lane, so that the block is straight-line code (selects, no nested exec regions
+            scale = slide ? (len2 > 0 ? t : (real)0) : (real)1;       // and the scalar registers they hold); len2 == 0 gives NaN here, discarded by the select
         }
 #endif
     }
