@@ -676,7 +676,14 @@ __device__ __forceinline__ void pgs_cone(real &e, const real u, real &dvec, cons
         // lmv * rsqrt_(len2) (v_rsq_f64 and two Newton steps, < 2 ulp of lmv / sqrt(len2); 10 instructions).
         const bool slide = len2 >= lmv * lmv;
         scale = (real)1;
-        if (__ballot(slide) & ((1ull << LA) | (1ull << LB))) {
+        static_assert((LA >> 5) == (LB >> 5), "both lanes of a pair sit in the same half of the wave");
+        // one 32-bit scalar AND on the half of the ballot that holds the pair (written as asm: the compiler turns every C spelling of it back into a
+        // 64-bit test whose constant-zero other half it keeps -- and spills, and reloads -- in a scalar register)
+        const unsigned long long bal = __ballot(slide);
+        const unsigned half = (LA & 32) ? (unsigned)(bal >> 32) : (unsigned)bal;
+        unsigned any_slide;
+        asm("s_and_b32 %0, %1, %2" : "=s"(any_slide) : "s"(half), "n"((1u << (LA & 31)) | (1u << (LB & 31))) : "scc");
+        if (any_slide) {
             const real t = lmv * rsqrt_(len2);                // for every lane, so that the block is straight-line code (selects, no nested exec regions
             scale = slide ? (len2 > 0 ? t : (real)0) : (real)1;       // and the scalar registers they hold); len2 == 0 gives NaN here, discarded by the select
         }
