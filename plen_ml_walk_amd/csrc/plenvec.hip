@@ -261,6 +261,15 @@ __device__ __forceinline__ double dpp64(double x, double old) {
     const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(b >> 32), CTRL, 0xf, 0xf, BOUND_ZERO);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
+// the same for a control under which EVERY lane has a source (quad_perm) or the sourceless lanes get 0 (bound_ctrl): no `old` operand, so no copy of x
+// into the destination before the move (that was two v_mov + a wait state per call)
+template <int CTRL, bool BOUND_ZERO>
+__device__ __forceinline__ double dpp64_all(double x) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffLL), CTRL, 0xf, 0xf, BOUND_ZERO);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xf, 0xf, BOUND_ZERO);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
 // lane i receives x[i-1] (lane 0 keeps its own): one DPP move (two for f64)
 __device__ __forceinline__ float shift_up1(float x) {
     const int b = __builtin_bit_cast(int, x);
@@ -646,14 +655,14 @@ __device__ __forceinline__ void pgs_row_signed(real (&lim)[4][NV], real &e, cons
 // quad exchanges for the contact-point quads (normal, t1, t2, -): partner of the pair (lanes 1 <-> 2 of the quad) and lane 0 to all
 __device__ __forceinline__ float quad_swap12(float x) {
     const int b = __builtin_bit_cast(int, x);
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, 0xD8 /* quad_perm:[0,2,1,3] */, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(b, 0xD8 /* quad_perm:[0,2,1,3] */, 0xf, 0xf, false));      // every lane has a source: no `old` operand to copy
 }
-__device__ __forceinline__ double quad_swap12(double x) { return dpp64<0xD8 /* quad_perm:[0,2,1,3] */, false>(x, x); }
+__device__ __forceinline__ double quad_swap12(double x) { return dpp64_all<0xD8 /* quad_perm:[0,2,1,3] */, false>(x); }
 __device__ __forceinline__ float quad_bcast0(float x) {
     const int b = __builtin_bit_cast(int, x);
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, 0x00 /* quad_perm:[0,0,0,0] */, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(b, 0x00 /* quad_perm:[0,0,0,0] */, 0xf, 0xf, false));
 }
-__device__ __forceinline__ double quad_bcast0(double x) { return dpp64<0x00 /* quad_perm:[0,0,0,0] */, false>(x, x); }
+__device__ __forceinline__ double quad_bcast0(double x) { return dpp64_all<0x00 /* quad_perm:[0,0,0,0] */, false>(x); }
 
 template <int PN, typename real>
 __device__ __forceinline__ void pgs_cone(real &e, const real u, real &dvec, const real lmv, const real jdi, const real aA, const real aB,
@@ -745,10 +754,10 @@ struct Smem {
 // useful work with one level of lanes active at a time).
 template <int S>
 __device__ __forceinline__ float row_shr(float x) {        // lane i <- x[i - S] inside its 16-lane row, 0 shifted in
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x110 + S, 0xf, 0xf, true));
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x110 + S, 0xf, 0xf, true));
 }
 template <int S>
-__device__ __forceinline__ double row_shr(double x) { return dpp64<0x110 + S, true>(x, 0.0); }   // 0 shifted in, like the f32 form
+__device__ __forceinline__ double row_shr(double x) { return dpp64_all<0x110 + S, true>(x); }   // 0 shifted in (bound_ctrl), like the f32 form
 template <typename real>
 __device__ __forceinline__ void prefix3(real *v) {          // inclusive prefix sum along the row, offsets 1, 2, 4 (chains are <= 6 long)
 #pragma unroll
