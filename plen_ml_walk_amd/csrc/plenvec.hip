@@ -246,6 +246,15 @@ __device__ __forceinline__ double wrlane_late(double dst, double val) {
     asm volatile("s_nop 0\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4" : "+v"(lo), "+v"(hi) : "s"(slo), "s"(shi), "i"(L));
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
+// d = clamp(-e, lo, hi) of a solver row.  f64: written as the two instructions it is.  From fmin(fmax(-e, lo), hi) the compiler makes three wherever it
+// cannot prove e free of signalling NaNs (after every asm / scheduling barrier, i.e. in every contact row): a canonicalising v_max_f64 x, x, x first,
+// one more dependent f64 instruction per row of a latency-bound chain (122 of them in the solver loop).
+__device__ __forceinline__ float clamp_neg(float e, float lo, float hi) { return min_(max_(-e, lo), hi); }
+__device__ __forceinline__ double clamp_neg(double e, double lo, double hi) {
+    double d;
+    asm("v_max_f64 %0, -%1, %2\n\tv_min_f64 %0, %0, %3" : "=&v"(d) : "v"(e), "v"(lo), "v"(hi));
+    return d;
+}
 // compiler-path commit of a row's delta into lane L of the per-pass vector: f32 keeps the select (bit-identical to the asm path's
 // v_writelane and what the NO_ASM build is there to check), f64 uses the writelane form above
 template <int L>
@@ -376,7 +385,7 @@ __device__ __forceinline__ void pgs_row2d(real &e, const real blo, const real bh
             : [blo] "v"(blo), [bhi] "v"(bhi), [a] "v"(acol), [pp] "i"(lane_of_port(PP)));
     } else {
 #pragma clang fp contract(off)
-        const real d = min_(max_(-e, blo), bhi);
+        const real d = clamp_neg(e, blo, bhi);
         const real db = bcast(d, lane_of_port(PP));
         if constexpr (sizeof(real) == 8) {
             e = fma_(db, acol, e);
@@ -618,7 +627,7 @@ __device__ __forceinline__ void pgs_rowTd(real &e, const real nt1, const real t2
             : [nt1] "v"(nt1), [t2] "v"(t2), [a] "v"(acol), [pp] "i"(lane_of_port(PP)));
     } else {
 #pragma clang fp contract(off)
-        const real d = min_(max_(-e, nt1), t2);
+        const real d = clamp_neg(e, nt1, t2);
         const real db = bcast(d, lane_of_port(PP));
         if constexpr (sizeof(real) == 8) {
             e = fma_(db, acol, e);
