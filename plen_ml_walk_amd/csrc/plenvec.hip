@@ -255,6 +255,13 @@ __device__ __forceinline__ double clamp_neg(double e, double lo, double hi) {
     asm("v_max_f64 %0, -%1, %2\n\tv_min_f64 %0, %0, %3" : "=&v"(d) : "v"(e), "v"(lo), "v"(hi));
     return d;
 }
+// max(|a|, |b|, |c|, |d|): f64 as three instructions with |.| source modifiers (the compiler canonicalises each fabs() first: seven)
+__device__ __forceinline__ float absmax4(float a, float b, float c, float d) { return max_(max_(abs_(a), abs_(b)), max_(abs_(c), abs_(d))); }
+__device__ __forceinline__ double absmax4(double a, double b, double c, double d) {
+    double x, y;
+    asm("v_max_f64 %0, |%2|, |%3|\n\tv_max_f64 %1, |%4|, |%5|\n\tv_max_f64 %0, %0, %1" : "=&v"(x), "=&v"(y) : "v"(a), "v"(b), "v"(c), "v"(d));
+    return x;
+}
 // compiler-path commit of a row's delta into lane L of the per-pass vector: f32 keeps the select (bit-identical to the asm path's
 // v_writelane and what the NO_ASM build is there to check), f64 uses the writelane form above
 template <int L>
@@ -1649,7 +1656,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                     });
                 }
                 u0 += dv0; u1 += dv1; u2 += dv2; u3 += dv3;
-                exceed |= OVER(max_(max_(abs_(dv0), abs_(dv1)), max_(abs_(dv2), abs_(dv3))));
+                exceed |= OVER(absmax4(dv0, dv1, dv2, dv3));
             }
             ISTAMP(5);
             // -- lateral friction, cone-coupled pairs --
