@@ -303,6 +303,13 @@ __device__ __forceinline__ float gather_lane(float x, int src) {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, x)));
 }
 __device__ __forceinline__ double gather_lane(double x, int src) { return __shfl(x, src); }
+// the same with the byte address (4 x source lane) formed by the caller once, not per call (HIP's __shfl of a double recomputes it for both halves)
+__device__ __forceinline__ float gather_addr(float x, int addr4) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr4, __builtin_bit_cast(int, x))); }
+__device__ __forceinline__ double gather_addr(double x, int addr4) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_ds_bpermute(addr4, (int)(b & 0xffffffffLL)), hi = __builtin_amdgcn_ds_bpermute(addr4, (int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
 
 // all 64 lanes of the single-wave workgroup see each other's LDS writes after this
 #define WSYNC() __syncthreads()
@@ -1565,7 +1572,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         }
     }
     const real selA = (is_lin && pax == 1) ? (real)1 : (real)0;     // 1 in the first lane of every lateral-friction pair
-    const int tors_src = LANE_NORMAL0 + 16 * pf;              // lane of the first normal port of this lane's foot (the next ones: + 4 each)
+    const int tors_addr = 4 * (LANE_NORMAL0 + 16 * pf);       // byte address (LDS crossbar) of the first normal port's lane of this lane's foot; the next ones: + 16 each
     const real nfcn = (is_lin && pax == 0) ? -mu_g * jdi : (real)0;     // lane PN: mu * lambda_n = nfcn * blo
 
     real e = -rv;                  // e = J_port * deltaV - rv
@@ -1629,8 +1636,8 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             // because u_n only changes in the normal pass and uk only at its own row.  Bullet skips the row
             // while the normal impulse is not positive: bounds (0, 0) leave e and uk untouched.
             if (has_spin || has_roll) {
-                const real nbv0 = gather_lane(blo, tors_src), nbv1 = gather_lane(blo, tors_src + 4);
-                const real nbv2 = gather_lane(blo, tors_src + 8), nbv3 = gather_lane(blo, tors_src + 12);     // -u_n of point k of this lane's foot
+                const real nbv0 = gather_addr(blo, tors_addr), nbv1 = gather_addr(blo, tors_addr + 16);
+                const real nbv2 = gather_addr(blo, tors_addr + 32), nbv3 = gather_addr(blo, tors_addr + 48);     // -u_n of point k of this lane's foot
                 const real lim0 = mul_rn_(fc0, nbv0), lim1 = mul_rn_(fc1, nbv1), lim2 = mul_rn_(fc2, nbv2), lim3 = mul_rn_(fc3, nbv3);
                 const real nt10 = nbv0 < 0 ? -(lim0 + u0) : (real)0, nt11 = nbv1 < 0 ? -(lim1 + u1) : (real)0;
                 const real nt12 = nbv2 < 0 ? -(lim2 + u2) : (real)0, nt13 = nbv3 < 0 ? -(lim3 + u3) : (real)0;
