@@ -32,6 +32,8 @@ def _lib(dtype="f64"):
         lib.oracle_set_params.argtypes = [C.c_void_p, C.c_double, C.c_double]
         lib.oracle_set_world.argtypes = [C.c_void_p, C.c_int, C.c_double]
         lib.oracle_set_friction.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+        lib.oracle_set_hyp.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        lib.oracle_set_link_inertia.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double]
         lib.oracle_last_residual.restype = C.c_double
         lib.oracle_last_residual.argtypes = [C.c_void_p]
         lib.oracle_get_state.argtypes = [C.c_void_p, dp]

@@ -209,6 +209,17 @@ typedef struct {
     real angular_damping;    /* 0 */
     real motor_kp, motor_kd; /* PyBullet POSITION_CONTROL defaults 0.1 / 1.0 */
     real motor_max_force;    /* 0.15 (plen_env.py:753) */
+    /* ---- hypothesis switches (scripts/pin/, DESIGN.md "Hypotheses against the PyBullet-held pin"); 0 = the model described above ---- */
+    int manifold_mode;       /* 0: memoryless 8-corner reduction; 1: btPersistentManifold restated (one deepest hull vertex per collision pass,
+                                getCacheEntry / sortCachedPoints / refreshContactPoints, history dependent) */
+    real warmstart;          /* normal impulse of a persisting manifold point carried over, times this factor (Bullet: m_warmstartingFactor) */
+    int pyramid_friction;    /* 1: the two lateral rows solved independently (SOLVER_DISABLE_IMPLICIT_CONE_FRICTION) */
+    int base_gyro_off;       /* 1: no gyroscopic term on the base (btMultiBody::m_useGyroTerm false) */
+    real motor_rhs_clamp;    /* > 0: btMultiBodyJointMotor::m_rhsClamp (the motor's desired velocity clamped to +- this) */
+    real joint_damping;      /* btMultibodyLink::m_jointDamping of every revolute joint (URDF <dynamics damping>; the reference's URDF has none) */
+    int nc_order;            /* 1: motors visited in DoF order instead of btAlignedObjectArray::quickSort's scramble of equal island keys; 2: reverse DoF order */
+    int no_order_flip;       /* 1: the non-contact rows are not reversed on even iterations */
+    int torsional_points;    /* > 0: only the first n points of a manifold get spinning / rolling rows */
 } World;
 
 typedef struct {
@@ -229,6 +240,10 @@ typedef struct {
     int cp_slot[MAXCP], cp_link[MAXCP], cp_box[MAXCP];      /* slot of contact c; link it is on; box index or -1 for a foot point */
     real cp_mu[MAXCP], cp_rest[MAXCP];                      /* combined lateral friction and restitution of contact c */
     int reward_head;                 /* 0: PlenWalkEnv-v1 (plen_env.py), 1: PlenWalkEnv-v0 contract (plen_walk.py:346-396, 597-650) */
+    /* persistent foot manifolds (manifold_mode 1): point on the foot in the foot link frame, its anchor on the ground, carried normal impulse */
+    struct { int n; real lA[4][3], wB[4][3], imp[4]; } man[2];
+    real cp_drift[MAXCP][2];                  /* (posA - posB) along the two friction directions: the friction rows' positional error */
+    real cp_warm[MAXCP]; int cp_man[MAXCP];   /* warm-start impulse of contact c and its manifold entry (-1: none) */
     real foot_force[2][3];           /* contact force on each foot over the last substep (impulses / dt), right then left */
     int right_contact, left_contact;
     int last_iterations; real last_residual;
@@ -324,6 +339,7 @@ static void aba(Oracle *o, real *qdd) {
         IA[21] = IA[28] = IA[35] = o->mass[b];
         real Iom[3], g[3];
         m3mulv(Iom, o->Iw[b], om[b]); v3cross(g, om[b], Iom);
+        if (b == 0 && w->base_gyro_off) v3set(g, 0, 0, 0);
         real wn = v3norm(om[b]), vn = v3norm(vc[b]);
         for (int k = 0; k < 3; k++) {
             p[b][k] = g[k] + Iom[k] * (w->angular_damping + w->angular_damping * wn);
@@ -340,7 +356,7 @@ static void aba(Oracle *o, real *qdd) {
             m6mulv(o->U[b], o->IA[b], o->S[b]);
             real D = v6dot(o->S[b], o->U[b]);
             o->Dinv[b] = 1 / D;
-            real u = -v6dot(o->S[b], p[b]);            /* tau = 0 */
+            real u = -v6dot(o->S[b], p[b]) - w->joint_damping * o->qd[RAW_DOF[i]];   /* tau = 0 (+ joint damping, 0 in the reference) */
             for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) Ia[6 * a + c] -= o->U[b][a] * o->Dinv[b] * o->U[b][c];
             m6mulv(t6, Ia, zeta[b]);
             for (int a = 0; a < 6; a++) pa[a] = p[b][a] + t6[a] + o->U[b][a] * o->Dinv[b] * u;
@@ -363,7 +379,7 @@ static void aba(Oracle *o, real *qdd) {
         real ap[6]; motion_shift(ap, acc[pb], r);
         for (int a = 0; a < 6; a++) ap[a] += zeta[b][a];
         if (RAW_JTYPE[i] == 1) {
-            real u = -v6dot(o->S[b], p[b]);
+            real u = -v6dot(o->S[b], p[b]) - o->w.joint_damping * o->qd[RAW_DOF[i]];
             real qa = o->Dinv[b] * (u - v6dot(o->U[b], ap));
             qdd[6 + RAW_DOF[i]] = qa;
             for (int a = 0; a < 6; a++) acc[b][a] = ap[a] + o->S[b][a] * qa;
@@ -488,9 +504,73 @@ static int cand_less(const BoxCand *a, const BoxCand *b) { return a->dist < b->d
 static void collide(Oracle *o) {
     o->ncp = 0; o->right_contact = 0; o->left_contact = 0;
     int slot_used[MAXCP] = {0};
-    struct { int used, foot, link, box; real pos[3], dist, mu, rest; } slot[MAXCP];
+    struct { int used, foot, link, box, man; real pos[3], dist, mu, rest, warm, drift[2]; } slot[MAXCP];
     memset(slot, 0, sizeof slot);
-    for (int f = 0; f < 2; f++) {
+    for (int c = 0; c < MAXCP; c++) slot[c].man = -1;
+    if (o->w.manifold_mode == 1) for (int f = 0; f < 2; f++) {
+        /* btPersistentManifold restated (foot = body A of its manifold: btCompoundCollisionAlgorithm hands the child hull in first) */
+        int link = f == 0 ? RAW_RFOOT_LINK : RAW_LFOOT_LINK, b = link + 1;
+        const real thr = (real)(f == 0 ? RAW_RFOOT_BREAK : RAW_LFOOT_BREAK), thr2 = thr * thr;
+        const real *R = o->Rw[b], *O = o->Ow[b];
+        /* refreshContactPoints: distance along the normal and drift in the plane, from the stored local points */
+        for (int i = o->man[f].n - 1; i >= 0; i--) {
+            real pa[3]; m3mulv(pa, R, o->man[f].lA[i]); v3add(pa, pa, O);
+            real dist = pa[2] - o->man[f].wB[i][2];
+            real dx = o->man[f].wB[i][0] - pa[0], dy = o->man[f].wB[i][1] - pa[1];
+            if (dist > thr || dx * dx + dy * dy > thr2) {          /* removeContactPoint: the last entry takes its place */
+                int last = --o->man[f].n;
+                if (i != last) { v3cpy(o->man[f].lA[i], o->man[f].lA[last]); v3cpy(o->man[f].wB[i], o->man[f].wB[last]); o->man[f].imp[i] = o->man[f].imp[last]; }
+            }
+        }
+        /* the collision pass's one new point: GJK's closest point = the lowest hull vertex, sphere-swept by the margin */
+        int nh = f == 0 ? RAW_RFOOT_NHULL : RAW_LFOOT_NHULL, low = -1; real lowz = 0, lw[3] = {0, 0, 0};
+        for (int v = 0; v < nh; v++) {
+            const double *pl = f == 0 ? RAW_RFOOT_HULL[v] : RAW_LFOOT_HULL[v];
+            real l[3] = {(real)pl[0], (real)pl[1], (real)pl[2]}, w[3];
+            m3mulv(w, R, l); v3add(w, w, O);
+            if (low < 0 || w[2] < lowz) { low = v; lowz = w[2]; v3cpy(lw, w); }
+        }
+        real depth = lowz - (real)RAW_MARGIN;
+        if (depth <= thr) {
+            real pa[3] = {lw[0], lw[1], depth}, d[3], la[3];
+            v3sub(d, pa, O);
+            for (int k = 0; k < 3; k++) la[k] = R[k] * d[0] + R[3 + k] * d[1] + R[6 + k] * d[2];      /* R^T (pa - O) */
+            int near = -1; real best = thr2;                          /* getCacheEntry */
+            for (int i = 0; i < o->man[f].n; i++) { real e[3]; v3sub(e, o->man[f].lA[i], la); real q = v3dot(e, e); if (q < best) { best = q; near = i; } }
+            int ins;
+            if (near >= 0) ins = near;                                /* replaceContactPoint keeps the applied impulse */
+            else if (o->man[f].n < 4) { ins = o->man[f].n++; o->man[f].imp[ins] = 0; }
+            else {                                                    /* sortCachedPoints (gContactCalcArea3Points), deepest point kept */
+                int deep = -1; real maxpen = depth;
+                for (int i = 0; i < 4; i++) {
+                    real pi[3]; m3mulv(pi, R, o->man[f].lA[i]); v3add(pi, pi, O);
+                    real di = pi[2] - o->man[f].wB[i][2];
+                    if (di < maxpen) { deep = i; maxpen = di; }
+                }
+                real res[4] = {0, 0, 0, 0}, a[3], bb[3], c[3];
+                const real (*P)[3] = o->man[f].lA;
+                if (deep != 0) { v3sub(a, la, P[1]); v3sub(bb, P[3], P[2]); v3cross(c, a, bb); res[0] = v3dot(c, c); }
+                if (deep != 1) { v3sub(a, la, P[0]); v3sub(bb, P[3], P[2]); v3cross(c, a, bb); res[1] = v3dot(c, c); }
+                if (deep != 2) { v3sub(a, la, P[0]); v3sub(bb, P[3], P[1]); v3cross(c, a, bb); res[2] = v3dot(c, c); }
+                if (deep != 3) { v3sub(a, la, P[0]); v3sub(bb, P[2], P[1]); v3cross(c, a, bb); res[3] = v3dot(c, c); }
+                ins = 0; for (int i = 1; i < 4; i++) if (res[i] > res[ins]) ins = i;     /* btVector4::closestAxis4 */
+                o->man[f].imp[ins] = 0;
+            }
+            v3cpy(o->man[f].lA[ins], la); v3set(o->man[f].wB[ins], lw[0], lw[1], 0);
+        }
+        for (int i = 0; i < o->man[f].n; i++) {
+            int c = 4 * f + i;
+            real pa[3]; m3mulv(pa, R, o->man[f].lA[i]); v3add(pa, pa, O);
+            slot[c].used = 1; slot[c].foot = f; slot[c].link = link; slot[c].box = -1; slot[c].dist = pa[2] - o->man[f].wB[i][2];
+            v3cpy(slot[c].pos, pa);
+            slot[c].mu = o->w.lateral_friction; slot[c].rest = o->w.restitution;
+            slot[c].warm = o->man[f].imp[i] * o->w.warmstart; slot[c].man = i;
+            slot[c].drift[0] = -(pa[1] - o->man[f].wB[i][1]); slot[c].drift[1] = pa[0] - o->man[f].wB[i][0];    /* along (0,-1,0) and (1,0,0) */
+            slot_used[c] = 1;
+            if (f == 0) o->right_contact = 1; else o->left_contact = 1;
+        }
+    }
+    else for (int f = 0; f < 2; f++) {
         int link = f == 0 ? RAW_RFOOT_LINK : RAW_LFOOT_LINK, b = link + 1;
         real thr = (real)(f == 0 ? RAW_RFOOT_BREAK : RAW_LFOOT_BREAK);
         /* candidates: the representatives of the sole outline's 8 corner fillets (Bullet's manifold merges points closer than the breaking
@@ -562,6 +642,7 @@ static void collide(Oracle *o) {
         int n = o->ncp++;
         o->cp_slot[n] = c; o->cp_foot[n] = slot[c].foot; o->cp_link[n] = slot[c].link; o->cp_box[n] = slot[c].box;
         o->cp_dist[n] = slot[c].dist; v3cpy(o->cp_pos[n], slot[c].pos); o->cp_mu[n] = slot[c].mu; o->cp_rest[n] = slot[c].rest;
+        o->cp_warm[n] = slot[c].warm; o->cp_man[n] = slot[c].man; o->cp_drift[n][0] = slot[c].drift[0]; o->cp_drift[n][1] = slot[c].drift[1];
     }
 }
 
@@ -588,7 +669,9 @@ static void substep(Oracle *o) {
     Row nc[36], nrm[MAXCP], spin[MAXCP], roll[2 * MAXCP], fric[2 * MAXCP];
     int n_nc = 0, n_n = 0, n_spin = 0, n_roll = 0, n_fric = 0;
     for (int s = 0; s < 36; s++) {
-        int d = RAW_NC_DOF[s], link = RAW_MOVING[d];
+        int d = RAW_NC_DOF[s];
+        if (w->nc_order == 1) d = s % 18; else if (w->nc_order == 2) d = 17 - s % 18;
+        int link = RAW_MOVING[d];
         if (RAW_NC_KIND[s] == 1) {
             /* btMultiBodyJointMotor::createConstraintRows (POSITION_CONTROL, kp 0.1, kd 1, target vel 0) */
             Row *r = &nc[n_nc++];
@@ -596,6 +679,7 @@ static void substep(Oracle *o) {
             real rel = row_finish(o, r, 0);
             real pos_stab = (o->target[d] - o->q[d]) / dt;               /* motor erp = 1 */
             real desired = w->motor_kp * pos_stab + o->qd[d] + w->motor_kd * (0 - o->qd[d]);
+            if (w->motor_rhs_clamp > 0) { if (desired > w->motor_rhs_clamp) desired = w->motor_rhs_clamp; if (desired < -w->motor_rhs_clamp) desired = -w->motor_rhs_clamp; }
             real vel_err = desired - rel;
             r->rhs = vel_err * r->jac_diag_inv; r->cfm = 0;
             r->hi = w->motor_max_force * dt; r->lo = -r->hi;
@@ -634,14 +718,15 @@ static void substep(Oracle *o) {
         r->rhs = pos_err * r->jac_diag_inv + vel_err * r->jac_diag_inv;
         r->cfm = cfm * r->jac_diag_inv; r->lo = 0; r->hi = (real)1e10; r->friction = o->cp_mu[c];
         r->friction_index = n_n;
-        if (is_foot && w->spinning_friction > 0) {      /* spinning / rolling friction is set on the two foot links only (plen_env.py:439-467) */
+        const int tors_ok = !(w->torsional_points > 0 && o->cp_man[c] >= w->torsional_points);
+        if (is_foot && tors_ok && w->spinning_friction > 0) {      /* spinning / rolling friction is set on the two foot links only (plen_env.py:439-467) */
             Row *t = &spin[n_spin++];
             fill_jacobian(o, link, P, nrmW, Z3, t->jac);
             real rv = row_finish(o, t, 0);
             t->rhs = (0 - rv) * t->jac_diag_inv; t->cfm = 0; t->friction = w->spinning_friction; t->friction_index = n_n;
             t->lo = -t->friction; t->hi = t->friction;
         }
-        if (is_foot && w->rolling_friction > 0) {
+        if (is_foot && tors_ok && w->rolling_friction > 0) {
             for (int a = 0; a < 2; a++) {
                 Row *t = &roll[n_roll++];
                 fill_jacobian(o, link, P, a == 0 ? dir1 : dir2, Z3, t->jac);
@@ -653,8 +738,9 @@ static void substep(Oracle *o) {
         for (int a = 0; a < 2; a++) {
             Row *t = &fric[n_fric++];
             fill_jacobian(o, link, P, Z3, a == 0 ? dir1 : dir2, t->jac);
-            real rv = row_finish(o, t, 0);         /* frictionCFM = 0; friction positional error = 0 */
-            t->rhs = (0 - rv) * t->jac_diag_inv; t->cfm = 0; t->friction = o->cp_mu[c]; t->friction_index = n_n;
+            real rv = row_finish(o, t, 0);         /* frictionCFM = 0; positional error = drift from the manifold point's anchor x frictionERP (persistent manifolds only) */
+            real perr = w->manifold_mode == 1 ? -o->cp_drift[c][a] * w->friction_erp / dt : 0;
+            t->rhs = (perr + (0 - rv)) * t->jac_diag_inv; t->cfm = 0; t->friction = o->cp_mu[c]; t->friction_index = n_n;
             t->lo = -t->friction; t->hi = t->friction;
         }
         n_n++;
@@ -662,11 +748,15 @@ static void substep(Oracle *o) {
 
     /* ---- solveGroupCacheFriendlyIterations ---- */
     real dv[NV]; memset(dv, 0, sizeof dv);
+    if (w->warmstart > 0) for (int j = 0; j < n_n; j++) if (o->cp_warm[j] > 0) {     /* setupMultiBodyContactConstraint: warm starting */
+        nrm[j].applied = o->cp_warm[j];
+        for (int k = 0; k < NV; k++) dv[k] += nrm[j].delta[k] * o->cp_warm[j];
+    }
     int it; real residual = 0;
     for (it = 0; it < w->num_iterations; it++) {
         residual = 0;
         for (int j = 0; j < n_nc; j++) {
-            int idx = (it & 1) ? j : n_nc - 1 - j;
+            int idx = ((it & 1) || w->no_order_flip) ? j : n_nc - 1 - j;
             real r = resolve_row(&nc[idx], dv); if (r * r > residual) residual = r * r;
         }
         for (int j = 0; j < n_n; j++) { real r = resolve_row(&nrm[j], dv); if (r * r > residual) residual = r * r; }
@@ -684,11 +774,15 @@ static void substep(Oracle *o) {
             real tot = nrm[fric[j].friction_index].applied;
             fric[j].lo = -fric[j].friction * tot; fric[j].hi = fric[j].friction * tot;
             fric[j + 1].lo = fric[j].lo; fric[j + 1].hi = fric[j].hi;
-            real r = resolve_cone(&fric[j], &fric[j + 1], dv); if (r * r > residual) residual = r * r;
+            if (w->pyramid_friction) {
+                if (tot > 0) for (int a = 0; a < 2; a++) { real r = resolve_row(&fric[j + a], dv); if (r * r > residual) residual = r * r; }
+            } else { real r = resolve_cone(&fric[j], &fric[j + 1], dv); if (r * r > residual) residual = r * r; }
         }
         if (residual <= w->residual_threshold || it >= w->num_iterations - 1) { it++; break; }
     }
     o->last_iterations = it; o->last_residual = residual;
+    if (w->manifold_mode == 1) for (int c = 0; c < o->ncp; c++) if (o->cp_foot[c] >= 0 && o->cp_man[c] >= 0)
+        o->man[o->cp_foot[c]].imp[o->cp_man[c]] = nrm[c].applied;               /* solveGroupCacheFriendlyFinish: pt->m_appliedImpulse */
     /* contact force per foot (what a Gazebo bumper reports): normal + lateral impulses of its points / dt */
     memset(o->foot_force, 0, sizeof o->foot_force);
     for (int c = 0; c < o->ncp; c++) {
@@ -881,6 +975,34 @@ API void oracle_set_params(Oracle *o, double mass_scale, double lateral_friction
     for (int i = 0; i < NL; i++) { o->mass[i + 1] = (real)(RAW_MASS[i] * mass_scale); for (int k = 0; k < 3; k++) o->inertia[i + 1][k] = (real)(RAW_INERTIA[i][k] * mass_scale); }
     if (lateral_friction >= 0) o->w.lateral_friction = (real)lateral_friction;
 }
+/* hypothesis sweeps (scripts/pin/): any World scalar by key, any link's inertia diagonal */
+API int oracle_set_hyp(Oracle *o, int key, double v) {
+    World *w = &o->w;
+    switch (key) {
+    case 0: w->erp = (real)v; break;            case 1: w->erp2 = (real)v; break;
+    case 2: w->friction_erp = (real)v; break;   case 3: w->global_cfm = (real)v; break;
+    case 4: w->linear_slop = (real)v; break;    case 5: w->residual_threshold = (real)v; break;
+    case 6: w->restitution_velocity_threshold = (real)v; break;
+    case 7: w->max_coordinate_velocity = (real)v; break;
+    case 8: w->lateral_friction = (real)v; break;  case 9: w->box_lateral_friction = (real)v; break;
+    case 10: w->spinning_friction = (real)v; break; case 11: w->rolling_friction = (real)v; break;
+    case 12: w->restitution = (real)v; break;   case 13: w->linear_damping = (real)v; break;
+    case 14: w->angular_damping = (real)v; break; case 15: w->motor_kp = (real)v; break;
+    case 16: w->motor_kd = (real)v; break;      case 17: w->motor_max_force = (real)v; break;
+    case 18: w->num_iterations = (int)v; break; case 19: w->body_contacts = (int)v; break;
+    case 20: w->dt = (real)v; break;
+    case 21: w->manifold_mode = (int)v; break;  case 22: w->warmstart = (real)v; break;
+    case 23: w->pyramid_friction = (int)v; break; case 24: w->base_gyro_off = (int)v; break;
+    case 25: w->torsional_points = (int)v; break;
+    case 28: w->nc_order = (int)v; break; case 29: w->no_order_flip = (int)v; break;
+    case 26: w->motor_rhs_clamp = (real)v; break; case 27: w->joint_damping = (real)v; break;
+    default: return -1;
+    }
+    return 0;
+}
+API void oracle_set_link_inertia(Oracle *o, int b, double ixx, double iyy, double izz) {   /* b = 0 base, i + 1 link i */
+    o->inertia[b][0] = (real)ixx; o->inertia[b][1] = (real)iyy; o->inertia[b][2] = (real)izz;
+}
 API void oracle_set_world(Oracle *o, int num_iterations, double residual_threshold) {
     if (num_iterations > 0) o->w.num_iterations = num_iterations;
     if (residual_threshold >= 0) o->w.residual_threshold = (real)residual_threshold;
@@ -965,6 +1087,7 @@ API void oracle_reset(Oracle *o, double *obs_out) {
     o->base_quat[0] = o->base_quat[1] = o->base_quat[2] = 0; o->base_quat[3] = 1;
     v3set(o->base_omega, 0, 0, 0); v3set(o->base_vel, 0, 0, 0);
     for (int d = 0; d < ND; d++) { o->q[d] = 0; o->qd[d] = 0; o->target[d] = 0; }
+    o->man[0].n = o->man[1].n = 0;            /* the teleport moves every cached point beyond its breaking threshold */
     for (int i = 0; i < 8; i++) substep(o);                 /* 2 * sim_stepsize */
     real obs[26]; fk(o); compute_observation(o, obs);
     o->episode_timestep = 0;

@@ -1,0 +1,51 @@
+"""The HIP kernel against the PyBullet-held pin (tests/pybullet_pin.py), through the C ABI: the same reset / one-step / short-horizon
+residuals as the oracle's (tests/test_pybullet_pin.py), so the kernel itself -- not only its checker -- is held to PyBullet's data."""
+import numpy as np
+import pytest
+import torch
+import pybullet_pin as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _kernel_residuals(dtype, K=8, n=4, cfg=None):
+    from plen_ml_walk_amd.vec_env import PlenVecEnv
+    env = PlenVecEnv(n, device="cuda:0", dtype=dtype, auto_reset=False, cfg_overrides=cfg)
+
+    def reset():
+        return env.reset()[0].cpu().numpy().astype(np.float64)
+
+    def step(a):
+        act = torch.from_numpy(np.tile(np.asarray(a, dtype=np.float32), (n, 1))).cuda()
+        obs, _, done, _ = env.step(act)
+        o = obs.cpu().numpy().astype(np.float64)
+        assert np.array_equal(o[0], o[n - 1])                    # identical envs, identical results
+        return o[0], bool(done[0].item() & 1)
+    R, seq = P.residuals(reset, step, K)
+    env.close()
+    return R, seq
+
+
+def test_f64_kernel_meets_the_pybullet_pin():
+    R, seq = _kernel_residuals(torch.float64)
+    Ro, seqo = P.oracle_residuals(K=8)
+    assert R[0] < 0.015 and R[1] < 0.22 and np.nansum(R[1:5]) < 1.0, R
+    # and it is the oracle's trajectory: the first control steps agree to rounding, so the ablation's verdicts carry over to the kernel
+    assert np.abs(seq[0] - seqo[0]).max() < 1e-9 and np.abs(seq[1] - seqo[1]).max() < 1e-7, (np.abs(seq[:3] - seqo[:3]).max(1))
+    assert abs(R[0] - Ro[0]) < 1e-6 and abs(R[1] - Ro[1]) < 1e-4
+    d = P.min_norm_obs_correction(seq[0], 0)
+    assert np.abs(d[:18]).max() < 1e-3 and np.abs(d[20:23]).max() < 5e-4
+
+
+def test_f32_kernel_meets_the_reset_pin():
+    R, _ = _kernel_residuals(torch.float32, K=4)
+    assert R[0] < 0.02 and R[1] < 0.3, R
+
+
+def test_pin_discriminates_through_the_kernel():
+    """Two of the ablation's verdicts re-measured on the kernel itself (cfg fields of the C ABI): 49 iterations and erp2 0.04 move the
+    reset stance away from PyBullet's."""
+    base = _kernel_residuals(torch.float64, K=0)[0][0]
+    assert _kernel_residuals(torch.float64, K=0, cfg=dict(num_iterations=49))[0][0] > 2.5 * base
+    assert _kernel_residuals(torch.float64, K=0, cfg=dict(erp2=0.04))[0][0] > 3.0 * base
+    assert _kernel_residuals(torch.float64, K=1, cfg=dict(motor_kp=0.2))[0][1] > 3.0 * _kernel_residuals(torch.float64, K=1)[0][1]

@@ -1,0 +1,77 @@
+"""The physics oracle against the PyBullet-held pin (tests/pybullet_pin.py): the reference's recorded command log is the shipped
+actor's deterministic output along a PyBullet episode, so it constrains PyBullet's own observations.  These tests pin the ORACLE (CPU);
+tests/test_pin_gpu.py holds the HIP kernel to the same numbers through the C ABI."""
+import numpy as np
+import pytest
+import pybullet_pin as P
+from oracle.oracle import OracleEnv
+
+
+def test_command_log_starts_at_this_reset_observation():
+    """a_0 = actor_3229999(reset observation): reproduced from the oracle's reset (8 settle substeps from the spawn pose) to 0.03 in action
+    space / 0.015 rms pre-tanh -- observation errors of ~1e-4 -- and only with PyBullet's contact flags being (right 0, left 1)."""
+    obs0 = OracleEnv().reset()
+    a0 = np.tanh(P.pre(obs0))
+    assert np.abs(a0 - P.ACTS[0]).max() < 0.03
+    assert P.residual(obs0, 0) < 0.015
+    for rc, lc in ((1, 1), (0, 0), (1, 0)):
+        x = obs0.copy(); x[24] = rc; x[25] = lc
+        assert P.residual(x, 0) > 0.5, (rc, lc)
+    d = P.min_norm_obs_correction(obs0, 0)
+    assert np.abs(d[:18]).max() < 1e-3 and abs(d[18]) < 1e-4 and abs(d[19]) < 3e-3 and np.abs(d[20:23]).max() < 5e-4
+
+
+def test_one_step_and_short_horizon_pin():
+    """One control step under the log's full-range first command, then the accumulated open-loop trajectory: measured 0.183 / 0.167 / 0.181 /
+    0.241 (R_1..R_4), i.e. observation errors of a few 1e-3 after the first step.  The bounds leave room for rounding-level reshuffles of the
+    chaotic part only."""
+    R, seq = P.oracle_residuals(K=8)
+    assert R[1] < 0.22 and np.nansum(R[1:5]) < 1.0, R
+    assert np.all(np.isfinite(R[:9])) and R[8] < 2.5
+    # PyBullet's contact flags, decodable while the trajectories are close, equal the oracle's for the first 8 steps
+    for t in range(9):
+        best = min(((P.residual(np.r_[seq[t][:24], rc, lc], t), rc, lc) for rc in (0, 1) for lc in (0, 1)))
+        assert (best[1], best[2]) == (int(seq[t][24]), int(seq[t][25])), (t, best)
+
+
+@pytest.mark.parametrize("name,kw,factor", [
+    ("50 solver iterations, not 49", dict(hyp=dict(iters=49)), 2.5),
+    ("50 solver iterations, not 51", dict(hyp=dict(iters=51)), 2.5),
+    ("motor rows in btAlignedObjectArray::quickSort's order", dict(hyp=dict(nc_order=1)), 3.0),
+    ("non-contact rows reversed on even iterations", dict(hyp=dict(no_flip=1)), 3.0),
+    ("contact erp2 0.08, not 0.04", dict(hyp=dict(erp2=0.04)), 3.0),
+    ("contact erp2 0.08, not 0.2", dict(hyp=dict(erp2=0.2)), 3.0),
+    ("inertia from the collision shapes, not the URDF's <inertia>", dict(urdf_inertia=True), 2.5),
+    ("motor kd 1.0, not 0.5", dict(hyp=dict(kd=0.5)), 3.0),
+    ("rolling friction rows exist", dict(hyp=dict(roll=0.0)), 3.0),
+    ("no warm starting", dict(hyp=dict(manifold=1, warm=1.0)), 10.0),
+])
+def test_reset_pin_discriminates_bullet_hypotheses(name, kw, factor):
+    """profiles/r03_hypothesis_ablation.json in test form: each alternative to a DESIGN.md section 2 hypothesis moves the reset stance away
+    from PyBullet's by the stated factor in R_0 (baseline 0.0095)."""
+    base = P.oracle_residuals(K=0)[0][0]
+    alt = P.oracle_residuals(K=0, **kw)[0][0]
+    assert alt > factor * base, (name, base, alt)
+
+
+@pytest.mark.parametrize("name,hyp,factor", [
+    ("motor kp 0.1, not 0.05", dict(kp=0.05), 3.0), ("motor kp 0.1, not 0.2", dict(kp=0.2), 3.0),
+    ("motor impulse clamp 0.15 dt, not 0.1 dt", dict(max_force=0.1), 2.5), ("motor impulse clamp 0.15 dt, not 0.3 dt", dict(max_force=0.3), 2.5),
+    ("no 8 rad/s velocity clamp from the URDF", dict(rhs_clamp=8.0), 4.0), ("spinning friction rows exist", dict(spin=0.0), 3.0),
+])
+def test_one_step_pin_discriminates_motor_hypotheses(name, hyp, factor):
+    base = P.oracle_residuals(K=1)[0][1]
+    alt = P.oracle_residuals(K=1, hyp=hyp)[0][1]
+    assert alt > factor * base, (name, base, alt)
+
+
+def test_stance_is_nearly_a_fixed_point_at_init_height():
+    """`init_height = 0.160178937611  # measured in bullet` (plen_env.py:70): two seconds of the zero-pose stance end 0.07 mm below it and
+    drift 0.09 mm over the last second."""
+    e = OracleEnv(); e.reset()
+    s = np.zeros(49); s[2] = 0.158; s[6] = 1.0
+    e.set_state(s); e.set_targets(np.zeros(18))
+    z = []
+    for _ in range(480):
+        e.substep(); z.append(e.get_state()[2])
+    assert abs(z[479] - 0.160178937611) < 2e-4 and abs(z[479] - z[239]) < 2e-4, (z[239], z[479])

@@ -135,7 +135,10 @@ def main():
         # child transform relative to the inertial frame (inertial rotation is identity)
         rel_t = ct - com
         rel_identity = bool(np.all(rel_t == 0) and np.all(cR == np.eye(3)))
-        out = dict(name=name, mass=mass, com=com.tolist())
+        iu = ine.find("inertia")
+        assert all(float(iu.get(k)) == 0 for k in ("ixy", "ixz", "iyz")), "URDF inertia tensors are diagonal in this URDF"
+        # kept only for the hypothesis ablation (scripts/pin/): what URDF_USE_INERTIA_FROM_FILE would have used
+        out = dict(name=name, mass=mass, com=com.tolist(), inertia_urdf=[float(iu.get(k)) for k in ("ixx", "iyy", "izz")])
         if g.tag == "box":
             size = f3(g.get("size"))
             half = 0.5 * size

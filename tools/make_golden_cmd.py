@@ -15,3 +15,19 @@ acts = np.stack([np.load(os.path.join(REF, "plen_bullet/trajectories", j + "_cmd
 assert acts.shape == (500, 18) and np.abs(acts).max() <= 1.0
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "policy_cmd_sequence.npz"), actions=acts, joint_names=np.array(JOINT_NAMES))
 print("policy_cmd_sequence.npz", acts.shape, acts.dtype, float(acts.min()), float(acts.max()))
+
+# ---- which of the shipped actors produced the log?  (walk_eval.py:48-54 loads 3229999; verified, not assumed)
+# The first recorded action must be actor(reset observation).  Needs torch + the oracle's reset observation (test infrastructure).
+try:
+    import torch
+    from oracle.oracle import OracleEnv
+    obs0 = OracleEnv().reset()
+    print("actor identification: max |actor_k(reset obs) - a_0| over the 18 channels")
+    for k in (3189999, 3199999, 3209999, 3219999, 3229999, 3239999, 3249999):
+        sd = torch.load(os.path.join(REF, "plen_bullet/models/plen_walk_gazebo_%d_actor" % k), map_location="cpu", weights_only=True)
+        sd = {n: v.numpy().astype(np.float64) for n, v in sd.items()}
+        h = np.maximum(sd["fc1.weight"] @ obs0 + sd["fc1.bias"], 0); h = np.maximum(sd["fc2.weight"] @ h + sd["fc2.bias"], 0)
+        a0 = np.tanh(sd["fc3.weight"] @ h + sd["fc3.bias"])
+        print("   %d  %.4f" % (k, np.abs(a0 - acts[0]).max()))
+except Exception as e:            # the fixture above does not depend on this
+    print("actor identification skipped:", e)
