@@ -34,6 +34,7 @@ if ROOT not in sys.path:
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")        # before the HIP runtime initialises: see plen_ml_walk_amd/__init__.py
 
 ENVS_PER_GPU = 4096
+MIN_TIMED_S = 0.25                     # the timed block is repeated until this much timed work has accumulated (VERDICT r02 weak point 6)
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # Measured chip-wide wave64 vector-instruction issue rates (profiles/r02_valu_issue.json, scripts/ubench/valu_issue.hip, 8 waves per
 # SIMD on all 1024 SIMDs), in G wave-instructions/s.  The guide's nominal 2-cycle wave64 rate (1228.8 G/s at 2.4 GHz) is approached
@@ -97,6 +98,70 @@ def pybullet_status():
         return {"available": True, "error": "harness failed: %r" % (ex,)}
 
 
+# ------------------------------------------------------------------------------------------------ parity (rank 0, N = 1, outside every timed region)
+def obs_err_vs_oracle(dev, envs=64, steps=64):
+    """SURVEY 8(d) Config 2: "obs parity checked on env 0..63 for the first 64 steps against the CPU restatement (f64) with identical actions".
+    The oracle is the CHECKER here (never timed, never on the product path).  Two configurations: the reference's, whose solver iteration
+    amplifies rounding differences between any two implementations within a few steps, and the same with rolling
+    friction off, where kernel and oracle stay at rounding level for the whole rollout."""
+    import numpy as np
+    import torch
+    from plen_ml_walk_amd.vec_env import PlenVecEnv
+    from oracle import oracle as O
+    g = torch.Generator(device=dev).manual_seed(0)
+    actions = torch.rand(steps, envs, 18, generator=g, device=dev, dtype=torch.float32) * 2 - 1
+    out = {"envs": envs, "steps": steps, "dtype": "f64", "actions": "U[-1,1] from torch.Generator(device).manual_seed(0), identical for kernel and oracle; auto-reset on"}
+    for name, rolling in (("reference_config", None), ("rolling_friction_off", 0.0)):
+        env = PlenVecEnv(envs, device=dev, dtype=torch.float64, cfg_overrides=None if rolling is None else {"rolling_friction": rolling})
+        env.reset()
+        obs, rew, flg = [], [], []
+        for t in range(steps):
+            o, r, d, _ = env.step(actions[t])
+            obs.append(o.cpu().numpy().copy()); rew.append(r.cpu().numpy().copy()); flg.append(d.cpu().numpy().copy())
+        env.close()
+        obs, rew, flg = np.array(obs), np.array(rew), np.array(flg)
+        oo, orw, ofl = O.batch_rollout(actions.cpu().numpy(), rolling=-1.0 if rolling is None else rolling)
+        err = np.abs(obs - oo).max(axis=2)                       # [steps, envs]: max over the 26 observation entries
+        # once an env's done flags differ the two rollouts are in different episodes: compare up to and including that step
+        same = np.cumsum((flg & 3) != (ofl & 3), axis=0) == 0
+        valid = np.vstack([np.ones((1, envs), bool), same[:-1]])
+        e = err[valid]
+        per_step_median = [float(np.median(err[t][valid[t]])) if valid[t].any() else None for t in (0, 1, 3, 7, 15, 31, 63) if t < steps]
+        out[name] = {"median": float(np.median(e)), "p90": float(np.percentile(e, 90)), "max": float(e.max()), "frac_le_1e-4": float((e <= 1e-4).mean()),
+                     "first_step": {"median": float(np.median(err[0])), "max": float(err[0].max()), "frac_le_1e-4": float((err[0] <= 1e-4).mean())},
+                     "median_at_step_1_2_4_8_16_32_64": per_step_median,
+                     "flags_equal": float(((flg & 3) == (ofl & 3))[valid].mean()), "contact_flags_equal": float((obs[..., 24:26] == oo[..., 24:26])[valid].mean()),
+                     "reward_max_err_first_step": float(np.abs(rew[0] - orw[0]).max()), "compared_env_steps": int(valid.sum())}
+    return out
+
+
+def pybullet_pin(dev):
+    """obs error against PyBullet ITSELF, as far as the reference holds it: the recorded command log is the shipped actor's output along a PyBullet
+    episode (tests/pybullet_pin.py), so it constrains PyBullet's observations.  R_t = rms pre-tanh residual of the f64 KERNEL's observation
+    after replaying t recorded commands; min_norm_obs_correction = the smallest change of the kernel's reset observation that reproduces
+    PyBullet's first recorded action exactly (a lower bound on its distance from PyBullet's reset observation)."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import pybullet_pin as P
+    from plen_ml_walk_amd.vec_env import PlenVecEnv
+    env = PlenVecEnv(2, device=dev, dtype=torch.float64, auto_reset=False)
+
+    def step(a):
+        o, _, d, _ = env.step(torch.from_numpy(np.tile(np.asarray(a, dtype=np.float32), (2, 1))).to(dev))
+        return o[0].cpu().numpy(), bool(d[0].item() & 1)
+    R, seq = P.residuals(lambda: env.reset()[0].cpu().numpy(), step, 8)
+    env.close()
+    d = P.min_norm_obs_correction(seq[0], 0)
+    a0 = np.tanh(P.pre(seq[0]))
+    return {"source": "tests/golden/policy_cmd_sequence.npz (plen_bullet/trajectories/*_cmd.npy) through tests/golden/policy_3229999.npz",
+            "R": [round(float(x), 5) for x in R], "max_abs_action_err_step0": float(np.abs(a0 - P.ACTS[0]).max()),
+            "reset_obs_min_norm_correction": {"joints_max_rad": float(np.abs(d[:18]).max()), "z_m": float(d[18]), "vx_m_s": float(d[19]),
+                                              "roll_pitch_yaw_max_rad": float(np.abs(d[20:23]).max()), "y_m": float(d[23])},
+            "note": "R = 0.01 corresponds to observation errors of 1e-4..1e-3 (actor Jacobian column norms 7..180); R_0 pins the reset stance, R_1 one control "
+                    "step; profiles/r03_hypothesis_ablation.json shows what each Bullet hypothesis does to them"}
+
+
 # ------------------------------------------------------------------------------------------------ multi-GPU self launch
 def spawn_ranks(argv, n):
     """`python bench.py --gpus N` from a plain shell: start N ranks as child processes through torch.distributed.run (this parent never
@@ -143,16 +208,29 @@ def env_leg(a, dtype_name, dev, rank, world, dist, steps, warmup, dr=None):
         env.step_async(actions[t % ring])
     env.sync()
     barrier()
-    with torch.cuda.stream(env.streams[0]):          # HIP events on the stream the dominant kernel is launched on (sub-batch 0)
-        env.envs[0].timing_begin()
-    t0 = time.perf_counter()
-    for t in range(steps):
-        env.step_async(actions[(warmup + t) % ring])
-    with torch.cuda.stream(env.streams[0]):
-        kernel_ms, launches = env.envs[0].timing_end()
-    env.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # EXACTLY `steps` vector steps per timed block, barrier + synchronize on both sides; the block is repeated until MIN_TIMED_S of
+    # timed work has accumulated (20 steps of this workload last 16 ms) and every block is reported: value = all timed env-steps / all
+    # timed seconds.  The decision to run another block is taken from rank 0's clock so that all ranks run the same number.
+    block_s, kernel_ms, launches, tcur = [], 0.0, 0, warmup
+    while True:
+        with torch.cuda.stream(env.streams[0]):          # HIP events on the stream the dominant kernel is launched on (sub-batch 0)
+            env.envs[0].timing_begin()
+        t0 = time.perf_counter()
+        for t in range(steps):
+            env.step_async(actions[(tcur + t) % ring])
+        with torch.cuda.stream(env.streams[0]):
+            km, ln = env.envs[0].timing_end()
+        env.sync()
+        barrier()
+        block_s.append(time.perf_counter() - t0)
+        kernel_ms += km; launches += ln; tcur += steps
+        more = torch.tensor([1.0 if (sum(block_s) < MIN_TIMED_S and len(block_s) < 1000) else 0.0], device=dev)
+        if world > 1:
+            dist.broadcast(more, 0)
+        if more.item() == 0.0:
+            break
+    blocks = len(block_s)
+    elapsed = sum(block_s) / blocks                      # mean seconds per block of `steps` steps
     nonfinite = int(env.nonfinite_count())          # PLENVEC_DONE_NONFINITE events of this rank during warm-up + timed steps
     env.close()
     # the same workload as ONE launch of all envs per step: the mode in which the dominant kernel's own duration is well defined
@@ -181,6 +259,7 @@ def env_leg(a, dtype_name, dev, rank, world, dist, steps, warmup, dr=None):
         env1.close()
     # the slowest rank defines every time (sharding.max_over_ranks is the identity for one rank)
     elapsed = sharding.max_over_ranks(elapsed, dev)
+    block_ms = [sharding.max_over_ranks(b, dev) * 1e3 for b in block_s] if world > 1 else [b * 1e3 for b in block_s]
     slot_ms = sharding.max_over_ranks(kernel_ms / max(launches, 1), dev)
     if single is not None:
         single = sharding.max_over_ranks(single, dev)
@@ -206,6 +285,10 @@ def env_leg(a, dtype_name, dev, rank, world, dist, steps, warmup, dr=None):
                 "waves_per_simd": wps, "class_rates_measured": VALU_CLASS_GINST_S, "source": pmc_file, "rates_source": "profiles/r02_valu_issue.json"}
     return {
         "value": value, "unit": "env-steps/s", "dtype": dtype_name, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "timed_region": {"steps_per_block": steps, "blocks": blocks, "seconds_total": sum(block_ms) / 1e3, "min_seconds": MIN_TIMED_S,
+                         "block_ms_min": min(block_ms), "block_ms_max": max(block_ms), "first_block_ms": block_ms[0],
+                         "note": "each block is exactly `steps` vector steps between barrier + synchronize; repeated until min_seconds of timed work; "
+                                 "value = env-steps of all blocks / their summed time"},
         "sub_batches": "%d x %d envs per GPU on %d HIP streams: every env advances one control step per bench step, sub-batches are not "
                        "synchronised with each other between steps (PlenVecEnvPipelined); --groups 1 = one launch per step" % (groups, n_sub, groups),
         "one_launch_per_step": None if single is None else {"ms_per_step": single * 1e3, "value": world * n / single},
@@ -308,6 +391,9 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f32", "f64"], help="arithmetic of the headline leg (f64 = the reference's)")
     ap.add_argument("--legs", default="f64,f32,td3,dr", help="comma list of legs to run besides the headline one (f64, f32, td3, dr)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the obs_err_vs_oracle / pybullet_pin blocks (outside the timed regions, rank 0, N = 1)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: --envs-per-gpu envs on every rank; strong: --envs-per-gpu envs in "
+                    "TOTAL, split over the ranks (the metric's literal '@4096 envs', SURVEY 8(d) Config 4)")
     ap.add_argument("--dr", action="store_true", help="BASELINE.json configs[4]: per-env link-mass scale U[0.8,1.2] and foot friction U[0.4,1.0], seed 1000+rank")
     ap.add_argument("--groups", type=int, default=0, help="independent sub-batches per GPU, one HIP stream each (1 = a single launch per step; "
                     "0 = the measured best: 2 for f32 (4 waves per SIMD: 2 x 2048 envs fill the chip), 4 for f64 (2 waves per SIMD))")
@@ -340,6 +426,11 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    total_envs_strong = a.envs_per_gpu
+    if a.scaling == "strong":
+        if a.envs_per_gpu % world:
+            raise SystemExit("--scaling strong needs --envs-per-gpu divisible by the number of ranks")
+        a.envs_per_gpu //= world
     legs_wanted = [x for x in a.legs.split(",") if x]
     head = env_leg(a, a.dtype, dev, rank, world, dist, a.steps, a.warmup)
     legs = {}
@@ -363,7 +454,7 @@ def main():
         n = a.envs_per_gpu
         out = {
             "metric": "env-steps/sec @4096 envs", "value": head["value"], "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[%d]: %d vectorised PLEN envs per MI355X%s, random-action rollout, auto-reset (done or 500-step limit), "
                                    "4 x 240 Hz substeps per 60 Hz step, %s arithmetic" % (4 if a.dr else 1, n, ", per-env domain randomisation (mass x U[0.8,1.2], friction U[0.4,1.0])" if a.dr else "",
@@ -371,12 +462,18 @@ def main():
                        "envs_per_gpu": n, "total_envs": world * n, "substeps": 4, "solver_iterations": 50, "sub_batches": head["sub_batches"],
                        "one_launch_per_step": head["one_launch_per_step"],
                        "parallelism": "env-sharded, %d rank(s), no data-path collective in the env step" % world},
-            "roofline": head["roofline"],
+            "roofline": head["roofline"], "timed_region": head["timed_region"],
             "kernel_ms_per_launch": head["kernel_ms_per_launch"], "pipelined_ms_per_launch_slot": head["pipelined_ms_per_launch_slot"],
             "nonfinite_resets": head["nonfinite_resets"],
             "legs": legs,
             "pybullet": pybullet_status(),
         }
+        if world == 1 and not a.no_parity:
+            for key, fn in (("obs_err_vs_oracle", obs_err_vs_oracle), ("pybullet_pin", pybullet_pin)):
+                try:
+                    out[key] = fn(dev)
+                except Exception as ex:
+                    out[key] = {"error": repr(ex)}
         if not a.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline()

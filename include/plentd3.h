@@ -37,10 +37,10 @@ int plentd3_explore(const float *pre, const float *noise, const uint64_t *rng, f
 int plentd3_uniform_actions(const uint64_t *rng, float *a, int n, void *stream);
 /* plen_td3.py:109-113 replay_buffer.add for a whole vector step: ring rows (*total + e) % capacity = s | a | s2 | r | 1 - done_bool,
  * done_bool = terminal and not time-limit (done = PLENVEC_DONE_* bits of plenvec_step); real arrays are float32.  ep_ret [n][2] / stats [3]
- * (both or neither NULL): per-env running return and length; finished episodes are added to stats = {sum of returns, episodes, sum of lengths}
+ * (both or neither NULL): per-env running return and length; finished episodes are added to stats = {sum of returns, episodes, sum of lengths} (float64: exact counts to 2^53)
  * (the reference prints each episode's return and a moving average, plen_env.py:616-636) */
 int plentd3_store(float *data, const int64_t *total, int64_t capacity, const float *s, const float *a, const float *s2, const float *r, const uint8_t *done, uint64_t *rng_bump,
-                  float *ep_ret, float *stats, int n, void *stream);
+                  float *ep_ret, double *stats, int n, void *stream);
 /* td3.py:299-304: sa2 = [s2 | clamp(max_a tanh(pre) + clamp(noise sigma, +-clip), +-max_a)], pre = actor_target's last pre-activation */
 int plentd3_target_action(const float *pre, const float *noise, const uint64_t *rng, const float *batch, float *sa2, float sigma, float clip, float max_a, int B, void *stream);
 /* twin last layers on h2 = [h2_a | h2_b] ([B][512]).  mode 0, td3.py:306-309: y = r + not_done gamma min(q_a, q_b).

@@ -29,6 +29,12 @@ static __device__ __forceinline__ rsrc_t mkrs(const float *p, size_t bytes) { re
 static __device__ __forceinline__ floatx4 bload4(rsrc_t rs, uint32_t voff, uint32_t soff) { return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0)); }
 static __device__ __forceinline__ float bload1(rsrc_t rs, uint32_t voff, uint32_t soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0)); }
 static __device__ __forceinline__ void bstore1(float v, rsrc_t rs, uint32_t voff, uint32_t soff) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs, voff, soff, 0); }
+// Row i (0..3) of a lane's 4-row group, column `col`, of a row-major [B][ld] matrix whose descriptor covers exactly B rows: the ROW part of the
+// address goes into voffset, which the hardware range-checks (rows >= B: stores dropped, loads return 0); only the column part rides in soffset,
+// which raw buffers exclude from bounds checking (with the row term there, a 4-row group straddling B -- B % 4 != 0 -- could write up to 3
+// rows past the end into a neighbouring allocation)
+static __device__ __forceinline__ void bstore_row(float v, rsrc_t rs, uint32_t voff, int i, int ld, int col) { bstore1(v, rs, voff + 4u * (uint32_t)(i * ld), 4u * (uint32_t)col); }
+static __device__ __forceinline__ float bload_row(rsrc_t rs, uint32_t voff, int i, int ld, int col) { return bload1(rs, voff + 4u * (uint32_t)(i * ld), 4u * (uint32_t)col); }
 
 // acc[t] += X[16 rows][K] * W[n0 + 16 t + (0..15)][K]^T for t < NT.  Lane (r = lane % 16, g = lane / 16) feeds MFMA j of a 16-wide k step with
 // A[i = r][k] = X[r][k0 + 4 g + j] and B[k][n = r] = W[n0 + 16 t + r][k0 + 4 g + j] (any assignment of k indices to the instruction's four
@@ -145,7 +151,7 @@ static __device__ __forceinline__ void dense_relu(rsrc_t rx, uint32_t xoff, int 
     for (int t = 0; t < NT; t++) {
         const float bv = bias[n0 + 16 * t + rb.r];
 #pragma unroll
-        for (int i = 0; i < 4; i++) bstore1(fmaxf(acc[t][i] + bv, 0.f), ry, yoff, 4u * (uint32_t)(i * ldy + n0 + 16 * t));
+        for (int i = 0; i < 4; i++) bstore_row(fmaxf(acc[t][i] + bv, 0.f), ry, yoff, i, ldy, n0 + 16 * t);
     }
 }
 
@@ -171,7 +177,7 @@ static __device__ __forceinline__ void critic_l2_head(rsrc_t rx, uint32_t xoff, 
             for (int i = 0; i < 4; i++) {
                 const float v = fmaxf(acc[t][i] + bv, 0.f);
                 part[i] += v * wv;
-                if constexpr (STORE) bstore1(v, rh, hoff, 4u * (uint32_t)(i * ldh + hcol0 + n0 + 16 * t));
+                if constexpr (STORE) bstore_row(v, rh, hoff, i, ldh, hcol0 + n0 + 16 * t);
             }
         }
     }
@@ -366,8 +372,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 for (int t = 0; t < 8; t++)
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        const uint32_t so = 4u * (uint32_t)(i * 2 * TD3_H + c * TD3_H + j0 + 16 * t);
-                        bstore1(bload1(r_c1, ooff, so) > 0.f ? acc[t][i] : 0.f, r_dh1, ooff, so);
+                        const int col = c * TD3_H + j0 + 16 * t;
+                        bstore_row(bload_row(r_c1, ooff, i, 2 * TD3_H, col) > 0.f ? acc[t][i] : 0.f, r_dh1, ooff, i, 2 * TD3_H, col);
                     }
             }
         }
@@ -450,7 +456,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 const int c = n0 + 16 * t + r;
                 const float bv = A.c_b2[c], wv = ginv * A.c_w3[c];
 #pragma unroll
-                for (int i = 0; i < 4; i++) bstore1(acc[t][i] + bv > 0.f ? wv : 0.f, r_dg2, hoff, 4u * (uint32_t)(i * TD3_H + n0 + 16 * t));
+                for (int i = 0; i < 4; i++) bstore_row(acc[t][i] + bv > 0.f ? wv : 0.f, r_dg2, hoff, i, TD3_H, n0 + 16 * t);
             }
         }
     }
@@ -469,8 +475,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             for (int t = 0; t < 8; t++)
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const uint32_t so = 4u * (uint32_t)(i * TD3_H + j0 + 16 * t);
-                    bstore1(bload1(r_g1, hoff, so) > 0.f ? acc[t][i] : 0.f, r_dg1, hoff, so);
+                    bstore_row(bload_row(r_g1, hoff, i, TD3_H, j0 + 16 * t) > 0.f ? acc[t][i] : 0.f, r_dg1, hoff, i, TD3_H, j0 + 16 * t);
                 }
         }
     }
@@ -510,8 +515,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             for (int t = 0; t < 8; t++)
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const uint32_t so = 4u * (uint32_t)(i * TD3_H + j0 + 16 * t);
-                    bstore1(bload1(r_p2, hoff, so) > 0.f ? acc[t][i] : 0.f, r_dp2, hoff, so);
+                    bstore_row(bload_row(r_p2, hoff, i, TD3_H, j0 + 16 * t) > 0.f ? acc[t][i] : 0.f, r_dp2, hoff, i, TD3_H, j0 + 16 * t);
                 }
         }
     }
@@ -529,8 +533,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             for (int t = 0; t < 8; t++)
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const uint32_t so = 4u * (uint32_t)(i * TD3_H + j0 + 16 * t);
-                    bstore1(bload1(r_p1, hoff, so) > 0.f ? acc[t][i] : 0.f, r_dp1, hoff, so);
+                    bstore_row(bload_row(r_p1, hoff, i, TD3_H, j0 + 16 * t) > 0.f ? acc[t][i] : 0.f, r_dp1, hoff, i, TD3_H, j0 + 16 * t);
                 }
         }
     }

@@ -252,9 +252,11 @@ class _FlatGrads(object):
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
         self.views = _stacked_views(module, self.flat)
+        self.dirty = False         # set by the autograd path whenever it may have left gradients in the bucket (FusedTD3._zero_grads reads it)
 
     def zero(self):
         self.flat.zero_()
+        self.dirty = False
 
     def all_reduce_mean(self):
         import torch.distributed as dist
@@ -279,6 +281,7 @@ def td3_critic_backward(agent, batch, noise=None):
     critic_loss = F.mse_loss(current_Q1, target_Q) + F.mse_loss(current_Q2, target_Q)
     agent._critic_grads.zero()
     critic_loss.backward()
+    agent._critic_grads.dirty = True
     return critic_loss.detach()
 
 
@@ -288,6 +291,7 @@ def td3_actor_backward(agent, batch):
     actor_loss = -agent.critic.Q1(state, agent.actor(state)).mean()
     agent._actor_grads.zero()
     actor_loss.backward()                          # also writes critic grads; they are zeroed before their next use
+    agent._actor_grads.dirty = agent._critic_grads.dirty = True
     return actor_loss.detach()
 
 

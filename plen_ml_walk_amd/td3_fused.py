@@ -154,6 +154,7 @@ class FusedTD3(object):
         # launches (PipelinedVecTD3Trainer: 0.73 -> 0.66 ms per step); on an otherwise idle GPU the library GEMMs are faster (critic pass 239 vs 315 us)
         self.rows = (os.environ.get("PLEN_TD3_ROWS", "0") == "1") if rows is None else bool(rows)
         self._done_count = None
+        self._alloc = None           # test hook: allocator of the per-iteration scratch matrices (tests put canary rows behind them)
         self._critic_adam = self._actor_adam = None
         self._zeroed = {}
         self.epilogue = False
@@ -192,10 +193,14 @@ class FusedTD3(object):
 
     def _zero_grads(self, which):
         """Zero a gradient bucket before a backward pass unless the last Adam step already did."""
-        if self._zeroed.get(which):
+        grads = self.agent._critic_grads if which == "critic" else self.agent._actor_grads
+        if self._zeroed.get(which) and not grads.dirty:
             self._zeroed[which] = False
             return
-        (self.agent._critic_grads if which == "critic" else self.agent._actor_grads).zero()
+        # the autograd path on the same agent (TD3Agent.train: td3_actor_backward also writes critic gradients) leaves the bucket dirty
+        # whatever the last fused Adam step did (ADVICE r02)
+        self._zeroed[which] = False
+        grads.zero()
 
     def _probe(self, k):
         """Timeline hook (train_vec.PipelinedVecTD3Trainer.enable_timeline): stamp point k of the update; nothing unless a probe is installed."""
@@ -247,7 +252,7 @@ class FusedTD3(object):
         if self.rows and rng is not None:
             n = int(state.shape[0])
             assert state.dtype == torch.float32 and state.is_contiguous() and state.shape[1] == S
-            new = lambda *shape: torch.empty(*shape, device=self.dev, dtype=torch.float32)
+            new = self._alloc or (lambda *shape: torch.empty(*shape, device=self.dev, dtype=torch.float32))
             p1, p2, act = new(n, H), new(n, H), new(n, A)
             a = ActorRowsArgs()
             a.a_w1, a.a_b1, a.a_w2, a.a_b2, a.a_w3, a.a_b3 = (t.data_ptr() for t in (ac.fc1.weight, ac.fc1.bias, ac.fc2.weight, ac.fc2.bias, ac.fc3.weight, ac.fc3.bias))
@@ -271,7 +276,7 @@ class FusedTD3(object):
 
     def store(self, data, total, state, action, next_obs, reward, done, rng=None, episodes=None):
         """One vector step into the packed replay ring at positions (total + e) % capacity (plen_td3.py:109-113); `total` = device int64 scalar.
-        rng: the collect stream's random state, whose call counter this kernel advances.  episodes: (ep_ret [n, 2], stats [3]) float32 device
+        rng: the collect stream's random state, whose call counter this kernel advances.  episodes: (ep_ret [n, 2] float32, stats [3] float64) device
         tensors for the episode bookkeeping (running return / length per env; finished episodes summed into stats)."""
         n = int(state.shape[0])
         for t in (state, action, next_obs, reward):
@@ -289,7 +294,7 @@ class FusedTD3(object):
         ag, lib, st = self.agent, self.lib, self._stream()
         dev = self.dev
         assert data.dtype == torch.float32 and data.is_contiguous() and data.shape[1] == ROW
-        new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        new = self._alloc or (lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32))
         if isinstance(idx, int):
             B = idx
             batch, sa_pi, loss = new(B, ROW), new(B, SA), new(2)
@@ -360,7 +365,7 @@ class FusedTD3(object):
         ag, lib, st = self.agent, self.lib, self._stream()
         dev = self.dev
         assert data.dtype == torch.float32 and data.is_contiguous() and data.shape[1] == ROW and total is not None
-        new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        new = self._alloc or (lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32))
         with torch.no_grad():
             at, ct, cr = ag.actor_target, ag.critic_target, ag.critic
             tv, cv, gv = ag._critic_target_flat.views, ag._critic_flat.views, ag._critic_grads.views
@@ -401,7 +406,7 @@ class FusedTD3(object):
         ag, lib, st = self.agent, self.lib, self._stream()
         dev = self.dev
         s, sa_pi, B = self._saved
-        new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        new = self._alloc or (lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32))
         cr = ag.critic
         if self.rows:
             with torch.no_grad():

@@ -160,7 +160,9 @@ def main(argv=None):
         tr = VecTD3Trainer(env, agent, replay, a.start_timesteps, 0.1, a.batch, a.updates_per_step, seed=1000 + rank)
     if resumed:
         tr.restore_counters(resumed)
-    for _ in range(a.warmup):
+    # the pipelined loop has 6 update and 6 collect graph keys, each run eagerly twice and captured on its third use: ~22 steps pass before
+    # everything replays, so a shorter warm-up would put eager runs, captures and device-wide syncs into the timed region
+    for _ in range(max(a.warmup, 30) if pipelined else a.warmup):
         tr.step()
     torch.cuda.synchronize()
     if world > 1:
@@ -440,7 +442,7 @@ class PipelinedVecTD3Trainer(object):
         self.base = [torch.tensor(h * self.nh, dtype=torch.long, device=dev) for h in range(self.H)]  # next ring row of each sub-batch
         self.total_u = torch.zeros((), dtype=torch.long, device=dev)                                  # rows complete before the current step
         self.ep_ret = [torch.zeros(self.nh, 2, device=dev) for _ in range(self.H)]                    # running return / length of every env
-        self.ep_stats = torch.zeros(3, device=dev)                                                    # finished episodes: sum of returns, count, sum of lengths
+        self.ep_stats = torch.zeros(3, dtype=torch.float64, device=dev)                                                    # finished episodes: sum of returns, count, sum of lengths
         self._critic_loss = torch.zeros((), device=dev)
         self.t = 0
         self.env_steps = self.grad_steps = 0
@@ -590,7 +592,13 @@ class PipelinedVecTD3Trainer(object):
         self.sync()
         s = self.ep_stats.tolist()
         if reset:
-            self.ep_stats.zero_()
+            # the collectors' next k_store adds into ep_stats on their own (non-blocking) streams: zero it on the update stream and make
+            # both collectors wait for that, like every other cross-stream access of this class
+            with torch.cuda.stream(self.su):
+                self.ep_stats.zero_()
+                ev = torch.cuda.Event(); ev.record(self.su)
+            for st in self.streams:
+                st.wait_event(ev)
         n = max(s[1], 1.0)
         return {"episodes": int(s[1]), "mean_return": s[0] / n, "mean_length": s[2] / n}
 

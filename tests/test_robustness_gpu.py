@@ -589,3 +589,52 @@ def test_two_ranks_on_one_gpu_graph_trainer(tmp_path, fused):
         assert r["params_equal_across_ranks"] and r["targets_equal_across_ranks"] and r["finite"] and r["moved"] > 1e-4
         assert r["rank_local_env_states_differ"]
     assert any("critic_backward" in g for g in r0["graphs"]) and any("actor_step" in g for g in r0["graphs"])
+
+
+@pytest.mark.parametrize("B", [3, 37, 101])
+def test_row_block_kernels_never_write_past_a_ragged_batch(B):
+    """a 4-row store group straddling B (B % 4 != 0) must not write rows >= B.  Every per-iteration scratch matrix is allocated with
+    canary rows behind it (FusedTD3._alloc hook); critic rows, policy rows and actor rows run at ragged sizes; the canaries stay untouched."""
+    from plen_ml_walk_amd import td3 as T
+    from plen_ml_walk_amd.td3_fused import FusedTD3
+    torch.manual_seed(21)
+    ag = T.TD3Agent(26, 18, 1.0, data_parallel=False)
+    fz = FusedTD3(ag, seed=5, rows=True)
+    pads = []
+
+    def alloc(*shape):
+        full = torch.full((shape[0] + 8,) + tuple(shape[1:]), 12345.0, device="cuda", dtype=torch.float32)
+        pads.append(full[shape[0]:])
+        return full[:shape[0]]
+    fz._alloc = alloc
+    data = torch.randn(400, 72, device="cuda")
+    tot = torch.tensor(300, dtype=torch.long, device="cuda")
+    loss = fz.critic_backward(data, B, total=tot, guard=0)
+    fz.policy_backward()
+    a = fz.explore(torch.randn(B, 26, device="cuda"), 0.1, rng=FusedTD3.new_rng("cuda", 3))
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and a.shape == (B, 18)
+    assert len(pads) >= 15
+    for k, p_ in enumerate(pads):
+        assert bool((p_ == 12345.0).all()), "scratch matrix %d of %d: rows past B = %d were written" % (k, len(pads), B)
+
+
+def test_episode_statistics_survive_long_runs():
+    """the ring-store kernel's episode statistics are float64 (count exact to 2^53): pre-loaded beyond float32's 2^24 they still
+    absorb single episodes."""
+    from plen_ml_walk_amd import td3 as T
+    from plen_ml_walk_amd.td3_fused import FusedTD3
+    ag = T.TD3Agent(26, 18, 1.0, data_parallel=False)
+    fz = FusedTD3(ag, seed=1)
+    n = 64
+    data = torch.zeros(1000, 72, device="cuda")
+    total = torch.zeros(1, dtype=torch.long, device="cuda")
+    ep_ret = torch.zeros(n, 2, device="cuda")
+    stats = torch.tensor([3.0e9, float(2 ** 24 + 1), float(2 ** 31)], dtype=torch.float64, device="cuda")
+    s0 = stats.clone()
+    done = torch.zeros(n, dtype=torch.uint8, device="cuda"); done[:5] = 1
+    rew = torch.full((n,), 0.25, device="cuda")
+    fz.store(data, total, torch.zeros(n, 26, device="cuda"), torch.zeros(n, 18, device="cuda"), torch.zeros(n, 26, device="cuda"), rew, done, episodes=(ep_ret, stats))
+    torch.cuda.synchronize()
+    d = (stats - s0).tolist()
+    assert d == [5 * 0.25, 5.0, 5.0], d
