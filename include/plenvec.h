@@ -15,6 +15,14 @@
  *     nothing synchronises with the host except create/destroy and the *_host helpers;
  *   - a handle is not thread-safe: one stream per handle at a time;
  *   - real-valued device arrays are float or double according to PlenCfg.dtype.
+ *
+ * Deviations from the sketch in SURVEY.md section 8(b), on purpose:
+ *   - plenvec_create takes no model: the PLEN tables are compiled in (generated from the reference's plen.urdf + foot STLs).
+ *     plenvec_create_from_model takes a PlenModel for variants of the same tree (other masses, inertias, frames, soles, boxes);
+ *   - plenvec_step reports truncation as a BIT of `done` (PLENVEC_DONE_TIMELIMIT) instead of a separate trunc[] array, because the
+ *     non-finite guard needs a third state; plenvec_step2 returns the sketch's (done, trunc) pair of 0/1 bytes;
+ *   - there is no device = -1 CPU backend: the only CPU implementation of this path is the test oracle, and a product path through it
+ *     would void every parity claim.  Without a GPU every entry point fails with PLENVEC_E_NODEV.
  */
 #ifndef PLENVEC_H
 #define PLENVEC_H
@@ -82,11 +90,47 @@ typedef struct PlenCfg {
 /* Fills *cfg with the reference configuration for the given joint_act mode. */
 int plenvec_default_cfg(PlenCfg *cfg, int joint_act);
 
+/* The robot as numbers (what loadURDF("plen.urdf") hands PyBullet, plen_env.py:312-315, after the importer's rules: fixed joints folded
+ * into 19 composite bodies, inertia from the collision shapes).  The TOPOLOGY is fixed -- the kernels are written for the PLEN tree: body 0
+ * the base, four serial chains (right leg 1-6, left leg 7-12, right arm 13-15, left arm 16-18), feet = bodies 6 and 12 -- every number may
+ * change (a plen_new.urdf-style variant with other masses / link geometry, a measured robot, ...). */
+#define PLENVEC_NBODY 19
+#define PLENVEC_MAXMEMB 7
+#define PLENVEC_MAXBOX 31
+typedef struct PlenModel {
+    int32_t num_bodies;                         /* 19 */
+    int32_t parent[PLENVEC_NBODY];              /* must be {-1, 0,1,2,3,4,5, 0,7,8,9,10,11, 0,13,14, 0,16,17} */
+    double joint_R[PLENVEC_NBODY][9];           /* joint frame in the parent body frame, row major */
+    double joint_t[PLENVEC_NBODY][3];
+    double axis[PLENVEC_NBODY][3];              /* revolute axis in the body frame (unit) */
+    double com[PLENVEC_NBODY][3];               /* composite centre of mass, body frame */
+    double inertia[PLENVEC_NBODY][6];           /* about the COM, body axes: xx yy zz xy xz yz */
+    double mass[PLENVEC_NBODY];
+    int32_t n_member[PLENVEC_NBODY];            /* links folded into the body (Bullet applies linear damping per LINK) */
+    double member_com[PLENVEC_NBODY][PLENVEC_MAXMEMB][3];
+    double member_mass[PLENVEC_NBODY][PLENVEC_MAXMEMB];
+    double margin;                              /* collision margin of the foot hulls (0.001) */
+    double foot_break[2];                       /* contact breaking threshold, right / left foot */
+    double sole[2][32][3];                      /* the 32 sole-plane hull vertices per foot, foot body frame, outline order */
+    int32_t sole_rep[2][32];                    /* 1: the vertex is a contact candidate (one per corner fillet) */
+    int32_t sole_order[2][4][32];               /* per sole diagonal: vertex indices by descending key (candidates first) */
+    int32_t num_boxes;                          /* <= 31 box colliders of the non-foot links */
+    int32_t box_body[PLENVEC_MAXBOX];
+    double box_R[PLENVEC_MAXBOX][9], box_t[PLENVEC_MAXBOX][3], box_half[PLENVEC_MAXBOX][3];   /* pose in the body frame, half extents */
+    double box_break[PLENVEC_MAXBOX];           /* contact breaking threshold */
+    double box_link_restitution[PLENVEC_MAXBOX];/* 0.5 (plen_env.py:472-481), base link 0 */
+} PlenModel;
+/* Fills *model with the compiled-in PLEN robot (plen.urdf + rfoot.stl / lfoot.stl through tools/extract_model.py). */
+int plenvec_default_model(PlenModel *model);
+
 /* Replaces: PlenWalkEnv.__init__ (plen_env.py:34-556: connect, loadURDF, changeDynamics...) for
  * `num_envs` independent environments on HIP device `device`.  The PLEN model tables are compiled
  * in (generated from the reference's plen.urdf + foot STLs by tools/extract_model.py).
  * All envs start in the post-reset state (see plenvec_reset).  Host-synchronous. */
 int plenvec_create(const PlenCfg *cfg, int num_envs, int device, plenvec_t **out);
+/* The same with the robot given as numbers; PLENVEC_E_INVAL if the topology is not the PLEN tree.  plenvec_create(cfg, ...) ==
+ * plenvec_create_from_model(default model, cfg, ...). */
+int plenvec_create_from_model(const PlenModel *model, const PlenCfg *cfg, int num_envs, int device, plenvec_t **out);
 int plenvec_destroy(plenvec_t *h);
 int plenvec_num_envs(const plenvec_t *h);
 int plenvec_dtype(const plenvec_t *h);
@@ -108,6 +152,10 @@ int plenvec_reset(plenvec_t *h, const uint8_t *mask, void *obs, void *stream);
  *   cur_obs  real[num_envs][26]    observation to act on next: == next_obs unless the env was
  *                                  auto-reset, then the reset observation.  May be NULL. */
 int plenvec_step(plenvec_t *h, const float *action, void *next_obs, void *reward, uint8_t *done, void *cur_obs, void *stream);
+/* plenvec_step with SURVEY 8(b)'s output pair: done[e] = 1 iff compute_done() fired and the time limit did not (the `done_bool` the
+ * reference driver stores, plen_td3.py:109-110), trunc[e] = 1 iff the episode was cut by the time limit (or by the non-finite guard).
+ * One extra tiny launch on the same stream; the hot loops of this repository use plenvec_step. */
+int plenvec_step2(plenvec_t *h, const float *action, void *next_obs, void *reward, uint8_t *done, uint8_t *trunc, void *cur_obs, void *stream);
 
 /* State injection / extraction for parity tests (no reference equivalent; PyBullet's
  * resetBasePositionAndOrientation/resetJointState/getJointStates family).

@@ -25,7 +25,22 @@ class PlenCfg(C.Structure):
                 ("box_lateral_friction", C.c_double), ("nonfinite_guard", C.c_int32), ("body_contacts", C.c_int32)]
 
 
-EXPORTS = ["plenvec_default_cfg", "plenvec_create", "plenvec_destroy", "plenvec_num_envs", "plenvec_dtype", "plenvec_reset",
+NBODY, MAXMEMB, MAXBOX = 19, 7, 31
+
+
+class PlenModel(C.Structure):
+    """include/plenvec.h PlenModel: the robot as numbers (fixed PLEN topology)."""
+    _d = C.c_double
+    _fields_ = [("num_bodies", C.c_int32), ("parent", C.c_int32 * NBODY), ("joint_R", (_d * 9) * NBODY), ("joint_t", (_d * 3) * NBODY),
+                ("axis", (_d * 3) * NBODY), ("com", (_d * 3) * NBODY), ("inertia", (_d * 6) * NBODY), ("mass", _d * NBODY),
+                ("n_member", C.c_int32 * NBODY), ("member_com", ((_d * 3) * MAXMEMB) * NBODY), ("member_mass", (_d * MAXMEMB) * NBODY),
+                ("margin", _d), ("foot_break", _d * 2), ("sole", ((_d * 3) * 32) * 2), ("sole_rep", (C.c_int32 * 32) * 2),
+                ("sole_order", ((C.c_int32 * 32) * 4) * 2), ("num_boxes", C.c_int32), ("box_body", C.c_int32 * MAXBOX),
+                ("box_R", (_d * 9) * MAXBOX), ("box_t", (_d * 3) * MAXBOX), ("box_half", (_d * 3) * MAXBOX), ("box_break", _d * MAXBOX),
+                ("box_link_restitution", _d * MAXBOX)]
+
+
+EXPORTS = ["plenvec_default_model", "plenvec_create_from_model", "plenvec_step2", "plenvec_default_cfg", "plenvec_create", "plenvec_destroy", "plenvec_num_envs", "plenvec_dtype", "plenvec_reset",
            "plenvec_step", "plenvec_get_state", "plenvec_set_state", "plenvec_get_aux", "plenvec_debug_substeps",
            "plenvec_set_params", "plenvec_get_nonfinite_count", "plenvec_timing_begin", "plenvec_timing_end", "plenvec_last_error", "plenvec_version"]
 
@@ -48,6 +63,9 @@ def load():
     vp, i32 = C.c_void_p, C.c_int
     lib.plenvec_default_cfg.argtypes = [C.POINTER(PlenCfg), i32]
     lib.plenvec_create.argtypes = [C.POINTER(PlenCfg), i32, i32, C.POINTER(vp)]
+    lib.plenvec_default_model.argtypes = [C.POINTER(PlenModel)]
+    lib.plenvec_create_from_model.argtypes = [C.POINTER(PlenModel), C.POINTER(PlenCfg), i32, i32, C.POINTER(vp)]
+    lib.plenvec_step2.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     lib.plenvec_destroy.argtypes = [vp]
     lib.plenvec_num_envs.argtypes = [vp]
     lib.plenvec_dtype.argtypes = [vp]
@@ -72,6 +90,12 @@ def load():
 def check(code):
     if code != 0:
         raise PlenvecError("libplenvec error %d: %s" % (code, load().plenvec_last_error().decode()))
+
+
+def default_model():
+    m = PlenModel()
+    check(load().plenvec_default_model(C.byref(m)))
+    return m
 
 
 def default_cfg(joint_act=False):

@@ -2122,42 +2122,93 @@ struct plenvec {
     int64_t launches, launches_mark;
 };
 
+// the compiled-in PLEN model (tools/extract_model.py -> plen_model_gen.h) as the C ABI's PlenModel
+int plenvec_default_model(PlenModel *m) {
+    if (!m) return fail(PLENVEC_E_INVAL, "model is NULL");
+    memset(m, 0, sizeof *m);
+    static const int parent[NB] = {-1, 0, 1, 2, 3, 4, 5, 0, 7, 8, 9, 10, 11, 0, 13, 14, 0, 16, 17};
+    m->num_bodies = NB; m->num_boxes = GEN_NBOX; m->margin = GEN_MARGIN; m->foot_break[0] = GEN_RFOOT_BREAK; m->foot_break[1] = GEN_LFOOT_BREAK;
+    for (int b = 0; b < NB; b++) {
+        m->parent[b] = parent[b];
+        for (int i = 0; i < 9; i++) m->joint_R[b][i] = GEN_JR[b][i];
+        for (int i = 0; i < 3; i++) { m->joint_t[b][i] = GEN_JT[b][i]; m->axis[b][i] = GEN_AXIS[b][i]; m->com[b][i] = GEN_COM[b][i]; }
+        for (int i = 0; i < 6; i++) m->inertia[b][i] = GEN_INERTIA[b][i];
+        m->mass[b] = GEN_MASS[b]; m->n_member[b] = GEN_NMEMB[b];
+        for (int i = 0; i < GEN_MAXMEMB; i++) { for (int c = 0; c < 3; c++) m->member_com[b][i][c] = GEN_MEMB_COM[b][3 * i + c]; m->member_mass[b][i] = GEN_MEMB_MASS[b][i]; }
+    }
+    for (int f = 0; f < 2; f++)
+        for (int v = 0; v < 32; v++) {
+            for (int i = 0; i < 3; i++) m->sole[f][v][i] = f == 0 ? GEN_RFOOT_SOLE[v][i] : GEN_LFOOT_SOLE[v][i];
+            m->sole_rep[f][v] = f == 0 ? GEN_RFOOT_SOLE_REP[v] : GEN_LFOOT_SOLE_REP[v];
+            for (int k = 0; k < 4; k++) m->sole_order[f][k][v] = f == 0 ? GEN_RFOOT_SOLE_ORDER[k][v] : GEN_LFOOT_SOLE_ORDER[k][v];
+        }
+    for (int x = 0; x < GEN_NBOX; x++) {
+        m->box_body[x] = GEN_BOX_BODY[x];
+        for (int i = 0; i < 9; i++) m->box_R[x][i] = GEN_BOX_R[x][i];
+        for (int i = 0; i < 3; i++) { m->box_t[x][i] = GEN_BOX_T[x][i]; m->box_half[x][i] = GEN_BOX_H[x][i]; }
+        m->box_break[x] = GEN_BOX_BREAK[x]; m->box_link_restitution[x] = GEN_BOX_LINK_RESTITUTION[x];
+    }
+    return PLENVEC_OK;
+}
+
+// the kernels are written for the PLEN tree (a base and four serial chains of 6, 6, 3, 3 bodies, feet = bodies 6 and 12): a PlenModel may
+// change every number but not the topology
+static int check_model(const PlenModel &m) {
+    PlenModel d; plenvec_default_model(&d);
+    if (m.num_bodies != NB) return fail(PLENVEC_E_INVAL, "PlenModel.num_bodies must be 19");
+    for (int b = 0; b < NB; b++) {
+        if (m.parent[b] != d.parent[b]) return fail(PLENVEC_E_INVAL, "PlenModel.parent must be the PLEN tree (base + chains of 6, 6, 3, 3 bodies)");
+        if (!(m.mass[b] > 0)) return fail(PLENVEC_E_INVAL, "PlenModel.mass must be positive");
+        if (m.n_member[b] < 1 || m.n_member[b] > PLENVEC_MAXMEMB) return fail(PLENVEC_E_INVAL, "PlenModel.n_member out of range");
+        if (b > 0) { double n2 = m.axis[b][0] * m.axis[b][0] + m.axis[b][1] * m.axis[b][1] + m.axis[b][2] * m.axis[b][2]; if (fabs(n2 - 1.0) > 1e-6) return fail(PLENVEC_E_INVAL, "PlenModel.axis must be unit vectors"); }
+    }
+    if (m.num_boxes < 0 || m.num_boxes > GEN_NBOX) return fail(PLENVEC_E_INVAL, "PlenModel.num_boxes out of range");
+    for (int x = 0; x < m.num_boxes; x++) if (m.box_body[x] < 0 || m.box_body[x] >= NB) return fail(PLENVEC_E_INVAL, "PlenModel.box_body out of range");
+    for (int f = 0; f < 2; f++) for (int k = 0; k < 4; k++) for (int v = 0; v < 32; v++)
+        if (m.sole_order[f][k][v] < 0 || m.sole_order[f][k][v] >= 32) return fail(PLENVEC_E_INVAL, "PlenModel.sole_order out of range");
+    return PLENVEC_OK;
+}
+
 template <typename real>
-static void fill_params(const PlenCfg &c, DevParams<real> &p) {
+static void fill_params(const PlenCfg &c, const PlenModel &m, DevParams<real> &p) {
     memset(&p, 0, sizeof p);
     p.dt = (real)c.dt; p.inv_dt = (real)(1.0 / c.dt); p.gz = (real)c.gravity_z; p.erp = (real)c.erp; p.erp2 = (real)c.erp2;
     p.slop = (real)c.linear_slop; p.res_thr = (real)c.residual_threshold; p.res_thr_sqrt = (real)sqrt(c.residual_threshold); p.rest_thr = (real)c.restitution_velocity_threshold;
     p.vmax = (real)c.max_coordinate_velocity; p.mu_lat = (real)c.lateral_friction; p.mu_spin = (real)c.spinning_friction;
     p.mu_roll = (real)c.rolling_friction; p.restitution = (real)c.restitution; p.lin_damp = (real)c.linear_damping;
     p.kp = (real)c.motor_kp; p.kd = (real)c.motor_kd; p.max_imp = (real)(c.motor_max_force * c.dt); p.spawn_z = (real)c.spawn_z;
-    p.margin = (real)GEN_MARGIN; p.brk[0] = (real)GEN_RFOOT_BREAK; p.brk[1] = (real)GEN_LFOOT_BREAK;
+    p.margin = (real)m.margin; p.brk[0] = (real)m.foot_break[0]; p.brk[1] = (real)m.foot_break[1];
     for (int f = 0; f < 2; f++) {
         p.corner_pack[f] = 0;
         for (int v = 0; v < 32; v++) {
-            for (int i = 0; i < 3; i++) p.sole[f][v][i] = (real)(f == 0 ? GEN_RFOOT_SOLE[v][i] : GEN_LFOOT_SOLE[v][i]);
-            p.sole[f][v][3] = (real)(f == 0 ? GEN_RFOOT_SOLE_REP[v] : GEN_LFOOT_SOLE_REP[v]);
+            for (int i = 0; i < 3; i++) p.sole[f][v][i] = (real)m.sole[f][v][i];
+            p.sole[f][v][3] = (real)m.sole_rep[f][v];
             p.sole_src[f][v] = 0;
-            for (int k = 0; k < 4; k++) p.sole_src[f][v] |= (unsigned)(f == 0 ? GEN_RFOOT_SOLE_ORDER[k][v] : GEN_LFOOT_SOLE_ORDER[k][v]) << (8 * k);
+            for (int k = 0; k < 4; k++) p.sole_src[f][v] |= (unsigned)m.sole_order[f][k][v] << (8 * k);
         }
         p.corner_pack[f] = p.sole_src[f][0];
     }
     for (int b = 0; b < NB; b++) {
-        for (int i = 0; i < 9; i++) p.mdl[b][i] = (real)GEN_JR[b][i];
-        for (int i = 0; i < 3; i++) { p.mdl[b][9 + i] = (real)GEN_JT[b][i]; p.mdl[b][12 + i] = (real)GEN_AXIS[b][i]; p.mdl[b][15 + i] = (real)GEN_COM[b][i]; }
-        for (int i = 0; i < 6; i++) p.mdl[b][18 + i] = (real)GEN_INERTIA[b][i];
-        p.mdl[b][24] = (real)GEN_MASS[b];
-        p.nmemb[b] = GEN_NMEMB[b];
+        for (int i = 0; i < 9; i++) p.mdl[b][i] = (real)m.joint_R[b][i];
+        for (int i = 0; i < 3; i++) { p.mdl[b][9 + i] = (real)m.joint_t[b][i]; p.mdl[b][12 + i] = (real)m.axis[b][i]; p.mdl[b][15 + i] = (real)m.com[b][i]; }
+        for (int i = 0; i < 6; i++) p.mdl[b][18 + i] = (real)m.inertia[b][i];
+        p.mdl[b][24] = (real)m.mass[b];
+        p.nmemb[b] = m.n_member[b];
         for (int i = 0; i < GEN_MAXMEMB; i++) {
-            for (int c = 0; c < 3; c++) p.memb[b][i][c] = (real)GEN_MEMB_COM[b][3 * i + c];
-            p.memb[b][i][3] = (real)GEN_MEMB_MASS[b][i];
+            for (int c = 0; c < 3; c++) p.memb[b][i][c] = (real)m.member_com[b][i][c];
+            p.memb[b][i][3] = (real)m.member_mass[b][i];
         }
     }
     for (int x = 0; x < GEN_NBOX; x++) {
-        for (int i = 0; i < 9; i++) p.box[x][i] = (real)GEN_BOX_R[x][i];
-        for (int i = 0; i < 3; i++) { p.box[x][9 + i] = (real)GEN_BOX_T[x][i]; p.box[x][12 + i] = (real)GEN_BOX_H[x][i]; }
-        p.box[x][15] = (real)GEN_BOX_BREAK[x];
-        p.box[x][16] = (real)(c.restitution * (GEN_BOX_LINK_RESTITUTION[x] / 0.5));      // c.restitution = link 0.5 x plane 0.5; the base link keeps Bullet's default 0
-        p.box_body[x] = GEN_BOX_BODY[x];
+        if (x >= m.num_boxes) {          // unused box slots: a point box far above the ground never comes into range
+            p.box[x][0] = p.box[x][4] = p.box[x][8] = 1; p.box[x][11] = (real)1e6; p.box[x][15] = (real)-1; p.box_body[x] = 0;
+            continue;
+        }
+        for (int i = 0; i < 9; i++) p.box[x][i] = (real)m.box_R[x][i];
+        for (int i = 0; i < 3; i++) { p.box[x][9 + i] = (real)m.box_t[x][i]; p.box[x][12 + i] = (real)m.box_half[x][i]; }
+        p.box[x][15] = (real)m.box_break[x];
+        p.box[x][16] = (real)(c.restitution * (m.box_link_restitution[x] / 0.5));      // c.restitution = link 0.5 x plane 0.5; the base link keeps Bullet's default 0
+        p.box_body[x] = m.box_body[x];
     }
     p.mu_box = (real)c.box_lateral_friction; p.body_contacts = c.body_contacts;
     p.num_iterations = c.num_iterations; p.max_episode_steps = c.max_episode_steps; p.joint_act = c.joint_act; p.reward_head = c.reward_head;
@@ -2240,8 +2291,15 @@ int plenvec_default_cfg(PlenCfg *c, int joint_act) {
 }
 
 int plenvec_create(const PlenCfg *cfg, int num_envs, int device, plenvec_t **out) {
+    PlenModel m; plenvec_default_model(&m);
+    return plenvec_create_from_model(&m, cfg, num_envs, device, out);
+}
+
+int plenvec_create_from_model(const PlenModel *model, const PlenCfg *cfg, int num_envs, int device, plenvec_t **out) {
     if (!out) return fail(PLENVEC_E_INVAL, "out is NULL");
     *out = nullptr;
+    if (!model) return fail(PLENVEC_E_INVAL, "model is NULL");
+    { int mc = check_model(*model); if (mc != PLENVEC_OK) return mc; }
     if (num_envs <= 0) return fail(PLENVEC_E_INVAL, "num_envs must be positive");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -2269,10 +2327,10 @@ int plenvec_create(const PlenCfg *cfg, int num_envs, int device, plenvec_t **out
     HIPCHK_H(hipMalloc((void **)&h->nonfinite, sizeof(unsigned long long)));
     HIPCHK_H(hipMemset(h->nonfinite, 0, sizeof(unsigned long long)));
     if (h->dtype == PLENVEC_DTYPE_F64) {
-        DevParams<double> p; fill_params(h->cfg, p);
+        DevParams<double> p; fill_params(h->cfg, *model, p);
         HIPCHK_H(hipMalloc(&h->P, sizeof p)); HIPCHK_H(hipMemcpy(h->P, &p, sizeof p, hipMemcpyHostToDevice));
     } else {
-        DevParams<float> p; fill_params(h->cfg, p);
+        DevParams<float> p; fill_params(h->cfg, *model, p);
         HIPCHK_H(hipMalloc(&h->P, sizeof p)); HIPCHK_H(hipMemcpy(h->P, &p, sizeof p, hipMemcpyHostToDevice));
     }
     HIPCHK_H(hipEventCreate(&h->ev0)); HIPCHK_H(hipEventCreate(&h->ev1));
@@ -2328,6 +2386,21 @@ int plenvec_step(plenvec_t *h, const float *action, void *next_obs, void *reward
         if (rcode != PLENVEC_OK) return rcode;
     }
     return launch_env_any(h, MODE_STEP, h->cfg.substeps, action, nullptr, next_obs, reward, done, cur_obs, nullptr, (hipStream_t)stream);
+}
+
+// done bits -> the (done, trunc) pair of SURVEY 8(b)'s sketch / gymnasium's (terminated, truncated)
+__global__ void plen_split_done_kernel(uint8_t *__restrict__ done, uint8_t *__restrict__ trunc, int n) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) { const uint8_t d = done[e]; trunc[e] = (d & PLENVEC_DONE_TIMELIMIT) ? 1 : 0; done[e] = ((d & PLENVEC_DONE_TERMINAL) && !(d & PLENVEC_DONE_TIMELIMIT)) ? 1 : 0; }
+}
+
+int plenvec_step2(plenvec_t *h, const float *action, void *next_obs, void *reward, uint8_t *done, uint8_t *trunc, void *cur_obs, void *stream) {
+    if (!trunc) return fail(PLENVEC_E_INVAL, "trunc must be a device pointer");
+    int rcode = plenvec_step(h, action, next_obs, reward, done, cur_obs, stream);
+    if (rcode != PLENVEC_OK) return rcode;
+    hipLaunchKernelGGL(plen_split_done_kernel, dim3((h->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, done, trunc, h->n);
+    HIPCHK(hipGetLastError());
+    return PLENVEC_OK;
 }
 
 int plenvec_debug_substeps(plenvec_t *h, const void *targets, int nsub, void *dump, void *stream) {

@@ -44,7 +44,7 @@ class PlenVecEnv(object):
       `done_bool` the reference stores in the replay buffer (plen_td3.py:109-110);
       info["time_limit"] marks gym TimeLimit truncations (plen_env.py:15-19)."""
 
-    def __init__(self, num_envs, device=None, dtype=torch.float32, joint_act=False, auto_reset=True, cfg_overrides=None, out_buffers=None):
+    def __init__(self, num_envs, device=None, dtype=torch.float32, joint_act=False, auto_reset=True, cfg_overrides=None, out_buffers=None, model=None):
         if not torch.cuda.is_available():
             raise L.PlenvecError("PlenVecEnv needs a ROCm GPU (MI355X); there is no CPU fallback")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -63,7 +63,10 @@ class PlenVecEnv(object):
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         h = C.c_void_p()
         with torch.cuda.device(idx):
-            L.check(self.lib.plenvec_create(C.byref(cfg), self.num_envs, idx, C.byref(h)))
+            if model is None:
+                L.check(self.lib.plenvec_create(C.byref(cfg), self.num_envs, idx, C.byref(h)))
+            else:                         # a _lib.PlenModel: the same tree with other numbers (plenvec_create_from_model)
+                L.check(self.lib.plenvec_create_from_model(C.byref(model), C.byref(cfg), self.num_envs, idx, C.byref(h)))
         self.h = h
         n, dev = self.num_envs, self.device
         if out_buffers is None:
@@ -106,6 +109,15 @@ class PlenVecEnv(object):
                                       _ptr(self._cur_obs), self._stream()))
         flags = self._done
         return self._next_obs, self._reward, flags, StepInfo(flags, self._cur_obs)
+
+    def step2(self, action):
+        """plenvec_step2: (next_obs, reward, done, trunc) with done / trunc as separate 0/1 bytes (SURVEY 8(b)'s pair)."""
+        a = action.to(device=self.device, dtype=torch.float32).contiguous()
+        if getattr(self, "_trunc", None) is None:
+            self._trunc = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
+        L.check(self.lib.plenvec_step2(self.h, _ptr(a), _ptr(self._next_obs), _ptr(self._reward), _ptr(self._done), _ptr(self._trunc),
+                                       _ptr(self._cur_obs), self._stream()))
+        return self._next_obs, self._reward, self._done, self._trunc
 
     # ---- state access (parity tests) ------------------------------------------------------
     def get_state(self):

@@ -19,7 +19,7 @@ def lib():
 
 def test_header_symbols_are_exported(lib):
     hdr = open(os.path.join(ROOT, "include", "plenvec.h")).read()
-    names = sorted(set(re.findall(r"\b(plenvec_[a-z_]+)\s*\(", hdr)))
+    names = sorted(set(re.findall(r"\b(plenvec_[a-z0-9_]+)\s*\(", hdr)))
     assert len(names) >= 16
     from plen_ml_walk_amd import _lib
     assert sorted(_lib.EXPORTS) == names
