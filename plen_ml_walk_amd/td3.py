@@ -260,7 +260,9 @@ class _FlatGrads(object):
 
     def all_reduce_mean(self):
         import torch.distributed as dist
-        if self.data_parallel and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # PLEN_TD3_FORCE_COLLECTIVES=1: issue the collective at world size 1 too (one-GPU boxes: exercises RCCL's init, stream ordering and
+        # graph capture on the real backend; the reduction of one rank is the identity)
+        if self.data_parallel and dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("PLEN_TD3_FORCE_COLLECTIVES") == "1"):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())
 
@@ -353,7 +355,9 @@ class TD3Agent(object):
 
     def _broadcast_parameters(self):
         import torch.distributed as dist
-        if self.data_parallel and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # PLEN_TD3_FORCE_COLLECTIVES=1: issue the collective at world size 1 too (one-GPU boxes: exercises RCCL's init, stream ordering and
+        # graph capture on the real backend; the reduction of one rank is the identity)
+        if self.data_parallel and dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("PLEN_TD3_FORCE_COLLECTIVES") == "1"):
             for p in list(self.actor.parameters()) + list(self.critic.parameters()):
                 dist.broadcast(p.data, src=0)
 

@@ -27,7 +27,9 @@ import torch
 def setup_distributed():
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not dist.is_initialized():
+    forced = os.environ.get("PLEN_TD3_FORCE_COLLECTIVES") == "1"          # a world-size-1 RCCL group (one-GPU boxes), see td3._FlatGrads
+    if (world > 1 or forced) and not dist.is_initialized():
+        os.environ.setdefault("MASTER_PORT", "29517"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # PLEN_DIST_BACKEND=gloo: development override (two ranks sharing ONE GPU cannot use RCCL; gloo moves CUDA tensors through the host)
         backend = os.environ.get("PLEN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -230,7 +232,8 @@ class GraphedVecTD3Trainer(object):
         n = env.num_envs
         self.n = n
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        self.allreduce_mode = None if self.world == 1 else ("captured" if os.environ.get("PLEN_TD3_CAPTURE_ALLREDUCE") == "1" else "eager-between-graphs")
+        self.collectives = self.world > 1 or (dist.is_available() and dist.is_initialized() and os.environ.get("PLEN_TD3_FORCE_COLLECTIVES") == "1")
+        self.allreduce_mode = None if not self.collectives else ("captured" if os.environ.get("PLEN_TD3_CAPTURE_ALLREDUCE") == "1" else "eager-between-graphs")
         torch.manual_seed(seed)
         # capturable Adam (step counters on device) that CONTINUES the agent's optimisers: same lr/betas/eps, moments and step counts
         # carried over (a resumed run must not restart Adam)
@@ -288,9 +291,9 @@ class GraphedVecTD3Trainer(object):
 
         def update(with_policy):                       # one rank, or collectives captured: the whole iteration in one graph
             if fz is not None:
-                loss = fz.update(replay.data, batch_size, with_policy, all_reduce=self.world > 1, total=self.total_t)
+                loss = fz.update(replay.data, batch_size, with_policy, all_reduce=self.collectives, total=self.total_t)
             else:
-                loss = T.td3_update(agent, sample(), with_policy, all_reduce=self.world > 1)
+                loss = T.td3_update(agent, sample(), with_policy, all_reduce=self.collectives)
             self._critic_loss.copy_(loss)
 
         # --- segments for eager collectives between graph replays (world > 1) ---
@@ -365,7 +368,7 @@ class GraphedVecTD3Trainer(object):
         g.replay()                                   # the capture itself does not execute
 
     def _update(self, with_policy):
-        if self.world == 1 or self.allreduce_mode == "captured":
+        if not self.collectives or self.allreduce_mode == "captured":
             self._run(("update", with_policy), self._update_fn, with_policy)
             return
         a, b, c = self._segs
@@ -418,7 +421,8 @@ class PipelinedVecTD3Trainer(object):
         from .td3_fused import FusedTD3
         assert len(envs) >= 2 and all(e.num_envs == envs[0].num_envs for e in envs) and agent.device.type == "cuda"
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        self.allreduce_mode = None if self.world == 1 else "eager-between-graphs"
+        self.collectives = self.world > 1 or (dist.is_available() and dist.is_initialized() and os.environ.get("PLEN_TD3_FORCE_COLLECTIVES") == "1")
+        self.allreduce_mode = None if not self.collectives else "eager-between-graphs"
         self.envs, self.agent, self.replay = envs, agent, replay
         self.nh = envs[0].num_envs
         self.H = len(envs)                     # sub-batches ("halves" in the comments: 2 is the measured best, bench.py / DESIGN.md section 10)
@@ -543,7 +547,7 @@ class PipelinedVecTD3Trainer(object):
                 su.wait_event(ev)
         if learn:
             with_policy = (self.grad_steps + 1) % self.agent.policy_freq == 0
-            if self.world == 1:
+            if not self.collectives:
                 self._run(("update", with_policy, (t + 1) % 3), su, self._update, with_policy, (t + 1) % 3)
             else:
                 self._run(("critic_backward",), su, self._seg_critic_backward)

@@ -481,21 +481,22 @@ def test_mfma_weight_gradient_kernel(B, N, K):
     assert float((gb.double() - want_b).abs().max()) <= 2e-5 * float(want_b.abs().max()) + 1e-4
 
 
-def test_pipelined_trainer_overlaps_without_races():
-    """PipelinedVecTD3Trainer (two half batches + the fused update on three streams, event dependencies only): counters, ring contents and
+@pytest.mark.parametrize("n,T,batch", [(512, 45, 512), (4096, 64, 4096)])
+def test_pipelined_trainer_overlaps_without_races(n, T, batch):
+    """(n = 4096, batch 4096: BASELINE.json configs[2] at full size -- 2 x 2048 envs + the whole TD3 loop, 64 vector steps.)
+    PipelinedVecTD3Trainer (two half batches + the fused update on three streams, event dependencies only): counters, ring contents and
     ORDER are those of the synchronous loop -- every stored transition's next_state is the state stored one vector step later for the same
     env (unless its episode ended), which a torn or misplaced row would break; losses finite.  The collection side is bitwise reproducible
     (checked with learning off); the learner's float-atomic reductions (k_wgrad, k_colsum) are order-dependent in the last bits, like any
     split-K GEMM, so a learning run is not."""
     from plen_ml_walk_amd.td3 import ReplayBuffer, TD3Agent
     from plen_ml_walk_amd.train_vec import PipelinedVecTD3Trainer
-    n, T = 512, 45
     runs = []
     for start in (3 * n, 10 ** 9, 10 ** 9):
         torch.manual_seed(0)
         envs = [_env(n // 2), _env(n // 2)]
         agent = TD3Agent(26, 18, 1.0); replay = ReplayBuffer(40 * n)        # the ring wraps during the run: the sampling guard is exercised
-        tr = PipelinedVecTD3Trainer(envs, agent, replay, start_timesteps=start, batch_size=512, seed=7)
+        tr = PipelinedVecTD3Trainer(envs, agent, replay, start_timesteps=start, batch_size=batch, seed=7)
         for _ in range(T):
             tr.step()
         tr.sync(); torch.cuda.synchronize()
@@ -507,10 +508,10 @@ def test_pipelined_trainer_overlaps_without_races():
         assert torch.isfinite(d).all() and ((d[:, 71] == 0) | (d[:, 71] == 1)).all()
         if learning:
             assert torch.isfinite(agent.last_critic_loss) and float(agent.last_critic_loss) > 0
-        # continuity: rows of steps 10..38 (not overwritten by the wrap: steps 40..44 overwrote rows of steps 0..4)
+        # continuity: rows of steps T-35..T-7 (the ring holds the last 40 vector steps; the wrap is inside the checked range at T = 64)
         ok = tot = 0
-        for t in range(10, 38):
-            a, b = d[t * n:(t + 1) * n], d[(t + 1) * n:(t + 2) * n]
+        for t in range(T - 35, T - 7):
+            a, b = d[(t % 40) * n:(t % 40 + 1) * n], d[((t + 1) % 40) * n:((t + 1) % 40 + 1) * n]
             same = (a[:, 44:70] == b[:, 0:26]).all(1)
             tot += n; ok += int(same.sum())
             ended = ~same
@@ -638,3 +639,30 @@ def test_episode_statistics_survive_long_runs():
     torch.cuda.synchronize()
     d = (stats - s0).tolist()
     assert d == [5 * 0.25, 5.0, 5.0], d
+
+
+def test_rccl_world_size_one_runs_the_multi_rank_code_path(tmp_path):
+    """RCCL on the hardware there is: one rank, backend nccl, device_id given; with PLEN_TD3_FORCE_COLLECTIVES=1 both
+    trainers cut their update at the two gradient all-reduces (eager between graph segments) or capture them (PLEN_TD3_CAPTURE_ALLREDUCE=1).
+    One rank's reduction is the identity: the synchronous graph trainer on the autograd update (deterministic library GEMMs) ends bitwise where the
+    collective-free run ends; the fused update's float-atomic weight gradients are reproducible to rounding only."""
+    import json, socket, subprocess, sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "rccl.json")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_world1_worker.py"), out], check=True, timeout=900, env=env, cwd=ROOT)
+    r = json.load(open(out))
+    assert r["backend"] == "nccl" and r["world"] == 1
+    g, p, c = r["graphed"], r["pipelined"], r["graphed_captured"]
+    assert g["collectives"] and g["allreduce_mode"] == "eager-between-graphs" and any("critic_backward" in k for k in g["graphs"]) and any("actor_step" in k for k in g["graphs"])
+    assert g["finite"] and g["max_abs_param_diff_vs_no_collectives"] < 1e-3 and g["grad_steps"] == 13
+    ga = r["graphed_autograd"]
+    assert ga["collectives"] and ga["finite"] and ga["max_abs_param_diff_vs_no_collectives"] == 0.0 and ga["grad_steps"] == 13
+    assert c["allreduce_mode"] == "captured" and c["finite"] and c["max_abs_param_diff_vs_no_collectives"] < 1e-3
+    assert p["collectives"] and p["allreduce_mode"] == "eager-between-graphs" and p["finite"] and p["grad_steps"] == 22
+    assert p["max_abs_param_diff_vs_no_collectives"] < 1e-2          # (the pipelined learner's float atomics are not bitwise reproducible)
+    lat = r["allreduce_latency_620KB"]
+    assert lat["alone"]["device_us_per_call"] < 500 and lat["beside_two_resident_2048_env_launches"]["device_us_per_call"] < 5000
+    dst = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(dst):
+        json.dump(r, open(os.path.join(dst, "r03_rccl_world1.json"), "w"), indent=1)
