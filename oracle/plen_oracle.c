@@ -7,10 +7,14 @@
  *   compute_reward (:873-1070), compute_done (:1072-1093),
  * including what `p.stepSimulation()` (:667) does inside the third-party `pybullet` module.
  *
- * PARITY UNPINNED for the physics: pybullet / Bullet is NOT vendored by the reference, NOT version
- * pinned (no requirements file) and NOT installed in the build container, and the reference has no
- * tests or golden vectors for it.  The physics below restates Bullet's published multibody
- * algorithm (era ~2.89, early 2020) as documented in DESIGN.md section "Oracle":
+ * PHYSICS PARITY: PARTIAL.  pybullet / Bullet is NOT vendored by the reference, NOT version pinned (no requirements file) and NOT
+ * installed on any machine this was built or run on, and the reference has no tests or golden vectors for it, so the physics below cannot
+ * be compared with PyBullet output component by component.  What pins it (round 3, tests/pybullet_pin.py, tests/test_pybullet_pin.py): the
+ * reference's recorded command log trajectories/<joint>_cmd.npy is the shipped actor's deterministic output along a PyBullet episode,
+ * a_t = actor_3229999(obs_t^PyBullet), i.e. 500 x 18 equations on PyBullet's own observations: this oracle's reset observation satisfies
+ * them to observation errors of ~1e-4 and its observation after one full-range control step to a few 1e-3, and every Bullet default
+ * assumed below is a sharp optimum of those residuals (profiles/r03_hypothesis_ablation.json).  The physics
+ * restates Bullet's published multibody algorithm (era ~2.89, early 2020) as documented in DESIGN.md section "Oracle":
  *   btMultiBody::computeAccelerationsArticulatedBodyAlgorithmMultiDof  (Featherstone ABA, explicit
  *       gyroscopic term, semi-implicit Euler: v += dt*a before the constraint solve),
  *   btMultiBody::calcAccelerationDeltasMultiDof                         (unit-impulse response),
@@ -625,6 +629,15 @@ static void collide(Oracle *o) {
                 }
             }
         }
+        /* both feet fully planted (all 8 slots hold foot points) and another link near the ground: each foot gives up the slot of its FOURTH
+         * point -- a flat foot stands on three corners as well, and its occupied slots stay a prefix -- so that the link that touches down
+         * (a hand pressed to the floor while standing) is held up too.  Bullet keeps every manifold; this is the 8-slot layout's way of never
+         * leaving a touching link without a contact (round 3; before, such corners were dropped). */
+        int released = 0;
+        if (ncand > 0) {
+            int all = 1; for (int c = 0; c < MAXCP; c++) all = all && slot_used[c];
+            if (all) { slot_used[3] = slot_used[7] = 0; released = 1; }        /* slot[3], slot[7] keep the foot points: a released slot nobody takes gets its point back */
+        }
         /* deepest first (ties: candidate id) into the free slots in slot order */
         for (int i = 1; i < ncand; i++) { BoxCand k = cand[i]; int j = i - 1; while (j >= 0 && cand_less(&k, &cand[j])) { cand[j + 1] = cand[j]; j--; } cand[j + 1] = k; }
         int next = 0;
@@ -635,7 +648,9 @@ static void collide(Oracle *o) {
             v3cpy(slot[c].pos, q->pos);
             slot[c].mu = o->w.box_lateral_friction;
             slot[c].rest = (real)RAW_BOX_LINK_RESTITUTION[q->box] * (real)0.5;      /* x plane restitution 0.5 (plen_env.py:309) */
+            slot_used[c] = 1;
         }
+        (void)released;              /* an untaken released slot still holds its foot point (slot[c].used stayed 1) */
     }
     for (int c = 0; c < MAXCP; c++) {
         if (!slot[c].used) continue;

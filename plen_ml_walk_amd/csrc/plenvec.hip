@@ -226,6 +226,26 @@ __device__ __forceinline__ float wrlane(float dst, float val, int lane) {
 }
 // f64: two v_writelane_b32 on the halves (val is wave-uniform: it comes from a v_readlane broadcast).  The former `lane == L ? val : dst`
 // cost a v_mov + v_cndmask per half AND one live 64-bit lane mask per row, i.e. ~50 SGPR pairs held (and spilled) across the solver loop.
+// f64 commit of the wave-uniform `val` into lane L of `dst`: ONE v_mov_b64 under an EXEC mask of that lane.  The f64 kernel runs 2 waves per SIMD
+// and is bound by the VALU issue port (a v_writelane_b32 costs the port about as much as a v_fma_f64, profiles/r02_valu_issue.txt), while its
+// scalar unit idles: two v_writelane_b32 (+ their wait states) become one vector move, the EXEC writes ride on the scalar port.  (PLENVEC_F64_WRITELANE
+// keeps the former two-v_writelane form for A/B runs.)  The rows that use it sit in wave-uniform control flow; EXEC is saved and restored anyway.
+#ifndef PLENVEC_F64_WRITELANE
+template <int L>
+__device__ __forceinline__ double wrlane(double dst, double val, int lane) {
+    (void)lane;
+    unsigned long long keep;
+    const long long v = __builtin_bit_cast(long long, val);
+    const long long sv = ((long long)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffLL));
+    if constexpr (L < 32)
+        asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %3\n\tv_mov_b64 %0, %2\n\ts_mov_b64 exec, %1" : "+v"(dst), "=&s"(keep) : "s"(sv), "n"(1u << (L & 31)));
+    else
+        asm volatile("s_mov_b64 %1, exec\n\ts_mov_b32 exec_lo, 0\n\ts_mov_b32 exec_hi, %3\n\tv_mov_b64 %0, %2\n\ts_mov_b64 exec, %1" : "+v"(dst), "=&s"(keep) : "s"(sv), "n"(1u << (L & 31)));
+    return dst;
+}
+template <int L>
+__device__ __forceinline__ double wrlane_late(double dst, double val) { return wrlane<L>(dst, val, 0); }
+#else
 template <int L>
 __device__ __forceinline__ double wrlane(double dst, double val, int lane) {
     (void)lane;
@@ -235,9 +255,6 @@ __device__ __forceinline__ double wrlane(double dst, double val, int lane) {
     asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4" : "+v"(lo), "+v"(hi) : "s"(slo), "s"(shi), "i"(L));
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
-// f64 rows: the commit placed AFTER the row's fma in program order.  The next row's clamp waits for that fma anyway (e is the dependent chain),
-// so the two v_writelane fill its latency instead of sitting -- with their wait states -- between the broadcast and the fma.  One wait state
-// is left of the VALU-wrote-SGPR -> v_writelane hazard (the fma has issued in between).
 template <int L>
 __device__ __forceinline__ double wrlane_late(double dst, double val) {
     const long long d = __builtin_bit_cast(long long, dst), v = __builtin_bit_cast(long long, val);
@@ -246,6 +263,7 @@ __device__ __forceinline__ double wrlane_late(double dst, double val) {
     asm volatile("s_nop 0\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4" : "+v"(lo), "+v"(hi) : "s"(slo), "s"(shi), "i"(L));
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
+#endif
 // d = clamp(-e, lo, hi) of a solver row.  f64: written as the two instructions it is.  From fmin(fmax(-e, lo), hi) the compiler makes three wherever it
 // cannot prove e free of signalling NaNs (after every asm / scheduling barrier, i.e. in every contact row): a canonicalising v_max_f64 x, x, x first,
 // one more dependent f64 instruction per row of a latency-bound chain (122 of them in the solver loop).
@@ -1374,7 +1392,16 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             near_l = zmin <= bx[15];
         }
         const unsigned near = (unsigned)__ballot(near_l);           // boxes 0..30
-        if (near != 0u && act != 0xffu) box_contacts(s, P, lane, near, act, lent, is_lin, pf, pk, pax, p, O0, dist, Pw, rest_l, mu_l);
+        if (near != 0u) {
+            // Both feet fully planted (8 foot points) AND another link near the ground: each foot gives up the slot of its FOURTH point (a flat foot
+            // stands on three corners as well; the occupied slots of a foot stay a prefix), so that the link that touches down -- a hand pressed to
+            // the floor while standing -- is held up too instead of being dropped (round 3).  A released slot nobody takes keeps its foot point:
+            // its port lanes still hold that point's Jacobian.
+            const unsigned released = act == 0xffu ? 0x88u : 0u;
+            act &= ~released;
+            box_contacts(s, P, lane, near, act, lent, is_lin, pf, pk, pax, p, O0, dist, Pw, rest_l, mu_l);
+            act |= released;
+        }
     }
     lent_out = lent | (act << 8);          // bits 0-7: slots lent to box corners, bits 8-15: slots holding a contact point
     WSYNC();

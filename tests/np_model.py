@@ -251,6 +251,13 @@ def port_jacobians(kin, pos, body_contacts=True):
     slots = [dict(kind="foot", f=c // 4, k=c % 4) if foot_active[c // 4, c % 4] else None for c in range(8)]
     if body_contacts:
         cands = box_candidates(kin)
+        if cands and all(sl is not None for sl in slots):
+            # both feet fully planted (8 foot points) AND another link near the ground: each foot gives up the slot of its fourth point
+            # (a flat foot stands on three corners as well) so that the link that touches down is held up too (round 3)
+            keep = {3: slots[3], 7: slots[7]}
+            slots[3] = slots[7] = None
+        else:
+            keep = {}
         for c in range(8):
             if slots[c] is None and cands:
                 d_, _, box, b, P = cands.pop(0)
@@ -264,6 +271,9 @@ def port_jacobians(kin, pos, body_contacts=True):
                     J[row, 3:6] = ax
                     for bb in ancestors(b):
                         J[row, 5 + bb] = A[bb] @ np.cross(P - O[bb], ax)
+        for c, sl in keep.items():           # a released slot nobody took keeps its foot point (rows, position and distance are still the foot's)
+            if slots[c] is None:
+                slots[c] = sl
     return J, pts, dist, slots
 
 

@@ -145,3 +145,58 @@ def test_body_contacts_off_reproduces_the_feet_only_model():
         ref = np.array([want[i][t] for i in range(n)])
         assert np.abs(ob.cpu().numpy() - ref).max() <= 1e-6
     env.close()
+
+
+# both feet flat on the ground (8 foot points) AND the right hand's box on the floor: found by a least-squares search over the joint angles,
+# base pitch / roll and height (sole vertices and the hand's lowest corner 0.3 mm inside the ground); joints within +-1.6 rad
+HAND_DOWN_STATE = [0.0, 0.0, 0.089671, 0.25096, 0.458035, -0.136556, 0.841769, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, -0.262156, 0.382294, -0.594681, 1.194079,
+                   -0.552259, 0.236333, 0.403619, -0.007623, 0.459387, -1.1328, 0.286389, 0.643254, 0.863805, 0.32101, -0.210111] + [0.0] * 21
+R_HAND_BOX = 24
+
+
+def _hand_low(state):
+    R, O, _, _ = nm.fk(state[0:3], state[3:7], state[13:31])
+    x = nm.BOXES[R_HAND_BOX]; b = x["body"]; h = np.array(x["half"])
+    return min((O[b] + R[b] @ (np.array(x["t_body"]) + np.array(x["R_body"]) @ np.array([h[0] if cn & 1 else -h[0], h[1] if cn & 2 else -h[1], h[2] if cn & 4 else -h[2]])))[2]
+               for cn in range(8))
+
+
+def test_both_feet_flat_and_a_hand_pressed_to_the_ground():
+    """VERDICT r02 item 6 (the 8-slot cap): with both feet fully planted (8 foot points) a hand on the ground used to get NO contact.  Now each
+    foot gives up the slot of its fourth point while another link is near the ground: the hand's corner takes slot 3, the left foot keeps its
+    four points (nobody took slot 7), kernel = oracle on the slot masks and on the state (1e-9 with 3 iterations), and the hand CARRIES LOAD:
+    pressed down by its shoulder motor for 0.2 s it stays on the floor, while with body_contacts = 0 it sinks centimetres into it."""
+    s0 = np.array(HAND_DOWN_STATE)
+    tgt = s0[13:31].copy(); tgt[12] += 0.5                                       # the shoulder pushes the arm down
+    o = OracleEnv(); o.set_state(s0)
+    own, _ = o.contact_slots(run_collide=True)
+    assert own.tolist() == [-1, -1, -1, R_HAND_BOX, -1, -1, -1, -1]
+    # one substep, 3 and 50 iterations, kernel vs oracle: slot masks and state
+    for nit, tol in ((3, 1e-9), (50, 1e-6)):
+        env = _env(2, torch.float64, auto_reset=False, cfg_overrides=dict(rolling_friction=0.0, num_iterations=nit))
+        env.set_state(torch.as_tensor(np.tile(s0, (2, 1))))
+        env.debug_substeps(torch.as_tensor(np.tile(tgt, (2, 1))), 1)
+        got = env.get_state().cpu().numpy(); aux = env.get_aux().cpu().numpy()
+        o = OracleEnv(); o.set_friction(rolling=0.0); o.set_world(num_iterations=nit)
+        o.set_state(s0); o.set_targets(tgt); o.substep()
+        own, _ = o.contact_slots()
+        assert own.tolist() == [-1, -1, -1, R_HAND_BOX, -1, -1, -1, -1]
+        assert aux[0, 7] == ((1 << 3) | (0xff << 8)), hex(aux[0, 7])
+        assert aux[0, 4] == 1 and aux[0, 5] == 1                                 # contact flags are the feet's, unchanged
+        assert np.abs(got[0] - o.get_state()).max() <= tol, (nit, np.abs(got[0] - o.get_state()).max())
+        env.close()
+    # 48 substeps of pressing: held up with the box contacts, sunk without
+    low = {}
+    for bc in (1, 0):
+        env = _env(2, torch.float64, auto_reset=False, cfg_overrides=dict(rolling_friction=0.0, body_contacts=bc))
+        env.set_state(torch.as_tensor(np.tile(s0, (2, 1))))
+        env.debug_substeps(torch.as_tensor(np.tile(tgt, (2, 1))), 48)
+        st = env.get_state().cpu().numpy()[0]
+        assert np.isfinite(st).all()
+        low[bc] = _hand_low(st)
+        env.close()
+    assert low[1] > -0.001 and low[0] < -0.02, low
+    o = OracleEnv(); o.set_friction(rolling=0.0); o.set_state(s0); o.set_targets(tgt)
+    for _ in range(48):
+        o.substep()
+    assert abs(_hand_low(o.get_state()) - low[1]) < 1e-3
