@@ -228,9 +228,11 @@ __device__ __forceinline__ float wrlane(float dst, float val, int lane) {
 // cost a v_mov + v_cndmask per half AND one live 64-bit lane mask per row, i.e. ~50 SGPR pairs held (and spilled) across the solver loop.
 // f64 commit of the wave-uniform `val` into lane L of `dst`: ONE v_mov_b64 under an EXEC mask of that lane.  The f64 kernel runs 2 waves per SIMD
 // and is bound by the VALU issue port (a v_writelane_b32 costs the port about as much as a v_fma_f64, profiles/r02_valu_issue.txt), while its
-// scalar unit idles: two v_writelane_b32 (+ their wait states) become one vector move, the EXEC writes ride on the scalar port.  (PLENVEC_F64_WRITELANE
-// keeps the former two-v_writelane form for A/B runs.)  The rows that use it sit in wave-uniform control flow; EXEC is saved and restored anyway.
-#ifndef PLENVEC_F64_WRITELANE
+// scalar unit idles: two v_writelane_b32 (+ their wait states) become one vector move, the EXEC writes ride on the scalar port.
+// MEASURED (round 3, scripts/gpu_ab64.py, same box): SLOWER, 4.99 against 5.26 M env-steps/s -- three scalar instructions and two EXEC writes per row
+// lengthen the wave's own dependent chain by more than the saved vector slot is worth: at 2 waves per SIMD the f64 kernel is bound by per-wave latency,
+// not by the VALU port.  Kept behind -DPLENVEC_F64_EXEC_COMMIT as the record of that experiment; the product build uses the v_writelane pair below.
+#ifdef PLENVEC_F64_EXEC_COMMIT
 template <int L>
 __device__ __forceinline__ double wrlane(double dst, double val, int lane) {
     (void)lane;
@@ -386,6 +388,30 @@ __host__ __device__ constexpr int lane_of_port(int p) {
 __device__ __forceinline__ unsigned absbits(float x) { return __builtin_bit_cast(unsigned, x) & 0x7fffffffu; }
 __device__ __forceinline__ unsigned absbits(double x) { return __builtin_bit_cast(unsigned, (float)x) & 0x7fffffffu; }
 
+
+// One f64 solver row as a hand-written block (FAST path): the hi half of the commit sits in the wait states between the v_readlane pair and the
+// v_fmac_f64 that reads the SGPR pair, the lo half right after the v_fmac (in the latency shadow of the next row's clamp): 7 VALU + 2 waits
+// instead of 7 VALU + 4.  Same operations on the same values as the compiler path.  (-DPLENVEC_F64_ROW_LATE keeps the former layout for A/B.)
+template <int L>
+__device__ __forceinline__ void f64_row_asm(double &e, const double lo, const double hi, double &dvec, const double acol) {
+    const long long dvb = __builtin_bit_cast(long long, dvec);
+    int dlo = (int)(dvb & 0xffffffffLL), dhi = (int)(dvb >> 32);
+    asm volatile(
+        "v_max_f64 v[0:1], -%[e], %[lo]\n\t"
+        "v_min_f64 v[0:1], v[0:1], %[hi]\n\t"
+        "s_nop 0\n\t"
+        "v_readlane_b32 s5, v1, %[pp]\n\t"
+        "v_readlane_b32 s4, v0, %[pp]\n\t"
+        "s_nop 0\n\t"
+        "v_writelane_b32 %[dhi], s5, %[pp]\n\t"
+        "v_fmac_f64 %[e], s[4:5], %[a]\n\t"
+        "v_writelane_b32 %[dlo], s4, %[pp]\n\t"
+        : [e] "+v"(e), [dlo] "+v"(dlo), [dhi] "+v"(dhi)
+        : [lo] "v"(lo), [hi] "v"(hi), [a] "v"(acol), [pp] "i"(L)
+        : "v0", "v1", "s4", "s5");
+    dvec = __builtin_bit_cast(double, ((long long)dhi << 32) | (unsigned int)dlo);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Projected Gauss-Seidel rows in port space.  Per lane (= port) the solver keeps
 //     e   = (J_port * deltaV) - rv      rv = the row's velocity-level right-hand side (Bullet's m_rhs / jacDiagABInv)
@@ -415,7 +441,11 @@ __device__ __forceinline__ void pgs_row2d(real &e, const real blo, const real bh
             "v_fmac_f32 %[e], %[sd], %[a]\n\t"
             : [d] "=&v"(d), [sd] "=&s"(sd), [dv] "+v"(dvec), [e] "+v"(e)
             : [blo] "v"(blo), [bhi] "v"(bhi), [a] "v"(acol), [pp] "i"(lane_of_port(PP)));
-    } else {
+    }
+#ifndef PLENVEC_F64_ROW_LATE
+    else if constexpr (FAST && sizeof(real) == 8) f64_row_asm<lane_of_port(PP)>(e, blo, bhi, dvec, acol);
+#endif
+    else {
 #pragma clang fp contract(off)
         const real d = clamp_neg(e, blo, bhi);
         const real db = bcast(d, lane_of_port(PP));
@@ -633,6 +663,317 @@ __device__ __forceinline__ void pgs_motor_pass(real &e, const real blo, const re
             : [d] "=&v"(d), [sA] "=&s"(sA), [sB] "=&s"(sB), [dv] "+v"(dvec), [e] "+v"(e)
             : [blo] "v"(blo), [bhi] "v"(bhi), [a0] "v"(Ar[0]), [a1] "v"(Ar[1]), [a2] "v"(Ar[2]), [a3] "v"(Ar[3]), [a4] "v"(Ar[4]), [a5] "v"(Ar[5]), [a6] "v"(Ar[6]), [a7] "v"(Ar[7]), [a8] "v"(Ar[8]), [a9] "v"(Ar[9]), [a10] "v"(Ar[10]), [a11] "v"(Ar[11]), [a12] "v"(Ar[12]), [a13] "v"(Ar[13]), [a14] "v"(Ar[14]), [a15] "v"(Ar[15]), [a16] "v"(Ar[16]), [a17] "v"(Ar[17]));
         }
+    } else if constexpr (FAST && sizeof(real) == 8) {
+        // f64: the same software pipeline as the f32 block above (generated text: rows in NC_ORDER, SGPR pairs s[4:5] / s[38:39] alternating, the
+        // clamp's result in v[0:1]).  The two v_writelane_b32 that commit row i-1 sit in the wait states of row i -- one after its v_min_f64 (VALU
+        // wrote the VGPR the v_readlane reads), one in the two wait states between the v_readlane and the v_fmac_f64 that reads the SGPR pair --
+        // so a row is 7 VALU + 1 wait instead of 7 VALU + 4 waits on the wave's dependent chain; same operations on the same values as the
+        // compiler path (bit-identical, tests/test_env_gpu.py::test_asm_path_bitwise_equals_compiler_path).  dvec travels as two 32-bit halves.
+        static_assert(NC_ORDER[0] == 6 && NC_ORDER[8] == 2 && NC_ORDER[9] == 15 && NC_ORDER[17] == 11, "the lane numbers in the asm below are NC_ORDER_LIST written out");
+        const long long dvb = __builtin_bit_cast(long long, dvec);
+        int dlo = (int)(dvb & 0xffffffffLL), dhi = (int)(dvb >> 32);
+        if constexpr (!REV) {
+            asm volatile(
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "s_nop 0\n\t"
+            "v_readlane_b32 s5, v1, 6\n\t"
+            "v_readlane_b32 s4, v0, 6\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f64 %[e], s[4:5], %[a6]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s4, 6\n\t"
+            "v_readlane_b32 s39, v1, 5\n\t"
+            "v_readlane_b32 s38, v0, 5\n\t"
+            "v_writelane_b32 %[dhi], s5, 6\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[38:39], %[a5]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s38, 5\n\t"
+            "v_readlane_b32 s5, v1, 8\n\t"
+            "v_readlane_b32 s4, v0, 8\n\t"
+            "v_writelane_b32 %[dhi], s39, 5\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[4:5], %[a8]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s4, 8\n\t"
+            "v_readlane_b32 s39, v1, 7\n\t"
+            "v_readlane_b32 s38, v0, 7\n\t"
+            "v_writelane_b32 %[dhi], s5, 8\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[38:39], %[a7]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s38, 7\n\t"
+            "v_readlane_b32 s5, v1, 4\n\t"
+            "v_readlane_b32 s4, v0, 4\n\t"
+            "v_writelane_b32 %[dhi], s39, 7\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[4:5], %[a4]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s4, 4\n\t"
+            "v_readlane_b32 s39, v1, 1\n\t"
+            "v_readlane_b32 s38, v0, 1\n\t"
+            "v_writelane_b32 %[dhi], s5, 4\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[38:39], %[a1]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s38, 1\n\t"
+            "v_readlane_b32 s5, v1, 0\n\t"
+            "v_readlane_b32 s4, v0, 0\n\t"
+            "v_writelane_b32 %[dhi], s39, 1\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[4:5], %[a0]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s4, 0\n\t"
+            "v_readlane_b32 s39, v1, 3\n\t"
+            "v_readlane_b32 s38, v0, 3\n\t"
+            "v_writelane_b32 %[dhi], s5, 0\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[38:39], %[a3]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s38, 3\n\t"
+            "v_readlane_b32 s5, v1, 2\n\t"
+            "v_readlane_b32 s4, v0, 2\n\t"
+            "v_writelane_b32 %[dhi], s39, 3\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[4:5], %[a2]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s4, 2\n\t"
+            "v_readlane_b32 s39, v1, 15\n\t"
+            "v_readlane_b32 s38, v0, 15\n\t"
+            "v_writelane_b32 %[dhi], s5, 2\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[38:39], %[a15]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s38, 15\n\t"
+            "v_readlane_b32 s5, v1, 14\n\t"
+            "v_readlane_b32 s4, v0, 14\n\t"
+            "v_writelane_b32 %[dhi], s39, 15\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[4:5], %[a14]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s4, 14\n\t"
+            "v_readlane_b32 s39, v1, 17\n\t"
+            "v_readlane_b32 s38, v0, 17\n\t"
+            "v_writelane_b32 %[dhi], s5, 14\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[38:39], %[a17]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s38, 17\n\t"
+            "v_readlane_b32 s5, v1, 16\n\t"
+            "v_readlane_b32 s4, v0, 16\n\t"
+            "v_writelane_b32 %[dhi], s39, 17\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[4:5], %[a16]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s4, 16\n\t"
+            "v_readlane_b32 s39, v1, 13\n\t"
+            "v_readlane_b32 s38, v0, 13\n\t"
+            "v_writelane_b32 %[dhi], s5, 16\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[38:39], %[a13]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s38, 13\n\t"
+            "v_readlane_b32 s5, v1, 10\n\t"
+            "v_readlane_b32 s4, v0, 10\n\t"
+            "v_writelane_b32 %[dhi], s39, 13\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[4:5], %[a10]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s4, 10\n\t"
+            "v_readlane_b32 s39, v1, 9\n\t"
+            "v_readlane_b32 s38, v0, 9\n\t"
+            "v_writelane_b32 %[dhi], s5, 10\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[38:39], %[a9]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s38, 9\n\t"
+            "v_readlane_b32 s5, v1, 12\n\t"
+            "v_readlane_b32 s4, v0, 12\n\t"
+            "v_writelane_b32 %[dhi], s39, 9\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[4:5], %[a12]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s4, 12\n\t"
+            "v_readlane_b32 s39, v1, 11\n\t"
+            "v_readlane_b32 s38, v0, 11\n\t"
+            "v_writelane_b32 %[dhi], s5, 12\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[38:39], %[a11]\n\t"
+            "v_writelane_b32 %[dlo], s38, 11\n\t"
+            "v_writelane_b32 %[dhi], s39, 11\n\t"
+            : [e] "+v"(e), [dlo] "+v"(dlo), [dhi] "+v"(dhi)
+            : [blo] "v"(blo), [bhi] "v"(bhi), [a0] "v"(Ar[0]), [a1] "v"(Ar[1]), [a2] "v"(Ar[2]), [a3] "v"(Ar[3]), [a4] "v"(Ar[4]), [a5] "v"(Ar[5]), [a6] "v"(Ar[6]), [a7] "v"(Ar[7]), [a8] "v"(Ar[8]), [a9] "v"(Ar[9]), [a10] "v"(Ar[10]), [a11] "v"(Ar[11]), [a12] "v"(Ar[12]), [a13] "v"(Ar[13]), [a14] "v"(Ar[14]), [a15] "v"(Ar[15]), [a16] "v"(Ar[16]), [a17] "v"(Ar[17])
+            : "v0", "v1", "s4", "s5", "s38", "s39");
+        } else {
+            asm volatile(
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "s_nop 0\n\t"
+            "v_readlane_b32 s5, v1, 11\n\t"
+            "v_readlane_b32 s4, v0, 11\n\t"
+            "s_nop 1\n\t"
+            "v_fmac_f64 %[e], s[4:5], %[a11]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s4, 11\n\t"
+            "v_readlane_b32 s39, v1, 12\n\t"
+            "v_readlane_b32 s38, v0, 12\n\t"
+            "v_writelane_b32 %[dhi], s5, 11\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[38:39], %[a12]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s38, 12\n\t"
+            "v_readlane_b32 s5, v1, 9\n\t"
+            "v_readlane_b32 s4, v0, 9\n\t"
+            "v_writelane_b32 %[dhi], s39, 12\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[4:5], %[a9]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s4, 9\n\t"
+            "v_readlane_b32 s39, v1, 10\n\t"
+            "v_readlane_b32 s38, v0, 10\n\t"
+            "v_writelane_b32 %[dhi], s5, 9\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[38:39], %[a10]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s38, 10\n\t"
+            "v_readlane_b32 s5, v1, 13\n\t"
+            "v_readlane_b32 s4, v0, 13\n\t"
+            "v_writelane_b32 %[dhi], s39, 10\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[4:5], %[a13]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s4, 13\n\t"
+            "v_readlane_b32 s39, v1, 16\n\t"
+            "v_readlane_b32 s38, v0, 16\n\t"
+            "v_writelane_b32 %[dhi], s5, 13\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[38:39], %[a16]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s38, 16\n\t"
+            "v_readlane_b32 s5, v1, 17\n\t"
+            "v_readlane_b32 s4, v0, 17\n\t"
+            "v_writelane_b32 %[dhi], s39, 16\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[4:5], %[a17]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s4, 17\n\t"
+            "v_readlane_b32 s39, v1, 14\n\t"
+            "v_readlane_b32 s38, v0, 14\n\t"
+            "v_writelane_b32 %[dhi], s5, 17\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[38:39], %[a14]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s38, 14\n\t"
+            "v_readlane_b32 s5, v1, 15\n\t"
+            "v_readlane_b32 s4, v0, 15\n\t"
+            "v_writelane_b32 %[dhi], s39, 14\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[4:5], %[a15]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s4, 15\n\t"
+            "v_readlane_b32 s39, v1, 2\n\t"
+            "v_readlane_b32 s38, v0, 2\n\t"
+            "v_writelane_b32 %[dhi], s5, 15\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[38:39], %[a2]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s38, 2\n\t"
+            "v_readlane_b32 s5, v1, 3\n\t"
+            "v_readlane_b32 s4, v0, 3\n\t"
+            "v_writelane_b32 %[dhi], s39, 2\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[4:5], %[a3]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s4, 3\n\t"
+            "v_readlane_b32 s39, v1, 0\n\t"
+            "v_readlane_b32 s38, v0, 0\n\t"
+            "v_writelane_b32 %[dhi], s5, 3\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[38:39], %[a0]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s38, 0\n\t"
+            "v_readlane_b32 s5, v1, 1\n\t"
+            "v_readlane_b32 s4, v0, 1\n\t"
+            "v_writelane_b32 %[dhi], s39, 0\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[4:5], %[a1]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s4, 1\n\t"
+            "v_readlane_b32 s39, v1, 4\n\t"
+            "v_readlane_b32 s38, v0, 4\n\t"
+            "v_writelane_b32 %[dhi], s5, 1\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[38:39], %[a4]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s38, 4\n\t"
+            "v_readlane_b32 s5, v1, 7\n\t"
+            "v_readlane_b32 s4, v0, 7\n\t"
+            "v_writelane_b32 %[dhi], s39, 4\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[4:5], %[a7]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s4, 7\n\t"
+            "v_readlane_b32 s39, v1, 8\n\t"
+            "v_readlane_b32 s38, v0, 8\n\t"
+            "v_writelane_b32 %[dhi], s5, 7\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[38:39], %[a8]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s38, 8\n\t"
+            "v_readlane_b32 s5, v1, 5\n\t"
+            "v_readlane_b32 s4, v0, 5\n\t"
+            "v_writelane_b32 %[dhi], s39, 8\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[4:5], %[a5]\n\t"
+            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
+            "v_writelane_b32 %[dlo], s4, 5\n\t"
+            "v_readlane_b32 s39, v1, 6\n\t"
+            "v_readlane_b32 s38, v0, 6\n\t"
+            "v_writelane_b32 %[dhi], s5, 5\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64 %[e], s[38:39], %[a6]\n\t"
+            "v_writelane_b32 %[dlo], s38, 6\n\t"
+            "v_writelane_b32 %[dhi], s39, 6\n\t"
+            : [e] "+v"(e), [dlo] "+v"(dlo), [dhi] "+v"(dhi)
+            : [blo] "v"(blo), [bhi] "v"(bhi), [a0] "v"(Ar[0]), [a1] "v"(Ar[1]), [a2] "v"(Ar[2]), [a3] "v"(Ar[3]), [a4] "v"(Ar[4]), [a5] "v"(Ar[5]), [a6] "v"(Ar[6]), [a7] "v"(Ar[7]), [a8] "v"(Ar[8]), [a9] "v"(Ar[9]), [a10] "v"(Ar[10]), [a11] "v"(Ar[11]), [a12] "v"(Ar[12]), [a13] "v"(Ar[13]), [a14] "v"(Ar[14]), [a15] "v"(Ar[15]), [a16] "v"(Ar[16]), [a17] "v"(Ar[17])
+            : "v0", "v1", "s4", "s5", "s38", "s39");
+        }
+        dvec = __builtin_bit_cast(real, ((long long)dhi << 32) | (unsigned int)dlo);
     } else {
         static_for<ND>([&](auto ic) {
             constexpr int PP = NC_ORDER[REV ? ND - 1 - decltype(ic)::value : decltype(ic)::value];
@@ -657,7 +998,11 @@ __device__ __forceinline__ void pgs_rowTd(real &e, const real nt1, const real t2
             "v_fmac_f32 %[e], %[sd], %[a]\n\t"
             : [d] "=&v"(d), [sd] "=&s"(sd), [dv] "+v"(dvec), [e] "+v"(e)
             : [nt1] "v"(nt1), [t2] "v"(t2), [a] "v"(acol), [pp] "i"(lane_of_port(PP)));
-    } else {
+    }
+#ifndef PLENVEC_F64_ROW_LATE
+    else if constexpr (FAST && sizeof(real) == 8) f64_row_asm<lane_of_port(PP)>(e, nt1, t2, dvec, acol);
+#endif
+    else {
 #pragma clang fp contract(off)
         const real d = clamp_neg(e, nt1, t2);
         const real db = bcast(d, lane_of_port(PP));
