@@ -1085,6 +1085,32 @@ __device__ __forceinline__ void pgs_cone(real &e, const real u, real &dvec, cons
 #endif
     }
     const real d = fma_(w, scale, -u);              // deltaVel of this lane's row
+#ifndef PLENVEC_F64_CONE_C
+    if constexpr (sizeof(real) == 8) {
+        // hand-scheduled tail (f64): four v_readlane, then the two v_fmac_f64 with the four commit v_writelane between and behind them -- every
+        // scalar operand is old enough when it is read, so the only wait state left is the one between the fma that made d and the first
+        // v_readlane (the compiler's layout had six).  Same operations, same order (A then B), same values.
+        const long long dvb = __builtin_bit_cast(long long, dvec);
+        int dlo = (int)(dvb & 0xffffffffLL), dhi = (int)(dvb >> 32);
+        asm volatile(
+            "s_nop 0\n\t"
+            "v_readlane_b32 s5, v1, %[la]\n\t"
+            "v_readlane_b32 s4, v0, %[la]\n\t"
+            "v_readlane_b32 s39, v1, %[lb]\n\t"
+            "v_readlane_b32 s38, v0, %[lb]\n\t"
+            "v_writelane_b32 %[dhi], s5, %[la]\n\t"
+            "v_fmac_f64 %[e], s[4:5], %[aA]\n\t"
+            "v_writelane_b32 %[dlo], s4, %[la]\n\t"
+            "v_fmac_f64 %[e], s[38:39], %[aB]\n\t"
+            "v_writelane_b32 %[dhi], s39, %[lb]\n\t"
+            "v_writelane_b32 %[dlo], s38, %[lb]\n\t"
+            : [e] "+v"(e), [dlo] "+v"(dlo), [dhi] "+v"(dhi)
+            : "{v[0:1]}"(d), [aA] "v"(aA), [aB] "v"(aB), [la] "i"(LA), [lb] "i"(LB)
+            : "s4", "s5", "s38", "s39");
+        dvec = __builtin_bit_cast(real, ((long long)dhi << 32) | (unsigned int)dlo);
+        return;
+    }
+#endif
     const real dA = bcast(d, LA), dB = bcast(d, LB);
     dvec = wrlane<LA>(dvec, dA, lane); dvec = wrlane<LB>(dvec, dB, lane);     // u += dvec after the pass (no lane masks kept alive)
     e = fma_(dB, aB, fma_(dA, aA, e));
