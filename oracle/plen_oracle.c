@@ -221,6 +221,12 @@ typedef struct {
     int base_gyro_off;       /* 1: no gyroscopic term on the base (btMultiBody::m_useGyroTerm false) */
     real motor_rhs_clamp;    /* > 0: btMultiBodyJointMotor::m_rhsClamp (the motor's desired velocity clamped to +- this) */
     real joint_damping;      /* btMultibodyLink::m_jointDamping of every revolute joint (URDF <dynamics damping>; the reference's URDF has none) */
+    int man_cand;            /* manifold_mode 1: candidates of the per-pass new point: 0 all 209 hull vertices, 1 the 32 sole vertices, 2 the 8 corner representatives */
+    real man_drift;          /* manifold_mode 1: the drift test's threshold as a multiple of the breaking threshold (0 -> 1) */
+    int man_add_all;         /* manifold_mode 1: 1 = every in-range candidate goes through addContactPoint each pass, deepest last (multi-point generation) */
+    int man_order;           /* manifold_mode 1, add_all: 0 = candidates inserted from the highest to the lowest, 1 = lowest first */
+    real man_cache, man_range;   /* manifold_mode 1: getCacheEntry's merge radius / the in-range threshold as multiples of the breaking threshold (0 -> 1) */
+    int man_fresh;           /* manifold_mode 1: 1 = the manifold is rebuilt from nothing every pass (memoryless; no carried impulse either) */
     int nc_order;            /* 1: motors visited in DoF order instead of btAlignedObjectArray::quickSort's scramble of equal island keys; 2: reverse DoF order */
     int no_order_flip;       /* 1: the non-contact rows are not reversed on even iterations */
     int torsional_points;    /* > 0: only the first n points of a manifold get spinning / rolling rows */
@@ -516,30 +522,41 @@ static void collide(Oracle *o) {
         int link = f == 0 ? RAW_RFOOT_LINK : RAW_LFOOT_LINK, b = link + 1;
         const real thr = (real)(f == 0 ? RAW_RFOOT_BREAK : RAW_LFOOT_BREAK), thr2 = thr * thr;
         const real *R = o->Rw[b], *O = o->Ow[b];
+        if (o->w.man_fresh) o->man[f].n = 0;
         /* refreshContactPoints: distance along the normal and drift in the plane, from the stored local points */
         for (int i = o->man[f].n - 1; i >= 0; i--) {
             real pa[3]; m3mulv(pa, R, o->man[f].lA[i]); v3add(pa, pa, O);
             real dist = pa[2] - o->man[f].wB[i][2];
             real dx = o->man[f].wB[i][0] - pa[0], dy = o->man[f].wB[i][1] - pa[1];
-            if (dist > thr || dx * dx + dy * dy > thr2) {          /* removeContactPoint: the last entry takes its place */
+            const real dthr = o->w.man_drift > 0 ? thr * o->w.man_drift : thr;
+            if (dist > thr || dx * dx + dy * dy > dthr * dthr) {          /* removeContactPoint: the last entry takes its place */
                 int last = --o->man[f].n;
                 if (i != last) { v3cpy(o->man[f].lA[i], o->man[f].lA[last]); v3cpy(o->man[f].wB[i], o->man[f].wB[last]); o->man[f].imp[i] = o->man[f].imp[last]; }
             }
         }
-        /* the collision pass's one new point: GJK's closest point = the lowest hull vertex, sphere-swept by the margin */
-        int nh = f == 0 ? RAW_RFOOT_NHULL : RAW_LFOOT_NHULL, low = -1; real lowz = 0, lw[3] = {0, 0, 0};
-        for (int v = 0; v < nh; v++) {
-            const double *pl = f == 0 ? RAW_RFOOT_HULL[v] : RAW_LFOOT_HULL[v];
-            real l[3] = {(real)pl[0], (real)pl[1], (real)pl[2]}, w[3];
-            m3mulv(w, R, l); v3add(w, w, O);
-            if (low < 0 || w[2] < lowz) { low = v; lowz = w[2]; v3cpy(lw, w); }
+        /* the collision pass's new point(s): GJK's closest point = the lowest candidate vertex, sphere-swept by the margin */
+        const int ncand_v = o->w.man_cand == 0 ? (f == 0 ? RAW_RFOOT_NHULL : RAW_LFOOT_NHULL) : 32;
+        real cw[209][3]; int cok[209];
+        for (int v = 0; v < ncand_v; v++) {
+            const double *pl = o->w.man_cand == 0 ? (f == 0 ? RAW_RFOOT_HULL[v] : RAW_LFOOT_HULL[v]) : (f == 0 ? RAW_RFOOT_SOLE[v] : RAW_LFOOT_SOLE[v]);
+            real l[3] = {(real)pl[0], (real)pl[1], (real)pl[2]};
+            m3mulv(cw[v], R, l); v3add(cw[v], cw[v], O);
+            cok[v] = o->w.man_cand == 2 ? (f == 0 ? RAW_RFOOT_SOLE_REP[v] : RAW_LFOOT_SOLE_REP[v]) : 1;
         }
-        real depth = lowz - (real)RAW_MARGIN;
-        if (depth <= thr) {
+        /* order of insertion: one point (the lowest) or all in-range candidates from the highest to the lowest (the deepest added last) */
+        int ord[209], nord = 0;
+        const real rthr = o->w.man_range > 0 ? thr * o->w.man_range : thr;
+        for (int v = 0; v < ncand_v; v++) if (cok[v] && cw[v][2] - (real)RAW_MARGIN <= rthr) ord[nord++] = v;
+        for (int i = 1; i < nord; i++) { int k = ord[i], j = i - 1; while (j >= 0 && cw[ord[j]][2] < cw[k][2]) { ord[j + 1] = ord[j]; j--; } ord[j + 1] = k; }
+        if (o->w.man_order == 1 && o->w.man_add_all) for (int i = 0; i < nord / 2; i++) { int t_ = ord[i]; ord[i] = ord[nord - 1 - i]; ord[nord - 1 - i] = t_; }
+        for (int oi = (o->w.man_add_all ? 0 : (nord > 0 ? nord - 1 : 0)); oi < nord; oi++) {
+            const real *lw = cw[ord[oi]];
+            real depth = lw[2] - (real)RAW_MARGIN;
+            {
             real pa[3] = {lw[0], lw[1], depth}, d[3], la[3];
             v3sub(d, pa, O);
             for (int k = 0; k < 3; k++) la[k] = R[k] * d[0] + R[3 + k] * d[1] + R[6 + k] * d[2];      /* R^T (pa - O) */
-            int near = -1; real best = thr2;                          /* getCacheEntry */
+            int near = -1; real best = o->w.man_cache > 0 ? thr2 * o->w.man_cache * o->w.man_cache : thr2;                          /* getCacheEntry */
             for (int i = 0; i < o->man[f].n; i++) { real e[3]; v3sub(e, o->man[f].lA[i], la); real q = v3dot(e, e); if (q < best) { best = q; near = i; } }
             int ins;
             if (near >= 0) ins = near;                                /* replaceContactPoint keeps the applied impulse */
@@ -561,6 +578,7 @@ static void collide(Oracle *o) {
                 o->man[f].imp[ins] = 0;
             }
             v3cpy(o->man[f].lA[ins], la); v3set(o->man[f].wB[ins], lw[0], lw[1], 0);
+            }
         }
         for (int i = 0; i < o->man[f].n; i++) {
             int c = 4 * f + i;
@@ -1009,6 +1027,8 @@ API int oracle_set_hyp(Oracle *o, int key, double v) {
     case 21: w->manifold_mode = (int)v; break;  case 22: w->warmstart = (real)v; break;
     case 23: w->pyramid_friction = (int)v; break; case 24: w->base_gyro_off = (int)v; break;
     case 25: w->torsional_points = (int)v; break;
+    case 30: w->man_cand = (int)v; break; case 31: w->man_drift = (real)v; break; case 32: w->man_add_all = (int)v; break;
+    case 33: w->man_fresh = (int)v; break; case 34: w->man_order = (int)v; break; case 35: w->man_cache = (real)v; break; case 36: w->man_range = (real)v; break;
     case 28: w->nc_order = (int)v; break; case 29: w->no_order_flip = (int)v; break;
     case 26: w->motor_rhs_clamp = (real)v; break; case 27: w->joint_damping = (real)v; break;
     default: return -1;

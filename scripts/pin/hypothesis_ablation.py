@@ -51,6 +51,21 @@ V("persistent manifold, frictionERP 0", hyp=dict(manifold=1, friction_erp=0.0))
 V("persistent manifold + warm starting 0.1", hyp=dict(manifold=1, warm=0.1))
 V("persistent manifold + warm starting 1.0", hyp=dict(manifold=1, warm=1.0))
 V("persistent manifold, torsional rows on the first point only", hyp=dict(manifold=1, tors_pts=1))
+# the manifold family around "every in-range hull vertex goes through addContactPoint each pass" (all 209 vertices: the sole's bevel rings count)
+P = dict(manifold=1, man_add_all=1, friction_erp=0.0, man_drift=1e6)
+V("persistent, all in-range hull vertices per pass, no anchors (P)", hyp=dict(P))
+V("P with the drift test", hyp=dict(P, man_drift=1.0))
+V("P rebuilt from nothing every pass (memoryless)", hyp=dict(P, man_fresh=1))
+V("P, candidates = the 32 sole vertices", hyp=dict(P, man_cand=1))
+V("P, candidates = the 8 corner representatives", hyp=dict(P, man_cand=2))
+V("P, lowest candidate first", hyp=dict(P, man_order=1))
+V("P, merge radius x 2", hyp=dict(P, man_cache=2.0))
+V("P, in-range threshold x 1.2", hyp=dict(P, man_range=1.2))
+V("P, motor kp 0.09", hyp=dict(P, kp=0.09))
+V("P, motor kp 0.11", hyp=dict(P, kp=0.11))
+V("P, rolling friction 0.06", hyp=dict(P, roll=0.06))
+V("P, rolling friction 0.1", hyp=dict(P, roll=0.1))
+V("P, frictionERP 0.2", hyp=dict(P, friction_erp=0.2))
 
 
 def actor_stats(kw, episodes=128, sigma=0.01, seed=0):
