@@ -221,6 +221,7 @@ typedef struct {
     int base_gyro_off;       /* 1: no gyroscopic term on the base (btMultiBody::m_useGyroTerm false) */
     real motor_rhs_clamp;    /* > 0: btMultiBodyJointMotor::m_rhsClamp (the motor's desired velocity clamped to +- this) */
     real joint_damping;      /* btMultibodyLink::m_jointDamping of every revolute joint (URDF <dynamics damping>; the reference's URDF has none) */
+    real sole_grow, sole_dz; /* memoryless model: sole candidate vertices moved outward by sole_grow (m, along the direction from the sole centre) and up by sole_dz */
     int man_cand;            /* manifold_mode 1: candidates of the per-pass new point: 0 all 209 hull vertices, 1 the 32 sole vertices, 2 the 8 corner representatives */
     real man_drift;          /* manifold_mode 1: the drift test's threshold as a multiple of the breaking threshold (0 -> 1) */
     int man_add_all;         /* manifold_mode 1: 1 = every in-range candidate goes through addContactPoint each pass, deepest last (multi-point generation) */
@@ -601,6 +602,11 @@ static void collide(Oracle *o) {
         for (int v = 0; v < 32; v++) {
             const double *pl = f == 0 ? RAW_RFOOT_SOLE[v] : RAW_LFOOT_SOLE[v];
             real l[3] = {(real)pl[0], (real)pl[1], (real)pl[2]};
+            if (o->w.sole_grow != 0 || o->w.sole_dz != 0) {
+                double cx = 0, cy = 0; for (int q = 0; q < 32; q++) { const double *pq = f == 0 ? RAW_RFOOT_SOLE[q] : RAW_LFOOT_SOLE[q]; cx += pq[0] / 32; cy += pq[1] / 32; }
+                double dx = pl[0] - cx, dy = pl[1] - cy, n = sqrt(dx * dx + dy * dy);
+                l[0] += (real)(o->w.sole_grow * dx / n); l[1] += (real)(o->w.sole_grow * dy / n); l[2] += o->w.sole_dz;
+            }
             m3mulv(wv[v], o->Rw[b], l); v3add(wv[v], wv[v], o->Ow[b]);
             in_range[v] = (f == 0 ? RAW_RFOOT_SOLE_REP[v] : RAW_LFOOT_SOLE_REP[v]) && (wv[v][2] - (real)RAW_MARGIN) <= thr;
         }
@@ -1028,6 +1034,7 @@ API int oracle_set_hyp(Oracle *o, int key, double v) {
     case 23: w->pyramid_friction = (int)v; break; case 24: w->base_gyro_off = (int)v; break;
     case 25: w->torsional_points = (int)v; break;
     case 30: w->man_cand = (int)v; break; case 31: w->man_drift = (real)v; break; case 32: w->man_add_all = (int)v; break;
+    case 37: w->sole_grow = (real)v; break; case 38: w->sole_dz = (real)v; break;
     case 33: w->man_fresh = (int)v; break; case 34: w->man_order = (int)v; break; case 35: w->man_cache = (real)v; break; case 36: w->man_range = (real)v; break;
     case 28: w->nc_order = (int)v; break; case 29: w->no_order_flip = (int)v; break;
     case 26: w->motor_rhs_clamp = (real)v; break; case 27: w->joint_damping = (real)v; break;
