@@ -757,7 +757,8 @@ static void substep(Oracle *o) {
         r->rhs = pos_err * r->jac_diag_inv + vel_err * r->jac_diag_inv;
         r->cfm = cfm * r->jac_diag_inv; r->lo = 0; r->hi = (real)1e10; r->friction = o->cp_mu[c];
         r->friction_index = n_n;
-        const int tors_ok = !(w->torsional_points > 0 && o->cp_man[c] >= w->torsional_points);
+        const int tors_idx = o->cp_man[c] >= 0 ? o->cp_man[c] : (o->cp_slot[c] & 3);          /* position of the point in its foot's manifold */
+        const int tors_ok = !(w->torsional_points > 0 && tors_idx >= w->torsional_points);
         if (is_foot && tors_ok && w->spinning_friction > 0) {      /* spinning / rolling friction is set on the two foot links only (plen_env.py:439-467) */
             Row *t = &spin[n_spin++];
             fill_jacobian(o, link, P, nrmW, Z3, t->jac);
