@@ -49,3 +49,16 @@ def test_pin_discriminates_through_the_kernel():
     assert _kernel_residuals(torch.float64, K=0, cfg=dict(num_iterations=49))[0][0] > 2.5 * base
     assert _kernel_residuals(torch.float64, K=0, cfg=dict(erp2=0.04))[0][0] > 3.0 * base
     assert _kernel_residuals(torch.float64, K=1, cfg=dict(motor_kp=0.2))[0][1] > 3.0 * _kernel_residuals(torch.float64, K=1)[0][1]
+
+
+def test_shipped_policy_statistics_of_the_chosen_configuration(golden_dir):
+    """VERDICT r02 item 1's closing clause: the shipped actor's episode statistics in the configuration the ablation confirmed (f64 kernel,
+    sigma = 0.01, 2048 episodes; profiles/r03_hypothesis_ablation_gpu.json measured length 205.6 +- 3.0, return +86 +- 4, 19.7 % full-length
+    episodes over 4096).  A regression signal for the dynamics as a whole: kp 0.11 gives 92 steps / 3.8 %, erp2 0.04 gives 85 / 6.3 %."""
+    import os
+    from plen_ml_walk_amd.walk_eval import load_policy, evaluate
+    pol = load_policy(os.path.join(golden_dir, "policy_3229999.npz"))
+    r = evaluate(pol, 2048, 1, torch.float64, action_noise=0.01, seed=0)
+    ret, ln = np.array(r["returns"]), np.array(r["lengths"])
+    assert len(ln) == 2048
+    assert 175 <= ln.mean() <= 240 and 0.13 <= (ln >= 500).mean() <= 0.27 and 40 <= ret.mean() <= 135, (ln.mean(), (ln >= 500).mean(), ret.mean())
