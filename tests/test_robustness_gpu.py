@@ -658,11 +658,13 @@ def test_rccl_world_size_one_runs_the_multi_rank_code_path(tmp_path):
     assert r["backend"] == "nccl" and r["world"] == 1
     g, p, c = r["graphed"], r["pipelined"], r["graphed_captured"]
     assert g["collectives"] and g["allreduce_mode"] == "eager-between-graphs" and any("critic_backward" in k for k in g["graphs"]) and any("actor_step" in k for k in g["graphs"])
-    assert g["finite"] and g["max_abs_param_diff_vs_no_collectives"] < 5e-3 and g["grad_steps"] == 13
+    assert g["finite"] and g["max_abs_param_diff_vs_no_collectives"] < 1e-2 and g["grad_steps"] == 13
     ga = r["graphed_autograd"]
     assert ga["collectives"] and ga["finite"] and ga["max_abs_param_diff_vs_no_collectives"] == 0.0 and ga["grad_steps"] == 13
-    assert c["allreduce_mode"] == "captured" and c["finite"] and c["max_abs_param_diff_vs_no_collectives"] < 5e-3
+    assert c["allreduce_mode"] == "captured" and c["finite"] and c["max_abs_param_diff_vs_no_collectives"] < 1e-2
     assert p["collectives"] and p["allreduce_mode"] == "eager-between-graphs" and p["finite"] and p["grad_steps"] == 22
-    assert p["max_abs_param_diff_vs_no_collectives"] < 1e-2          # (the pipelined learner's float atomics are not bitwise reproducible)
+    # the fused learner's float-atomic weight gradients are not bitwise reproducible, and Adam turns a flipped sign of a tiny gradient into a full
+    # step: two runs can differ by up to 2 * lr * steps = 7.8e-3 (13 steps) / 1.3e-2 (22 steps) in single parameters; the exact check is the autograd run above
+    assert p["max_abs_param_diff_vs_no_collectives"] < 2e-2
     lat = r["allreduce_latency_620KB"]
     assert lat["alone"]["device_us_per_call"] < 500 and lat["beside_two_resident_2048_env_launches"]["device_us_per_call"] < 5000
