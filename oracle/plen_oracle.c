@@ -227,6 +227,9 @@ typedef struct {
     int man_add_all;         /* manifold_mode 1: 1 = every in-range candidate goes through addContactPoint each pass, deepest last (multi-point generation) */
     int man_order;           /* manifold_mode 1, add_all: 0 = candidates inserted from the highest to the lowest, 1 = lowest first */
     real man_cache, man_range;   /* manifold_mode 1: getCacheEntry's merge radius / the in-range threshold as multiples of the breaking threshold (0 -> 1) */
+    int man_p1;              /* manifold_mode 1: 1 = the FIRST point of an empty manifold is the sole-plane point (man_p1x, man_p1y) of the foot link frame
+                                (what EPA returns for the flat-on-flat start of every episode is an artefact of its polytope expansion: scanned, not known) */
+    real man_p1x, man_p1y;
     int man_fresh;           /* manifold_mode 1: 1 = the manifold is rebuilt from nothing every pass (memoryless; no carried impulse either) */
     int nc_order;            /* 1: motors visited in DoF order instead of btAlignedObjectArray::quickSort's scramble of equal island keys; 2: reverse DoF order */
     int no_order_flip;       /* 1: the non-contact rows are not reversed on even iterations */
@@ -550,8 +553,15 @@ static void collide(Oracle *o) {
         for (int v = 0; v < ncand_v; v++) if (cok[v] && cw[v][2] - (real)RAW_MARGIN <= rthr) ord[nord++] = v;
         for (int i = 1; i < nord; i++) { int k = ord[i], j = i - 1; while (j >= 0 && cw[ord[j]][2] < cw[k][2]) { ord[j + 1] = ord[j]; j--; } ord[j + 1] = k; }
         if (o->w.man_order == 1 && o->w.man_add_all) for (int i = 0; i < nord / 2; i++) { int t_ = ord[i]; ord[i] = ord[nord - 1 - i]; ord[nord - 1 - i] = t_; }
+        real p1w[3];
+        const int use_p1 = o->w.man_p1 && o->man[f].n == 0 && nord > 0;
+        if (use_p1) {
+            const double *pl = f == 0 ? RAW_RFOOT_SOLE[0] : RAW_LFOOT_SOLE[0];
+            real l[3] = {o->w.man_p1x, o->w.man_p1y, (real)pl[2]};
+            m3mulv(p1w, R, l); v3add(p1w, p1w, O);
+        }
         for (int oi = (o->w.man_add_all ? 0 : (nord > 0 ? nord - 1 : 0)); oi < nord; oi++) {
-            const real *lw = cw[ord[oi]];
+            const real *lw = use_p1 ? p1w : cw[ord[oi]];
             real depth = lw[2] - (real)RAW_MARGIN;
             {
             real pa[3] = {lw[0], lw[1], depth}, d[3], la[3];
@@ -1036,6 +1046,7 @@ API int oracle_set_hyp(Oracle *o, int key, double v) {
     case 25: w->torsional_points = (int)v; break;
     case 30: w->man_cand = (int)v; break; case 31: w->man_drift = (real)v; break; case 32: w->man_add_all = (int)v; break;
     case 37: w->sole_grow = (real)v; break; case 38: w->sole_dz = (real)v; break;
+    case 39: w->man_p1 = (int)v; break; case 40: w->man_p1x = (real)v; break; case 41: w->man_p1y = (real)v; break;
     case 33: w->man_fresh = (int)v; break; case 34: w->man_order = (int)v; break; case 35: w->man_cache = (real)v; break; case 36: w->man_range = (real)v; break;
     case 28: w->nc_order = (int)v; break; case 29: w->no_order_flip = (int)v; break;
     case 26: w->motor_rhs_clamp = (real)v; break; case 27: w->joint_damping = (real)v; break;

@@ -66,6 +66,10 @@ V("P, motor kp 0.11", hyp=dict(P, kp=0.11))
 V("P, rolling friction 0.06", hyp=dict(P, roll=0.06))
 V("P, rolling friction 0.1", hyp=dict(P, roll=0.1))
 V("P, frictionERP 0.2", hyp=dict(P, friction_erp=0.2))
+# the literal one-point-per-pass manifold whose FIRST point (flat-on-flat start: an artefact of EPA) is a scanned interior point of the sole
+V("persistent manifold, first point near the sole centre (10, 6) mm", hyp=dict(manifold=1, man_p1=1, man_p1x=0.010, man_p1y=0.006))
+V("persistent manifold, first point (4, -2) mm", hyp=dict(manifold=1, man_p1=1, man_p1x=0.004, man_p1y=-0.002))
+V("persistent manifold, first point (16, 10) mm", hyp=dict(manifold=1, man_p1=1, man_p1x=0.016, man_p1y=0.010))
 
 
 def actor_stats(kw, episodes=128, sigma=0.01, seed=0):
