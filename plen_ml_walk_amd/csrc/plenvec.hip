@@ -392,10 +392,27 @@ __device__ __forceinline__ unsigned absbits(double x) { return __builtin_bit_cas
 // One f64 solver row as a hand-written block (FAST path): the hi half of the commit sits in the wait states between the v_readlane pair and the
 // v_fmac_f64 that reads the SGPR pair, the lo half right after the v_fmac (in the latency shadow of the next row's clamp): 7 VALU + 2 waits
 // instead of 7 VALU + 4.  Same operations on the same values as the compiler path.  (-DPLENVEC_F64_ROW_LATE keeps the former layout for A/B.)
-template <int L>
+template <int L, bool NEGLO = false>
 __device__ __forceinline__ void f64_row_asm(double &e, const double lo, const double hi, double &dvec, const double acol) {
     const long long dvb = __builtin_bit_cast(long long, dvec);
     int dlo = (int)(dvb & 0xffffffffLL), dhi = (int)(dvb >> 32);
+    if constexpr (NEGLO) {           // the lower bound arrives as its negative (torsional rows: -(lim + u) kept as lim + u): a source modifier instead of an instruction
+        asm volatile(
+            "v_max_f64 v[0:1], -%[e], -%[lo]\n\t"
+            "v_min_f64 v[0:1], v[0:1], %[hi]\n\t"
+            "s_nop 0\n\t"
+            "v_readlane_b32 s5, v1, %[pp]\n\t"
+            "v_readlane_b32 s4, v0, %[pp]\n\t"
+            "s_nop 0\n\t"
+            "v_writelane_b32 %[dhi], s5, %[pp]\n\t"
+            "v_fmac_f64 %[e], s[4:5], %[a]\n\t"
+            "v_writelane_b32 %[dlo], s4, %[pp]\n\t"
+            : [e] "+v"(e), [dlo] "+v"(dlo), [dhi] "+v"(dhi)
+            : [lo] "v"(lo), [hi] "v"(hi), [a] "v"(acol), [pp] "i"(L)
+            : "v0", "v1", "s4", "s5");
+        dvec = __builtin_bit_cast(double, ((long long)dhi << 32) | (unsigned int)dlo);
+        return;
+    }
     asm volatile(
         "v_max_f64 v[0:1], -%[e], %[lo]\n\t"
         "v_min_f64 v[0:1], v[0:1], %[hi]\n\t"
@@ -982,29 +999,29 @@ __device__ __forceinline__ void pgs_motor_pass(real &e, const real blo, const re
     }
 }
 
-// torsional row with bounds prepared by the caller for this pass (nt1 = -(lim + u), t2 = lim - u) and a
-// deferred commit (u += dvec after the pass): med3 -> readlane -> writelane -> fmac
+// torsional row with bounds prepared by the caller for this pass -- pt1 = lim + u (the NEGATED lower bound: the negation is a source modifier of the
+// clamp), t2 = lim - u -- and a deferred commit (u += dvec after the pass): med3 -> readlane -> writelane -> fmac
 template <bool FAST, int PP, typename real>
-__device__ __forceinline__ void pgs_rowTd(real &e, const real nt1, const real t2, real &dvec, const real acol, const int lane) {
+__device__ __forceinline__ void pgs_rowTd(real &e, const real pt1, const real t2, real &dvec, const real acol, const int lane) {
     if constexpr (FAST && sizeof(real) == 4) {
         float d;
         int sd;
         asm volatile(
-            "v_med3_f32 %[d], -%[e], %[nt1], %[t2]\n\t"
+            "v_med3_f32 %[d], -%[e], -%[pt1], %[t2]\n\t"
             "s_nop 0\n\t"
             "v_readlane_b32 %[sd], %[d], %[pp]\n\t"
             "s_nop 1\n\t"
             "v_writelane_b32 %[dv], %[sd], %[pp]\n\t"
             "v_fmac_f32 %[e], %[sd], %[a]\n\t"
             : [d] "=&v"(d), [sd] "=&s"(sd), [dv] "+v"(dvec), [e] "+v"(e)
-            : [nt1] "v"(nt1), [t2] "v"(t2), [a] "v"(acol), [pp] "i"(lane_of_port(PP)));
+            : [pt1] "v"(pt1), [t2] "v"(t2), [a] "v"(acol), [pp] "i"(lane_of_port(PP)));
     }
 #ifndef PLENVEC_F64_ROW_LATE
-    else if constexpr (FAST && sizeof(real) == 8) f64_row_asm<lane_of_port(PP)>(e, nt1, t2, dvec, acol);
+    else if constexpr (FAST && sizeof(real) == 8) f64_row_asm<lane_of_port(PP), true>(e, pt1, t2, dvec, acol);
 #endif
     else {
 #pragma clang fp contract(off)
-        const real d = clamp_neg(e, nt1, t2);
+        const real d = clamp_neg(e, -pt1, t2);
         const real db = bcast(d, lane_of_port(PP));
         if constexpr (sizeof(real) == 8) {
             e = fma_(db, acol, e);
@@ -2037,10 +2054,13 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                 const real nbv0 = gather_addr(blo, tors_addr), nbv1 = gather_addr(blo, tors_addr + 16);
                 const real nbv2 = gather_addr(blo, tors_addr + 32), nbv3 = gather_addr(blo, tors_addr + 48);     // -u_n of point k of this lane's foot
                 const real lim0 = mul_rn_(fc0, nbv0), lim1 = mul_rn_(fc1, nbv1), lim2 = mul_rn_(fc2, nbv2), lim3 = mul_rn_(fc3, nbv3);
-                const real nt10 = nbv0 < 0 ? -(lim0 + u0) : (real)0, nt11 = nbv1 < 0 ? -(lim1 + u1) : (real)0;
-                const real nt12 = nbv2 < 0 ? -(lim2 + u2) : (real)0, nt13 = nbv3 < 0 ? -(lim3 + u3) : (real)0;
-                const real t20 = nbv0 < 0 ? lim0 - u0 : (real)0, t21 = nbv1 < 0 ? lim1 - u1 : (real)0;
-                const real t22 = nbv2 < 0 ? lim2 - u2 : (real)0, t23 = nbv3 < 0 ? lim3 - u3 : (real)0;
+                // bounds of point k's rows: [-(lim + u), lim - u] while its normal impulse is positive (nbv = -u_n < 0), else [0, 0].  As two fused
+                // operations on a 0/1 factor m instead of an add, a subtract, a negation and two selects each: u * m is exact, so fma(u, m, lim) rounds
+                // exactly like lim + u; with m = 0 it leaves lim = fc * 0 = +-0, the empty interval.  pt1 is the NEGATED lower bound (the rows negate it
+                // with a source modifier).  f64: 32 -> 16 vector instructions per iteration.
+                const real m0 = nbv0 < 0 ? (real)1 : (real)0, m1 = nbv1 < 0 ? (real)1 : (real)0, m2 = nbv2 < 0 ? (real)1 : (real)0, m3 = nbv3 < 0 ? (real)1 : (real)0;
+                const real nt10 = fma_(u0, m0, lim0), nt11 = fma_(u1, m1, lim1), nt12 = fma_(u2, m2, lim2), nt13 = fma_(u3, m3, lim3);
+                const real t20 = fma_(-u0, m0, lim0), t21 = fma_(-u1, m1, lim1), t22 = fma_(-u2, m2, lim2), t23 = fma_(-u3, m3, lim3);
                 real dv0 = 0, dv1 = 0, dv2 = 0, dv3 = 0;
                 ISTAMP(3);
                 if (has_spin) {
