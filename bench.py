@@ -278,10 +278,12 @@ def env_leg(a, dtype_name, dev, rank, world, dist, steps, warmup, dr=None):
     if pmc:
         ginst = pmc["valu_insts_per_env_step"] * value / world / 1e9      # whole-GPU issue rate (all concurrent launches)
         wps = 4 if dtype_name == "f32" else 2
+        # lead with the fraction of the guide's NOMINAL issue rate; the row-mix ceiling is a microbenchmark of this kernel's own row (it says the row
+        # issues as fast as the row can issue, not that the instruction count is the floor: VERDICT r02 weak point 5)
         valu = {"insts_per_env_step": pmc["valu_insts_per_env_step"], "achieved": ginst, "unit": "G wave-inst/s",
-                "peak_row_mix": VALU_ROW_MIX_GINST_S[4], "frac_row_mix": ginst / VALU_ROW_MIX_GINST_S[4],
-                "peak_fma_class": VALU_CLASS_GINST_S["fma_mul_add"], "frac_fma_class": ginst / VALU_CLASS_GINST_S["fma_mul_add"],
                 "peak_nominal_2cycle": VALU_NOMINAL_GINST_S, "frac_nominal_2cycle": ginst / VALU_NOMINAL_GINST_S,
+                "peak_fma_class": VALU_CLASS_GINST_S["fma_mul_add"], "frac_fma_class": ginst / VALU_CLASS_GINST_S["fma_mul_add"],
+                "peak_row_mix": VALU_ROW_MIX_GINST_S[4], "frac_row_mix": ginst / VALU_ROW_MIX_GINST_S[4],
                 "waves_per_simd": wps, "class_rates_measured": VALU_CLASS_GINST_S, "source": pmc_file, "rates_source": "profiles/r02_valu_issue.json"}
     return {
         "value": value, "unit": "env-steps/s", "dtype": dtype_name, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
