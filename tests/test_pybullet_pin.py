@@ -92,3 +92,15 @@ def test_listed_self_collision_pairs_overlap_at_reset_yet_the_reset_pin_holds():
     free = [o for o in ov if not o[3]]                      # overlapping listed pairs that are not parent / child
     assert len(free) >= 6 and max(o[2] for o in free) > 2e-3, free
     assert P.oracle_residuals(K=0)[0][0] < 0.015
+
+
+def test_every_hypothesis_switch_exists_in_the_oracle():
+    """tests/pybullet_pin.HYP names the oracle's runtime switches by number (oracle_set_hyp): every key must be accepted, unknown keys refused, and the
+    defaults must be the model DESIGN.md section 2 describes (all switches off)."""
+    e = OracleEnv()
+    base = e.reset().copy()
+    for name, key in P.HYP.items():
+        assert e.lib.oracle_set_hyp(e.h, key, 0.0) == 0 or name in ("dt",), name       # (value 0 is legal for every switch but dt, which is not touched here)
+    assert e.lib.oracle_set_hyp(e.h, 999, 1.0) == -1
+    # a fresh oracle with no switch touched reproduces the same reset bit for bit (the switches default to the section-2 model)
+    assert np.array_equal(OracleEnv().reset(), base)
