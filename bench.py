@@ -14,7 +14,11 @@ plen_env.py computes in NumPy float64); the same JSON line carries two more legs
   legs.td3 : BASELINE.json configs[2]/[3]: 4096 envs per GPU + the full TD3 loop (actor/critic/replay in
              PyTorch-ROCm on the same device, f32 env, hipGraph-captured; RCCL gradient all-reduce for N > 1):
              env-steps/s AND gradient-steps/s, batch and update-to-data ratio stated.
-and `pybullet` records whether the reference's physics engine exists on this machine (it never has so far).
+and `pybullet` records whether the reference's physics engine exists on this machine (it never has so far).  Outside every timed region, at
+N = 1, the line also carries `obs_err_vs_oracle` (SURVEY 8(d) Config 2: 64 envs x 64 steps, f64 kernel against the f64 oracle on identical
+actions) and `pybullet_pin` (the kernel's residuals against the PyBullet-held pin, tests/pybullet_pin.py).  The timed block of exactly K steps is
+repeated until MIN_TIMED_S of timed work has accumulated (`timed_region`).  `--scaling strong` splits --envs-per-gpu envs over the ranks (the
+metric's literal "@4096 envs" in total); the default is weak scaling, 4096 envs on every rank.
 
 Contract: `python bench.py --gpus N --steps K --warmup W`.  For N > 1 the driver launches it through
 torch.distributed.run (one rank per GPU, RCCL); started from a plain shell with --gpus N > 1 it spawns those ranks
