@@ -5,8 +5,8 @@ compared block by block with tests/golden/ref_training_log_summary.npz (the refe
 -190.8, last 1000 +50.4, max 328).
 
 n envs step together and n updates follow (same update-to-data ratio, same batch; the reference interleaves them one by one).
-usage: python scripts/gpu_reference_recipe.py [max_env_steps] [wall_budget_s] [n_envs] [f32|f64]
-writes gpurun_out/r03_reference_recipe_curve.json"""
+usage: python scripts/gpu_reference_recipe.py [max_env_steps] [wall_budget_s] [n_envs] [f32|f64] [seed]
+writes gpurun_out/r03_reference_recipe_curve[_seed<k>_n<envs>].json"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -20,17 +20,18 @@ max_steps = int(float(sys.argv[1])) if len(sys.argv) > 1 else 3250000
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 1500.0
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 dtype = torch.float64 if (len(sys.argv) > 4 and sys.argv[4] == "f64") else torch.float32
-torch.manual_seed(0); np.random.seed(0)
+seed = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+torch.manual_seed(seed); np.random.seed(seed)
 env = PlenVecEnv(n, dtype=dtype)
 agent = TD3Agent(26, 18, 1.0)
 replay = ReplayBuffer(1000000)
-tr = GraphedVecTD3Trainer(env, agent, replay, start_timesteps=10000, expl_noise=0.1, batch_size=100, updates_per_step=n, seed=0)
+tr = GraphedVecTD3Trainer(env, agent, replay, start_timesteps=10000, expl_noise=0.1, batch_size=100, updates_per_step=n, seed=seed)
 ep_ret = np.zeros(n); ep_len = np.zeros(n, dtype=np.int64)
 returns, lengths, at_step = [], [], []
 evals = []
 t0 = time.time()
 next_eval = 0
-out_path = os.path.join(ROOT, "gpurun_out", "r03_reference_recipe_curve.json")
+out_path = os.path.join(ROOT, "gpurun_out", "r03_reference_recipe_curve.json" if (seed == 0 and n == 16) else "r03_reference_recipe_curve_seed%d_n%d.json" % (seed, n))
 os.makedirs(os.path.dirname(out_path), exist_ok=True)
 ref = np.load(os.path.join(ROOT, "tests", "golden", "ref_training_log_summary.npz"))
 
@@ -38,7 +39,7 @@ ref = np.load(os.path.join(ROOT, "tests", "golden", "ref_training_log_summary.np
 def dump(final=False):
     r = np.array(returns); ln = np.array(lengths)
     blocks = [float(r[i:i + 1000].mean()) for i in range(0, len(r) - 999, 1000)]
-    res = dict(recipe=dict(envs=n, env_dtype=str(dtype), start_timesteps=10000, expl_noise=0.1, batch=100, updates_per_env_step=1.0, replay=1000000,
+    res = dict(recipe=dict(envs=n, seed=seed, env_dtype=str(dtype), start_timesteps=10000, expl_noise=0.1, batch=100, updates_per_env_step=1.0, replay=1000000,
                            policy_freq=2, note="n envs step together, then n updates of batch 100 (same update-to-data ratio as plen_td3.py:119-120)"),
                wall_s=round(time.time() - t0, 1), env_steps=int(tr.env_steps), grad_steps=int(tr.grad_steps), episodes=len(returns),
                training_episode_return_block_means_1000=blocks,
