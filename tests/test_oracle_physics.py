@@ -229,3 +229,27 @@ def _fall_through_both_formulations(nit):
         assert info["iterations"] == e.contacts()["iterations"]
         errs.append(np.abs(s1n - s1).max())
     return box_slots, foot_and_box, errs, e, s0
+
+
+def test_fully_planted_feet_lend_their_fourth_slots_to_a_touching_link():
+    """Round 3 (the 8-slot cap): both feet flat on the ground (8 foot points) and the right hand's box on the floor -- the oracle gives the hand the right
+    foot's fourth slot, leaves the left foot its four points (nobody took slot 7), agrees with the NumPy model on the slots, and the hand carries load:
+    pressed down for 0.2 s it stays on the floor, while without body contacts it sinks centimetres.  (tests/test_box_contacts_gpu.py holds the kernel to it.)"""
+    from test_box_contacts_gpu import HAND_DOWN_STATE, R_HAND_BOX, _hand_low
+    s0 = np.array(HAND_DOWN_STATE)
+    o = OracleEnv(); o.set_state(s0)
+    own, pos = o.contact_slots(run_collide=True)
+    assert own.tolist() == [-1, -1, -1, R_HAND_BOX, -1, -1, -1, -1]
+    info = {}
+    nm.substep(s0, s0[13:31].copy(), info=info)
+    slots = info["slots"]
+    assert [("box" if sl["kind"] == "box" else "foot") if sl is not None else None for sl in slots] == ["foot"] * 3 + ["box"] + ["foot"] * 4
+    assert slots[3]["box"] == R_HAND_BOX
+    tgt = s0[13:31].copy(); tgt[12] += 0.5
+    low = {}
+    for bc in (True, False):
+        o = OracleEnv(); o.set_friction(rolling=0.0); o.set_body_contacts(bc); o.set_state(s0); o.set_targets(tgt)
+        for _ in range(48):
+            o.substep()
+        low[bc] = _hand_low(o.get_state())
+    assert low[True] > -0.001 and low[False] < -0.02, low
