@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SRC = os.path.join(CSRC, "plenvec.hip")
 OUT = os.path.join(CSRC, "libplenvec.so")
-DEPS = [SRC, os.path.join(CSRC, "plen_model_gen.h"), os.path.join(os.path.dirname(_HERE), "include", "plenvec.h")]
+DEPS = [SRC, os.path.join(CSRC, "plen_model_gen.h"), os.path.join(CSRC, "plen_motor_pass_gen.h"), os.path.join(os.path.dirname(_HERE), "include", "plenvec.h")]
 
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared"]

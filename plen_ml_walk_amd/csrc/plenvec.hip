@@ -226,28 +226,9 @@ __device__ __forceinline__ float wrlane(float dst, float val, int lane) {
 }
 // f64: two v_writelane_b32 on the halves (val is wave-uniform: it comes from a v_readlane broadcast).  The former `lane == L ? val : dst`
 // cost a v_mov + v_cndmask per half AND one live 64-bit lane mask per row, i.e. ~50 SGPR pairs held (and spilled) across the solver loop.
-// f64 commit of the wave-uniform `val` into lane L of `dst`: ONE v_mov_b64 under an EXEC mask of that lane.  The f64 kernel runs 2 waves per SIMD
-// and is bound by the VALU issue port (a v_writelane_b32 costs the port about as much as a v_fma_f64, profiles/r02_valu_issue.txt), while its
-// scalar unit idles: two v_writelane_b32 (+ their wait states) become one vector move, the EXEC writes ride on the scalar port.
-// MEASURED (round 3, scripts/gpu_ab64.py, same box): SLOWER, 4.99 against 5.26 M env-steps/s -- three scalar instructions and two EXEC writes per row
-// lengthen the wave's own dependent chain by more than the saved vector slot is worth: at 2 waves per SIMD the f64 kernel is bound by per-wave latency,
-// not by the VALU port.  Kept behind -DPLENVEC_F64_EXEC_COMMIT as the record of that experiment; the product build uses the v_writelane pair below.
-#ifdef PLENVEC_F64_EXEC_COMMIT
-template <int L>
-__device__ __forceinline__ double wrlane(double dst, double val, int lane) {
-    (void)lane;
-    unsigned long long keep;
-    const long long v = __builtin_bit_cast(long long, val);
-    const long long sv = ((long long)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffLL));
-    if constexpr (L < 32)
-        asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %3\n\tv_mov_b64 %0, %2\n\ts_mov_b64 exec, %1" : "+v"(dst), "=&s"(keep) : "s"(sv), "n"(1u << (L & 31)));
-    else
-        asm volatile("s_mov_b64 %1, exec\n\ts_mov_b32 exec_lo, 0\n\ts_mov_b32 exec_hi, %3\n\tv_mov_b64 %0, %2\n\ts_mov_b64 exec, %1" : "+v"(dst), "=&s"(keep) : "s"(sv), "n"(1u << (L & 31)));
-    return dst;
-}
-template <int L>
-__device__ __forceinline__ double wrlane_late(double dst, double val) { return wrlane<L>(dst, val, 0); }
-#else
+// (Compiler path only since round 3: the fast path's rows clamp under EXEC = {lane L} straight into the destination, see f64_row_asm.
+// An EXEC-masked v_mov_b64 of the already broadcast value, tried before that, was 5 % SLOWER than this pair: three scalar instructions added
+// to the wave's dependent chain for one vector slot saved.)
 template <int L>
 __device__ __forceinline__ double wrlane(double dst, double val, int lane) {
     (void)lane;
@@ -265,7 +246,6 @@ __device__ __forceinline__ double wrlane_late(double dst, double val) {
     asm volatile("s_nop 0\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4" : "+v"(lo), "+v"(hi) : "s"(slo), "s"(shi), "i"(L));
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
-#endif
 // d = clamp(-e, lo, hi) of a solver row.  f64: written as the two instructions it is.  From fmin(fmax(-e, lo), hi) the compiler makes three wherever it
 // cannot prove e free of signalling NaNs (after every asm / scheduling barrier, i.e. in every contact row): a canonicalising v_max_f64 x, x, x first,
 // one more dependent f64 instruction per row of a latency-bound chain (122 of them in the solver loop).
@@ -373,6 +353,7 @@ __device__ __forceinline__ void for_foot_points(unsigned act, F &&row) {
 }
 
 static constexpr int NC_ORDER[ND] = {NC_ORDER_LIST};
+#include "plen_motor_pass_gen.h"
 __host__ __device__ constexpr int port_normal(int c) { return 18 + 15 * (c / 4) + 3 + 3 * (c % 4); }
 // Lanes of the ports.  Joint port d sits in lane d.  Contact point c (0..7) owns the quad of lanes 20+4c..23+4c (normal, t1, t2, unused),
 // so that its lateral pair exchanges values with DPP quad_perm and reads the normal row's limit with a quad broadcast.  The three
@@ -389,44 +370,35 @@ __device__ __forceinline__ unsigned absbits(float x) { return __builtin_bit_cast
 __device__ __forceinline__ unsigned absbits(double x) { return __builtin_bit_cast(unsigned, (float)x) & 0x7fffffffu; }
 
 
-// One f64 solver row as a hand-written block (FAST path): the hi half of the commit sits in the wait states between the v_readlane pair and the
-// v_fmac_f64 that reads the SGPR pair, the lo half right after the v_fmac (in the latency shadow of the next row's clamp): 7 VALU + 2 waits
-// instead of 7 VALU + 4.  Same operations on the same values as the compiler path.  (-DPLENVEC_F64_ROW_LATE keeps the former layout for A/B.)
-template <int L, bool NEGLO = false>
+// One f64 solver row as a hand-written block (FAST path).  The clamp runs under EXEC = {lane L} and writes the row's delta straight into lane L of the
+// per-pass vector (DVR selects it: 0 = dvec in v[2:3], 1..4 = the torsional rows' dv0..dv3 in v[4:5] .. v[10:11]; fixed registers because inline
+// asm cannot name the halves of a 64-bit operand), EXEC is back to all lanes before the v_readlane pair broadcasts it: 5 vector + 2 scalar
+// instructions where the v_writelane commit took 7 vector ones.  Same operations on the same values as the compiler path.
+#define PLEN_F64_ROW_EXEC(LO_, DV_, DVL_, DVH_)                                                                                           \
+    asm volatile("s_lshl_b64 exec, 1, %[pp]\n\t"                                                                                          \
+                 "v_max_f64 " DV_ ", -%[e], " LO_ "\n\t"                                                                                  \
+                 "v_min_f64 " DV_ ", " DV_ ", %[hi]\n\t"                                                                                  \
+                 "s_mov_b64 exec, -1\n\t"                                                                                                 \
+                 "v_readlane_b32 s4, " DVL_ ", %[pp]\n\t"                                                                                 \
+                 "v_readlane_b32 s5, " DVH_ ", %[pp]\n\t"                                                                                 \
+                 "s_nop 1\n\t"                                                                                                            \
+                 "v_fmac_f64 %[e], s[4:5], %[a]\n\t"                                                                                      \
+                 : [e] "+v"(e), "+{" DV_ "}"(dvec)                                                                                        \
+                 : [lo] "v"(lo), [hi] "v"(hi), [a] "v"(acol), [pp] "i"(L)                                                                 \
+                 : "s4", "s5", "scc")
+template <int L, bool NEGLO = false, int DVR = 0>
 __device__ __forceinline__ void f64_row_asm(double &e, const double lo, const double hi, double &dvec, const double acol) {
-    const long long dvb = __builtin_bit_cast(long long, dvec);
-    int dlo = (int)(dvb & 0xffffffffLL), dhi = (int)(dvb >> 32);
-    if constexpr (NEGLO) {           // the lower bound arrives as its negative (torsional rows: -(lim + u) kept as lim + u): a source modifier instead of an instruction
-        asm volatile(
-            "v_max_f64 v[0:1], -%[e], -%[lo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[hi]\n\t"
-            "s_nop 0\n\t"
-            "v_readlane_b32 s5, v1, %[pp]\n\t"
-            "v_readlane_b32 s4, v0, %[pp]\n\t"
-            "s_nop 0\n\t"
-            "v_writelane_b32 %[dhi], s5, %[pp]\n\t"
-            "v_fmac_f64 %[e], s[4:5], %[a]\n\t"
-            "v_writelane_b32 %[dlo], s4, %[pp]\n\t"
-            : [e] "+v"(e), [dlo] "+v"(dlo), [dhi] "+v"(dhi)
-            : [lo] "v"(lo), [hi] "v"(hi), [a] "v"(acol), [pp] "i"(L)
-            : "v0", "v1", "s4", "s5");
-        dvec = __builtin_bit_cast(double, ((long long)dhi << 32) | (unsigned int)dlo);
-        return;
+    // NEGLO: the lower bound arrives as its negative (torsional rows: -(lim + u) kept as lim + u): a source modifier instead of an instruction
+    if constexpr (NEGLO) {
+        if constexpr (DVR == 0) PLEN_F64_ROW_EXEC("-%[lo]", "v[2:3]", "v2", "v3");
+        else if constexpr (DVR == 1) PLEN_F64_ROW_EXEC("-%[lo]", "v[4:5]", "v4", "v5");
+        else if constexpr (DVR == 2) PLEN_F64_ROW_EXEC("-%[lo]", "v[6:7]", "v6", "v7");
+        else if constexpr (DVR == 3) PLEN_F64_ROW_EXEC("-%[lo]", "v[8:9]", "v8", "v9");
+        else PLEN_F64_ROW_EXEC("-%[lo]", "v[10:11]", "v10", "v11");
+    } else {
+        static_assert(DVR == 0, "only the torsional rows use dv0..dv3");
+        PLEN_F64_ROW_EXEC("%[lo]", "v[2:3]", "v2", "v3");
     }
-    asm volatile(
-        "v_max_f64 v[0:1], -%[e], %[lo]\n\t"
-        "v_min_f64 v[0:1], v[0:1], %[hi]\n\t"
-        "s_nop 0\n\t"
-        "v_readlane_b32 s5, v1, %[pp]\n\t"
-        "v_readlane_b32 s4, v0, %[pp]\n\t"
-        "s_nop 0\n\t"
-        "v_writelane_b32 %[dhi], s5, %[pp]\n\t"
-        "v_fmac_f64 %[e], s[4:5], %[a]\n\t"
-        "v_writelane_b32 %[dlo], s4, %[pp]\n\t"
-        : [e] "+v"(e), [dlo] "+v"(dlo), [dhi] "+v"(dhi)
-        : [lo] "v"(lo), [hi] "v"(hi), [a] "v"(acol), [pp] "i"(L)
-        : "v0", "v1", "s4", "s5");
-    dvec = __builtin_bit_cast(double, ((long long)dhi << 32) | (unsigned int)dlo);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -438,30 +410,33 @@ __device__ __forceinline__ void f64_row_asm(double &e, const double lo, const do
 // i.e. the dependent chain through e is  med3 -> readlane -> fmac.  d is Bullet's per-row residual
 // "deltaVel"; each lane keeps the max |d| of the rows it hosted and the exit test is one compare + ballot
 // (the rare joint-limit rows keep a scalar max of IEEE bits, res_i).
-// The commit is deferred: the row's delta is dropped into lane PP of `dvec` with v_writelane and the caller
-// applies  blo -= dvec (bhi -= dvec)  once after the pass; valid because a lane hosts at most one such row
-// per pass.  (Measured alternatives, all slower: narrowing EXEC to lane PP, an LDS slot written by lane PP,
-// skipping the broadcast of zero deltas with a scalar branch.)
-// f32 fast path: hand-written; the compiler path does the same arithmetic in the same order and tests
-// assert the two are bit-identical.
+// The commit is deferred: the row's delta lands in lane PP of `dvec` and the caller applies  blo -= dvec (bhi -= dvec)  once after the
+// pass; valid because a lane hosts at most one such row per pass.  Fast paths (hand-written): the clamp itself runs under EXEC = {lane PP}
+// with `dvec` as its destination, so the commit costs no vector instruction at all -- s_lshl_b64 exec | clamp | s_mov_b64 exec, -1 |
+// v_readlane | fmac: 3 (f32) / 5 (f64) vector instructions per row where the v_writelane commit of rounds 1-2 took 4 / 7; the two EXEC
+// writes ride on the scalar port, which the solver leaves idle, and the second fills the wait state between the clamp and the
+// v_readlane.  Worth +1 % (f64) / +1.3 % (f32, whose motor pass keeps the pipelined v_writelane form) end to end and -15 % on the cone
+// pairs: one more instruction slot on the wave's dependent chain eats most of what the two vector slots save (scripts/ubench/row_exec.hip
+// shows +38 % for rows alone at 2 waves per SIMD; the kernel is bound by the chain).  (Measured alternatives, all slower than v_writelane:
+// EXEC narrowed around a SEPARATE commit instruction -- `v_sub` pair, LDS slot, v_mov_b64 --; skipping the broadcast of zero deltas with a
+// scalar branch.)  The compiler path does the same arithmetic in the same order and tests assert the two
+// are bit-identical.
 template <bool FAST, int PP, typename real>
 __device__ __forceinline__ void pgs_row2d(real &e, const real blo, const real bhi, real &dvec, const real acol, const int lane) {
     if constexpr (FAST && sizeof(real) == 4) {
-        float d;
         int sd;
         asm volatile(
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "s_nop 0\n\t"
-            "v_readlane_b32 %[sd], %[d], %[pp]\n\t"
+            "s_lshl_b64 exec, 1, %[pp]\n\t"
+            "v_med3_f32 %[dv], -%[e], %[blo], %[bhi]\n\t"
+            "s_mov_b64 exec, -1\n\t"
+            "v_readlane_b32 %[sd], %[dv], %[pp]\n\t"
             "s_nop 1\n\t"
-            "v_writelane_b32 %[dv], %[sd], %[pp]\n\t"
             "v_fmac_f32 %[e], %[sd], %[a]\n\t"
-            : [d] "=&v"(d), [sd] "=&s"(sd), [dv] "+v"(dvec), [e] "+v"(e)
-            : [blo] "v"(blo), [bhi] "v"(bhi), [a] "v"(acol), [pp] "i"(lane_of_port(PP)));
+            : [sd] "=&s"(sd), [dv] "+v"(dvec), [e] "+v"(e)
+            : [blo] "v"(blo), [bhi] "v"(bhi), [a] "v"(acol), [pp] "i"(lane_of_port(PP))
+            : "scc");
     }
-#ifndef PLENVEC_F64_ROW_LATE
     else if constexpr (FAST && sizeof(real) == 8) f64_row_asm<lane_of_port(PP)>(e, blo, bhi, dvec, acol);
-#endif
     else {
 #pragma clang fp contract(off)
         const real d = clamp_neg(e, blo, bhi);
@@ -476,521 +451,23 @@ __device__ __forceinline__ void pgs_row2d(real &e, const real blo, const real bh
         }
     }
 }
-// The 18 motor rows of one pass as ONE software-pipelined block (f32 fast path): the v_writelane that commits
-// row i-1 sits in the wait state between row i's v_med3 and its v_readlane, so a row costs
-// med3 | writelane(prev) | readlane | s_nop 1 | fmac  = 4 VALU + 1 wait instead of 4 VALU + 2 waits.
+// The 18 motor rows of one pass as ONE straight-line block (fast paths; text generated by tools/gen_motor_pass.py into plen_motor_pass_gen.h).
 // REV = false: Bullet's sorted order NC_ORDER (odd iterations), REV = true: reversed (even iterations).
+//   f64: per row  s_lshl_b64 exec, 1, lane | clamp into dvec = v[2:3] (that lane only) | s_mov_b64 exec, -1 | v_readlane pair | s_nop 1 | fmac.
+//   f32: software-pipelined v_writelane commits -- the v_writelane of row i-1 sits in the wait state between row i's v_med3 and its v_readlane:
+//        med3 | writelane(prev) | readlane | s_nop 1 | fmac = 4 VALU + 1 wait.  At 4 waves per SIMD this beats the EXEC form (11.15 against
+//        10.97 M env-steps/s, scripts/gpu_ab64.py); for the f64 kernel's 2 waves it is the other way round (5.68 against 5.61 M).
 template <bool FAST, bool REV, typename real>
 __device__ __forceinline__ void pgs_motor_pass(real &e, const real blo, const real bhi, real &dvec, const real (&Ar)[NPORT], const int lane) {
+    static_assert(PLEN_MOTOR_PASS_ORDER_CHECK(NC_ORDER), "plen_motor_pass_gen.h is stale: run tools/gen_motor_pass.py");
     if constexpr (FAST && sizeof(real) == 4) {
-        static_assert(NC_ORDER[0] == 6 && NC_ORDER[1] == 5 && NC_ORDER[2] == 8 && NC_ORDER[3] == 7 && NC_ORDER[4] == 4 && NC_ORDER[5] == 1 &&
-                      NC_ORDER[6] == 0 && NC_ORDER[7] == 3 && NC_ORDER[8] == 2 && NC_ORDER[9] == 15 && NC_ORDER[10] == 14 && NC_ORDER[11] == 17 &&
-                      NC_ORDER[12] == 16 && NC_ORDER[13] == 13 && NC_ORDER[14] == 10 && NC_ORDER[15] == 9 && NC_ORDER[16] == 12 && NC_ORDER[17] == 11,
-                      "the lane numbers in the asm below are NC_ORDER_LIST written out");
         float d;
         int sA, sB;
-        if constexpr (!REV) {
-            asm volatile(
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "s_nop 0\n\t"
-            "v_readlane_b32 %[sA], %[d], 6\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sA], %[a6]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sA], 6\n\t"
-            "v_readlane_b32 %[sB], %[d], 5\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sB], %[a5]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sB], 5\n\t"
-            "v_readlane_b32 %[sA], %[d], 8\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sA], %[a8]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sA], 8\n\t"
-            "v_readlane_b32 %[sB], %[d], 7\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sB], %[a7]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sB], 7\n\t"
-            "v_readlane_b32 %[sA], %[d], 4\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sA], %[a4]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sA], 4\n\t"
-            "v_readlane_b32 %[sB], %[d], 1\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sB], %[a1]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sB], 1\n\t"
-            "v_readlane_b32 %[sA], %[d], 0\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sA], %[a0]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sA], 0\n\t"
-            "v_readlane_b32 %[sB], %[d], 3\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sB], %[a3]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sB], 3\n\t"
-            "v_readlane_b32 %[sA], %[d], 2\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sA], %[a2]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sA], 2\n\t"
-            "v_readlane_b32 %[sB], %[d], 15\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sB], %[a15]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sB], 15\n\t"
-            "v_readlane_b32 %[sA], %[d], 14\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sA], %[a14]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sA], 14\n\t"
-            "v_readlane_b32 %[sB], %[d], 17\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sB], %[a17]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sB], 17\n\t"
-            "v_readlane_b32 %[sA], %[d], 16\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sA], %[a16]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sA], 16\n\t"
-            "v_readlane_b32 %[sB], %[d], 13\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sB], %[a13]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sB], 13\n\t"
-            "v_readlane_b32 %[sA], %[d], 10\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sA], %[a10]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sA], 10\n\t"
-            "v_readlane_b32 %[sB], %[d], 9\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sB], %[a9]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sB], 9\n\t"
-            "v_readlane_b32 %[sA], %[d], 12\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sA], %[a12]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sA], 12\n\t"
-            "v_readlane_b32 %[sB], %[d], 11\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sB], %[a11]\n\t"
-            "v_writelane_b32 %[dv], %[sB], 11\n\t"
-            : [d] "=&v"(d), [sA] "=&s"(sA), [sB] "=&s"(sB), [dv] "+v"(dvec), [e] "+v"(e)
-            : [blo] "v"(blo), [bhi] "v"(bhi), [a0] "v"(Ar[0]), [a1] "v"(Ar[1]), [a2] "v"(Ar[2]), [a3] "v"(Ar[3]), [a4] "v"(Ar[4]), [a5] "v"(Ar[5]), [a6] "v"(Ar[6]), [a7] "v"(Ar[7]), [a8] "v"(Ar[8]), [a9] "v"(Ar[9]), [a10] "v"(Ar[10]), [a11] "v"(Ar[11]), [a12] "v"(Ar[12]), [a13] "v"(Ar[13]), [a14] "v"(Ar[14]), [a15] "v"(Ar[15]), [a16] "v"(Ar[16]), [a17] "v"(Ar[17]));
-        } else {
-            asm volatile(
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "s_nop 0\n\t"
-            "v_readlane_b32 %[sA], %[d], 11\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sA], %[a11]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sA], 11\n\t"
-            "v_readlane_b32 %[sB], %[d], 12\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sB], %[a12]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sB], 12\n\t"
-            "v_readlane_b32 %[sA], %[d], 9\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sA], %[a9]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sA], 9\n\t"
-            "v_readlane_b32 %[sB], %[d], 10\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sB], %[a10]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sB], 10\n\t"
-            "v_readlane_b32 %[sA], %[d], 13\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sA], %[a13]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sA], 13\n\t"
-            "v_readlane_b32 %[sB], %[d], 16\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sB], %[a16]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sB], 16\n\t"
-            "v_readlane_b32 %[sA], %[d], 17\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sA], %[a17]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sA], 17\n\t"
-            "v_readlane_b32 %[sB], %[d], 14\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sB], %[a14]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sB], 14\n\t"
-            "v_readlane_b32 %[sA], %[d], 15\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sA], %[a15]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sA], 15\n\t"
-            "v_readlane_b32 %[sB], %[d], 2\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sB], %[a2]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sB], 2\n\t"
-            "v_readlane_b32 %[sA], %[d], 3\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sA], %[a3]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sA], 3\n\t"
-            "v_readlane_b32 %[sB], %[d], 0\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sB], %[a0]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sB], 0\n\t"
-            "v_readlane_b32 %[sA], %[d], 1\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sA], %[a1]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sA], 1\n\t"
-            "v_readlane_b32 %[sB], %[d], 4\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sB], %[a4]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sB], 4\n\t"
-            "v_readlane_b32 %[sA], %[d], 7\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sA], %[a7]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sA], 7\n\t"
-            "v_readlane_b32 %[sB], %[d], 8\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sB], %[a8]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sB], 8\n\t"
-            "v_readlane_b32 %[sA], %[d], 5\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sA], %[a5]\n\t"
-            "v_med3_f32 %[d], -%[e], %[blo], %[bhi]\n\t"
-            "v_writelane_b32 %[dv], %[sA], 5\n\t"
-            "v_readlane_b32 %[sB], %[d], 6\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f32 %[e], %[sB], %[a6]\n\t"
-            "v_writelane_b32 %[dv], %[sB], 6\n\t"
-            : [d] "=&v"(d), [sA] "=&s"(sA), [sB] "=&s"(sB), [dv] "+v"(dvec), [e] "+v"(e)
-            : [blo] "v"(blo), [bhi] "v"(bhi), [a0] "v"(Ar[0]), [a1] "v"(Ar[1]), [a2] "v"(Ar[2]), [a3] "v"(Ar[3]), [a4] "v"(Ar[4]), [a5] "v"(Ar[5]), [a6] "v"(Ar[6]), [a7] "v"(Ar[7]), [a8] "v"(Ar[8]), [a9] "v"(Ar[9]), [a10] "v"(Ar[10]), [a11] "v"(Ar[11]), [a12] "v"(Ar[12]), [a13] "v"(Ar[13]), [a14] "v"(Ar[14]), [a15] "v"(Ar[15]), [a16] "v"(Ar[16]), [a17] "v"(Ar[17]));
-        }
+        if constexpr (!REV) asm volatile(PLEN_MOTOR_F32_FWD : [d] "=&v"(d), [sA] "=&s"(sA), [sB] "=&s"(sB), [dv] "+v"(dvec), [e] "+v"(e) : [blo] "v"(blo), [bhi] "v"(bhi), PLEN_MOTOR_A_OPERANDS(Ar));
+        else asm volatile(PLEN_MOTOR_F32_REV : [d] "=&v"(d), [sA] "=&s"(sA), [sB] "=&s"(sB), [dv] "+v"(dvec), [e] "+v"(e) : [blo] "v"(blo), [bhi] "v"(bhi), PLEN_MOTOR_A_OPERANDS(Ar));
     } else if constexpr (FAST && sizeof(real) == 8) {
-        // f64: the same software pipeline as the f32 block above (generated text: rows in NC_ORDER, SGPR pairs s[4:5] / s[38:39] alternating, the
-        // clamp's result in v[0:1]).  The two v_writelane_b32 that commit row i-1 sit in the wait states of row i -- one after its v_min_f64 (VALU
-        // wrote the VGPR the v_readlane reads), one in the two wait states between the v_readlane and the v_fmac_f64 that reads the SGPR pair --
-        // so a row is 7 VALU + 1 wait instead of 7 VALU + 4 waits on the wave's dependent chain; same operations on the same values as the
-        // compiler path (bit-identical, tests/test_env_gpu.py::test_asm_path_bitwise_equals_compiler_path).  dvec travels as two 32-bit halves.
-        static_assert(NC_ORDER[0] == 6 && NC_ORDER[8] == 2 && NC_ORDER[9] == 15 && NC_ORDER[17] == 11, "the lane numbers in the asm below are NC_ORDER_LIST written out");
-        const long long dvb = __builtin_bit_cast(long long, dvec);
-        int dlo = (int)(dvb & 0xffffffffLL), dhi = (int)(dvb >> 32);
-        if constexpr (!REV) {
-            asm volatile(
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "s_nop 0\n\t"
-            "v_readlane_b32 s5, v1, 6\n\t"
-            "v_readlane_b32 s4, v0, 6\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f64 %[e], s[4:5], %[a6]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s4, 6\n\t"
-            "v_readlane_b32 s39, v1, 5\n\t"
-            "v_readlane_b32 s38, v0, 5\n\t"
-            "v_writelane_b32 %[dhi], s5, 6\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[38:39], %[a5]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s38, 5\n\t"
-            "v_readlane_b32 s5, v1, 8\n\t"
-            "v_readlane_b32 s4, v0, 8\n\t"
-            "v_writelane_b32 %[dhi], s39, 5\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[4:5], %[a8]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s4, 8\n\t"
-            "v_readlane_b32 s39, v1, 7\n\t"
-            "v_readlane_b32 s38, v0, 7\n\t"
-            "v_writelane_b32 %[dhi], s5, 8\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[38:39], %[a7]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s38, 7\n\t"
-            "v_readlane_b32 s5, v1, 4\n\t"
-            "v_readlane_b32 s4, v0, 4\n\t"
-            "v_writelane_b32 %[dhi], s39, 7\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[4:5], %[a4]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s4, 4\n\t"
-            "v_readlane_b32 s39, v1, 1\n\t"
-            "v_readlane_b32 s38, v0, 1\n\t"
-            "v_writelane_b32 %[dhi], s5, 4\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[38:39], %[a1]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s38, 1\n\t"
-            "v_readlane_b32 s5, v1, 0\n\t"
-            "v_readlane_b32 s4, v0, 0\n\t"
-            "v_writelane_b32 %[dhi], s39, 1\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[4:5], %[a0]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s4, 0\n\t"
-            "v_readlane_b32 s39, v1, 3\n\t"
-            "v_readlane_b32 s38, v0, 3\n\t"
-            "v_writelane_b32 %[dhi], s5, 0\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[38:39], %[a3]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s38, 3\n\t"
-            "v_readlane_b32 s5, v1, 2\n\t"
-            "v_readlane_b32 s4, v0, 2\n\t"
-            "v_writelane_b32 %[dhi], s39, 3\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[4:5], %[a2]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s4, 2\n\t"
-            "v_readlane_b32 s39, v1, 15\n\t"
-            "v_readlane_b32 s38, v0, 15\n\t"
-            "v_writelane_b32 %[dhi], s5, 2\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[38:39], %[a15]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s38, 15\n\t"
-            "v_readlane_b32 s5, v1, 14\n\t"
-            "v_readlane_b32 s4, v0, 14\n\t"
-            "v_writelane_b32 %[dhi], s39, 15\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[4:5], %[a14]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s4, 14\n\t"
-            "v_readlane_b32 s39, v1, 17\n\t"
-            "v_readlane_b32 s38, v0, 17\n\t"
-            "v_writelane_b32 %[dhi], s5, 14\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[38:39], %[a17]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s38, 17\n\t"
-            "v_readlane_b32 s5, v1, 16\n\t"
-            "v_readlane_b32 s4, v0, 16\n\t"
-            "v_writelane_b32 %[dhi], s39, 17\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[4:5], %[a16]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s4, 16\n\t"
-            "v_readlane_b32 s39, v1, 13\n\t"
-            "v_readlane_b32 s38, v0, 13\n\t"
-            "v_writelane_b32 %[dhi], s5, 16\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[38:39], %[a13]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s38, 13\n\t"
-            "v_readlane_b32 s5, v1, 10\n\t"
-            "v_readlane_b32 s4, v0, 10\n\t"
-            "v_writelane_b32 %[dhi], s39, 13\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[4:5], %[a10]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s4, 10\n\t"
-            "v_readlane_b32 s39, v1, 9\n\t"
-            "v_readlane_b32 s38, v0, 9\n\t"
-            "v_writelane_b32 %[dhi], s5, 10\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[38:39], %[a9]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s38, 9\n\t"
-            "v_readlane_b32 s5, v1, 12\n\t"
-            "v_readlane_b32 s4, v0, 12\n\t"
-            "v_writelane_b32 %[dhi], s39, 9\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[4:5], %[a12]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s4, 12\n\t"
-            "v_readlane_b32 s39, v1, 11\n\t"
-            "v_readlane_b32 s38, v0, 11\n\t"
-            "v_writelane_b32 %[dhi], s5, 12\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[38:39], %[a11]\n\t"
-            "v_writelane_b32 %[dlo], s38, 11\n\t"
-            "v_writelane_b32 %[dhi], s39, 11\n\t"
-            : [e] "+v"(e), [dlo] "+v"(dlo), [dhi] "+v"(dhi)
-            : [blo] "v"(blo), [bhi] "v"(bhi), [a0] "v"(Ar[0]), [a1] "v"(Ar[1]), [a2] "v"(Ar[2]), [a3] "v"(Ar[3]), [a4] "v"(Ar[4]), [a5] "v"(Ar[5]), [a6] "v"(Ar[6]), [a7] "v"(Ar[7]), [a8] "v"(Ar[8]), [a9] "v"(Ar[9]), [a10] "v"(Ar[10]), [a11] "v"(Ar[11]), [a12] "v"(Ar[12]), [a13] "v"(Ar[13]), [a14] "v"(Ar[14]), [a15] "v"(Ar[15]), [a16] "v"(Ar[16]), [a17] "v"(Ar[17])
-            : "v0", "v1", "s4", "s5", "s38", "s39");
-        } else {
-            asm volatile(
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "s_nop 0\n\t"
-            "v_readlane_b32 s5, v1, 11\n\t"
-            "v_readlane_b32 s4, v0, 11\n\t"
-            "s_nop 1\n\t"
-            "v_fmac_f64 %[e], s[4:5], %[a11]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s4, 11\n\t"
-            "v_readlane_b32 s39, v1, 12\n\t"
-            "v_readlane_b32 s38, v0, 12\n\t"
-            "v_writelane_b32 %[dhi], s5, 11\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[38:39], %[a12]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s38, 12\n\t"
-            "v_readlane_b32 s5, v1, 9\n\t"
-            "v_readlane_b32 s4, v0, 9\n\t"
-            "v_writelane_b32 %[dhi], s39, 12\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[4:5], %[a9]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s4, 9\n\t"
-            "v_readlane_b32 s39, v1, 10\n\t"
-            "v_readlane_b32 s38, v0, 10\n\t"
-            "v_writelane_b32 %[dhi], s5, 9\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[38:39], %[a10]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s38, 10\n\t"
-            "v_readlane_b32 s5, v1, 13\n\t"
-            "v_readlane_b32 s4, v0, 13\n\t"
-            "v_writelane_b32 %[dhi], s39, 10\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[4:5], %[a13]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s4, 13\n\t"
-            "v_readlane_b32 s39, v1, 16\n\t"
-            "v_readlane_b32 s38, v0, 16\n\t"
-            "v_writelane_b32 %[dhi], s5, 13\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[38:39], %[a16]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s38, 16\n\t"
-            "v_readlane_b32 s5, v1, 17\n\t"
-            "v_readlane_b32 s4, v0, 17\n\t"
-            "v_writelane_b32 %[dhi], s39, 16\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[4:5], %[a17]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s4, 17\n\t"
-            "v_readlane_b32 s39, v1, 14\n\t"
-            "v_readlane_b32 s38, v0, 14\n\t"
-            "v_writelane_b32 %[dhi], s5, 17\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[38:39], %[a14]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s38, 14\n\t"
-            "v_readlane_b32 s5, v1, 15\n\t"
-            "v_readlane_b32 s4, v0, 15\n\t"
-            "v_writelane_b32 %[dhi], s39, 14\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[4:5], %[a15]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s4, 15\n\t"
-            "v_readlane_b32 s39, v1, 2\n\t"
-            "v_readlane_b32 s38, v0, 2\n\t"
-            "v_writelane_b32 %[dhi], s5, 15\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[38:39], %[a2]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s38, 2\n\t"
-            "v_readlane_b32 s5, v1, 3\n\t"
-            "v_readlane_b32 s4, v0, 3\n\t"
-            "v_writelane_b32 %[dhi], s39, 2\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[4:5], %[a3]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s4, 3\n\t"
-            "v_readlane_b32 s39, v1, 0\n\t"
-            "v_readlane_b32 s38, v0, 0\n\t"
-            "v_writelane_b32 %[dhi], s5, 3\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[38:39], %[a0]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s38, 0\n\t"
-            "v_readlane_b32 s5, v1, 1\n\t"
-            "v_readlane_b32 s4, v0, 1\n\t"
-            "v_writelane_b32 %[dhi], s39, 0\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[4:5], %[a1]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s4, 1\n\t"
-            "v_readlane_b32 s39, v1, 4\n\t"
-            "v_readlane_b32 s38, v0, 4\n\t"
-            "v_writelane_b32 %[dhi], s5, 1\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[38:39], %[a4]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s38, 4\n\t"
-            "v_readlane_b32 s5, v1, 7\n\t"
-            "v_readlane_b32 s4, v0, 7\n\t"
-            "v_writelane_b32 %[dhi], s39, 4\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[4:5], %[a7]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s4, 7\n\t"
-            "v_readlane_b32 s39, v1, 8\n\t"
-            "v_readlane_b32 s38, v0, 8\n\t"
-            "v_writelane_b32 %[dhi], s5, 7\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[38:39], %[a8]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s38, 8\n\t"
-            "v_readlane_b32 s5, v1, 5\n\t"
-            "v_readlane_b32 s4, v0, 5\n\t"
-            "v_writelane_b32 %[dhi], s39, 8\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[4:5], %[a5]\n\t"
-            "v_max_f64 v[0:1], -%[e], %[blo]\n\t"
-            "v_min_f64 v[0:1], v[0:1], %[bhi]\n\t"
-            "v_writelane_b32 %[dlo], s4, 5\n\t"
-            "v_readlane_b32 s39, v1, 6\n\t"
-            "v_readlane_b32 s38, v0, 6\n\t"
-            "v_writelane_b32 %[dhi], s5, 5\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64 %[e], s[38:39], %[a6]\n\t"
-            "v_writelane_b32 %[dlo], s38, 6\n\t"
-            "v_writelane_b32 %[dhi], s39, 6\n\t"
-            : [e] "+v"(e), [dlo] "+v"(dlo), [dhi] "+v"(dhi)
-            : [blo] "v"(blo), [bhi] "v"(bhi), [a0] "v"(Ar[0]), [a1] "v"(Ar[1]), [a2] "v"(Ar[2]), [a3] "v"(Ar[3]), [a4] "v"(Ar[4]), [a5] "v"(Ar[5]), [a6] "v"(Ar[6]), [a7] "v"(Ar[7]), [a8] "v"(Ar[8]), [a9] "v"(Ar[9]), [a10] "v"(Ar[10]), [a11] "v"(Ar[11]), [a12] "v"(Ar[12]), [a13] "v"(Ar[13]), [a14] "v"(Ar[14]), [a15] "v"(Ar[15]), [a16] "v"(Ar[16]), [a17] "v"(Ar[17])
-            : "v0", "v1", "s4", "s5", "s38", "s39");
-        }
-        dvec = __builtin_bit_cast(real, ((long long)dhi << 32) | (unsigned int)dlo);
+        if constexpr (!REV) asm volatile(PLEN_MOTOR_F64_FWD : [e] "+v"(e), "+{v[2:3]}"(dvec) : [blo] "v"(blo), [bhi] "v"(bhi), PLEN_MOTOR_A_OPERANDS(Ar) : "s4", "s5", "scc");
+        else asm volatile(PLEN_MOTOR_F64_REV : [e] "+v"(e), "+{v[2:3]}"(dvec) : [blo] "v"(blo), [bhi] "v"(bhi), PLEN_MOTOR_A_OPERANDS(Ar) : "s4", "s5", "scc");
     } else {
         static_for<ND>([&](auto ic) {
             constexpr int PP = NC_ORDER[REV ? ND - 1 - decltype(ic)::value : decltype(ic)::value];
@@ -1000,25 +477,23 @@ __device__ __forceinline__ void pgs_motor_pass(real &e, const real blo, const re
 }
 
 // torsional row with bounds prepared by the caller for this pass -- pt1 = lim + u (the NEGATED lower bound: the negation is a source modifier of the
-// clamp), t2 = lim - u -- and a deferred commit (u += dvec after the pass): med3 -> readlane -> writelane -> fmac
-template <bool FAST, int PP, typename real>
+// clamp), t2 = lim - u -- and a deferred commit (u += dvec after the pass) into the K-th of the four per-point delta vectors
+template <bool FAST, int PP, int K, typename real>
 __device__ __forceinline__ void pgs_rowTd(real &e, const real pt1, const real t2, real &dvec, const real acol, const int lane) {
     if constexpr (FAST && sizeof(real) == 4) {
-        float d;
         int sd;
         asm volatile(
-            "v_med3_f32 %[d], -%[e], -%[pt1], %[t2]\n\t"
-            "s_nop 0\n\t"
-            "v_readlane_b32 %[sd], %[d], %[pp]\n\t"
+            "s_lshl_b64 exec, 1, %[pp]\n\t"
+            "v_med3_f32 %[dv], -%[e], -%[pt1], %[t2]\n\t"
+            "s_mov_b64 exec, -1\n\t"
+            "v_readlane_b32 %[sd], %[dv], %[pp]\n\t"
             "s_nop 1\n\t"
-            "v_writelane_b32 %[dv], %[sd], %[pp]\n\t"
             "v_fmac_f32 %[e], %[sd], %[a]\n\t"
-            : [d] "=&v"(d), [sd] "=&s"(sd), [dv] "+v"(dvec), [e] "+v"(e)
-            : [pt1] "v"(pt1), [t2] "v"(t2), [a] "v"(acol), [pp] "i"(lane_of_port(PP)));
+            : [sd] "=&s"(sd), [dv] "+v"(dvec), [e] "+v"(e)
+            : [pt1] "v"(pt1), [t2] "v"(t2), [a] "v"(acol), [pp] "i"(lane_of_port(PP))
+            : "scc");
     }
-#ifndef PLENVEC_F64_ROW_LATE
-    else if constexpr (FAST && sizeof(real) == 8) f64_row_asm<lane_of_port(PP), true>(e, pt1, t2, dvec, acol);
-#endif
+    else if constexpr (FAST && sizeof(real) == 8) f64_row_asm<lane_of_port(PP), true, 1 + K>(e, pt1, t2, dvec, acol);
     else {
 #pragma clang fp contract(off)
         const real d = clamp_neg(e, -pt1, t2);
@@ -1067,7 +542,7 @@ __device__ __forceinline__ float quad_bcast0(float x) {
 }
 __device__ __forceinline__ double quad_bcast0(double x) { return dpp64_all<0x00 /* quad_perm:[0,0,0,0] */, false>(x); }
 
-template <int PN, typename real>
+template <bool FAST, int PN, typename real>
 __device__ __forceinline__ void pgs_cone(real &e, const real u, real &dvec, const real lmv, const real jdi, const real aA, const real aB,
                                          const int lane) {
 #pragma clang fp contract(off)      // same roundings in every instantiation: fused ops are written out
@@ -1101,33 +576,45 @@ __device__ __forceinline__ void pgs_cone(real &e, const real u, real &dvec, cons
         }
 #endif
     }
-    const real d = fma_(w, scale, -u);              // deltaVel of this lane's row
-#ifndef PLENVEC_F64_CONE_C
-    if constexpr (sizeof(real) == 8) {
-        // hand-scheduled tail (f64): four v_readlane, then the two v_fmac_f64 with the four commit v_writelane between and behind them -- every
-        // scalar operand is old enough when it is read, so the only wait state left is the one between the fma that made d and the first
-        // v_readlane (the compiler's layout had six).  Same operations, same order (A then B), same values.
-        const long long dvb = __builtin_bit_cast(long long, dvec);
-        int dlo = (int)(dvb & 0xffffffffLL), dhi = (int)(dvb >> 32);
+#ifndef PLENVEC_CONE_C
+    // hand-written tail (fast paths): the fma that makes the pair's two deltas runs under EXEC = {LA, LB} (adjacent lanes: 3 << LA) with dvec as its
+    // destination -- the commit costs nothing --, then the broadcasts and the two fmacs, A before B like the compiler path below.
+    // f64: dvec lives in v[2:3]; every scalar operand is two wait states old when its v_fmac_f64 reads it.
+    static_assert(LB == LA + 1, "the pair's lanes are adjacent");
+    if constexpr (FAST && sizeof(real) == 8) {
         asm volatile(
+            "s_lshl_b64 exec, 3, %[la]\n\t"
+            "v_fma_f64 v[2:3], %[w], %[sc], -%[u]\n\t"
+            "s_mov_b64 exec, -1\n\t"
+            "v_readlane_b32 s4, v2, %[la]\n\t"
+            "v_readlane_b32 s5, v3, %[la]\n\t"
+            "v_readlane_b32 s38, v2, %[lb]\n\t"
+            "v_readlane_b32 s39, v3, %[lb]\n\t"
             "s_nop 0\n\t"
-            "v_readlane_b32 s5, v1, %[la]\n\t"
-            "v_readlane_b32 s4, v0, %[la]\n\t"
-            "v_readlane_b32 s39, v1, %[lb]\n\t"
-            "v_readlane_b32 s38, v0, %[lb]\n\t"
-            "v_writelane_b32 %[dhi], s5, %[la]\n\t"
             "v_fmac_f64 %[e], s[4:5], %[aA]\n\t"
-            "v_writelane_b32 %[dlo], s4, %[la]\n\t"
             "v_fmac_f64 %[e], s[38:39], %[aB]\n\t"
-            "v_writelane_b32 %[dhi], s39, %[lb]\n\t"
-            "v_writelane_b32 %[dlo], s38, %[lb]\n\t"
-            : [e] "+v"(e), [dlo] "+v"(dlo), [dhi] "+v"(dhi)
-            : "{v[0:1]}"(d), [aA] "v"(aA), [aB] "v"(aB), [la] "i"(LA), [lb] "i"(LB)
-            : "s4", "s5", "s38", "s39");
-        dvec = __builtin_bit_cast(real, ((long long)dhi << 32) | (unsigned int)dlo);
+            : [e] "+v"(e), "+{v[2:3]}"(dvec)
+            : [w] "v"(w), [sc] "v"(scale), [u] "v"(u), [aA] "v"(aA), [aB] "v"(aB), [la] "i"(LA), [lb] "i"(LB)
+            : "s4", "s5", "s38", "s39", "scc");
+        return;
+    } else if constexpr (FAST) {
+        int sA, sB;
+        asm volatile(
+            "s_lshl_b64 exec, 3, %[la]\n\t"
+            "v_fma_f32 %[dv], %[w], %[sc], -%[u]\n\t"
+            "s_mov_b64 exec, -1\n\t"
+            "v_readlane_b32 %[sA], %[dv], %[la]\n\t"
+            "v_readlane_b32 %[sB], %[dv], %[lb]\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f32 %[e], %[sA], %[aA]\n\t"
+            "v_fmac_f32 %[e], %[sB], %[aB]\n\t"
+            : [e] "+v"(e), [dv] "+v"(dvec), [sA] "=&s"(sA), [sB] "=&s"(sB)
+            : [w] "v"(w), [sc] "v"(scale), [u] "v"(u), [aA] "v"(aA), [aB] "v"(aB), [la] "i"(LA), [lb] "i"(LB)
+            : "scc");
         return;
     }
 #endif
+    const real d = fma_(w, scale, -u);              // deltaVel of this lane's row
     const real dA = bcast(d, LA), dB = bcast(d, LB);
     dvec = wrlane<LA>(dvec, dA, lane); dvec = wrlane<LB>(dvec, dB, lane);     // u += dvec after the pass (no lane masks kept alive)
     e = fma_(dB, aB, fma_(dA, aA, e));
@@ -2066,7 +1553,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                 if (has_spin) {
                     for_foot_points<FEET>(act, [&](auto fc_, auto kc) {
                         constexpr int k = decltype(kc)::value, PP = 18 + 15 * decltype(fc_)::value;
-                        pgs_rowTd<FAST, PP>(e, k == 0 ? nt10 : k == 1 ? nt11 : k == 2 ? nt12 : nt13, k == 0 ? t20 : k == 1 ? t21 : k == 2 ? t22 : t23,
+                        pgs_rowTd<FAST, PP, k>(e, k == 0 ? nt10 : k == 1 ? nt11 : k == 2 ? nt12 : nt13, k == 0 ? t20 : k == 1 ? t21 : k == 2 ? t22 : t23,
                                             k == 0 ? dv0 : k == 1 ? dv1 : k == 2 ? dv2 : dv3, Ar[PP], lane);
                     });
                 }
@@ -2074,9 +1561,9 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                 if (has_roll) {
                     for_foot_points<FEET>(act, [&](auto fc_, auto kc) {
                         constexpr int k = decltype(kc)::value, PP = 18 + 15 * decltype(fc_)::value;
-                        pgs_rowTd<FAST, PP + 1>(e, k == 0 ? nt10 : k == 1 ? nt11 : k == 2 ? nt12 : nt13, k == 0 ? t20 : k == 1 ? t21 : k == 2 ? t22 : t23,
+                        pgs_rowTd<FAST, PP + 1, k>(e, k == 0 ? nt10 : k == 1 ? nt11 : k == 2 ? nt12 : nt13, k == 0 ? t20 : k == 1 ? t21 : k == 2 ? t22 : t23,
                                                 k == 0 ? dv0 : k == 1 ? dv1 : k == 2 ? dv2 : dv3, Ar[PP + 1], lane);
-                        pgs_rowTd<FAST, PP + 2>(e, k == 0 ? nt10 : k == 1 ? nt11 : k == 2 ? nt12 : nt13, k == 0 ? t20 : k == 1 ? t21 : k == 2 ? t22 : t23,
+                        pgs_rowTd<FAST, PP + 2, k>(e, k == 0 ? nt10 : k == 1 ? nt11 : k == 2 ? nt12 : nt13, k == 0 ? t20 : k == 1 ? t21 : k == 2 ? t22 : t23,
                                                 k == 0 ? dv0 : k == 1 ? dv1 : k == 2 ? dv2 : dv3, Ar[PP + 2], lane);
                     });
                 }
@@ -2090,7 +1577,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                 const real lmv = quad_bcast0(mul_rn_(nfcn, blo));
                 for_foot_points<FEET>(act, [&](auto fc_, auto kc) {
                     constexpr int PN = port_normal(4 * decltype(fc_)::value + decltype(kc)::value);
-                    pgs_cone<PN>(e, u0, dvec, lmv, jdi, Ar[PN + 1], Ar[PN + 2], lane);
+                    pgs_cone<FAST, PN>(e, u0, dvec, lmv, jdi, Ar[PN + 1], Ar[PN + 2], lane);
                 });
             }
             // Bullet's residual of a pair is |dA + dB|: after the pass every pair's deltas sit in its two lanes of dvec,

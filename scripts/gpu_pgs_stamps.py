@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 sys.path.insert(0, ROOT)
 from plen_ml_walk_amd.build import build_variant
-os.environ["PLENVEC_LIB"] = build_variant("stamps", ["-DPGS_STAMPS"])
+os.environ["PLENVEC_LIB"] = os.environ.get("STAMPS_LIB") or build_variant("stamps", ["-DPGS_STAMPS"])      # STAMPS_LIB: a -DPGS_STAMPS build of another source (A/B)
 from plen_ml_walk_amd.vec_env import PlenVecEnv
 names = ["motors(+limits)", "normals", "tors bounds", "spin rows", "roll rows", "cone pairs", "wave max"]
 dtype = torch.float64 if len(sys.argv) > 1 and sys.argv[1] == "f64" else torch.float32
