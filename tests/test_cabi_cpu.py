@@ -77,3 +77,17 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "plen_oracle" not in txt, f
+
+
+def test_generated_motor_pass_header_is_current(tmp_path):
+    """plen_motor_pass_gen.h (the solver's 18 motor rows as assembly text) is what tools/gen_motor_pass.py writes for the NC_ORDER_LIST of plenvec.hip."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_motor_pass", os.path.join(ROOT, "tools", "gen_motor_pass.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    committed = open(g.OUT).read()
+    g.OUT = str(tmp_path / "gen.h")
+    g.main()
+    assert open(g.OUT).read() == committed
+    order = g.nc_order()
+    assert sorted(order) == list(range(18)) and "order: " + ", ".join(map(str, order)) in committed
