@@ -311,6 +311,11 @@ __device__ __forceinline__ double gather_addr(double x, int addr4) {
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
+// an empty volatile asm on x: volatile asms keep their program order, so everything x depends on is issued before the next pin_order()
+#ifndef PIN_F32
+#define PIN_F32 0
+#endif
+template <typename T> __device__ __forceinline__ void pin_order(T &x) { asm volatile("" : "+v"(x)); }
 // all 64 lanes of the single-wave workgroup see each other's LDS writes after this
 #define WSYNC() __syncthreads()
 
@@ -1097,6 +1102,16 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             constexpr int J = decltype(jc)::value;
             if constexpr (l_nz(K, J)) Lr[J] -= lik * bcast(lik, J);
         });
+        // f64: a broadcast is an SGPR pair.  Left alone, the compiler turns this right-looking update into a left-looking one -- every product
+        // lik * bcast(lik, J) is applied only when column J becomes the pivot, its broadcast held in scalar registers until then: ~100 of them
+        // spilled into VGPR lanes and read back (half of the f64 kernel's SGPR spill traffic).  An empty volatile asm on the updated columns
+        // pins the order (volatile asms keep theirs): a column's broadcasts die with the column.
+        if constexpr (sizeof(real) == 8 || PIN_F32) {
+            static_for<K>([&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                if constexpr (l_nz(K, J)) pin_order(Lr[J]);
+            });
+        }
     });
     if (lane < NV) {
 #pragma unroll
