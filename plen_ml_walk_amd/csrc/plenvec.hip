@@ -1297,21 +1297,56 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     WSYNC();
     // own Jacobian row into registers, b = J v*, then Y = L^-T J^T by back substitution (A = J M^-1 J^T = Y^T Y)
     real Jr[NV];
+    if constexpr (sizeof(real) == 8) {
 #pragma unroll
-    for (int j = 0; j < NV; j++) Jr[j] = is_joint ? (j == 6 + p ? (real)1 : (real)0) : s.YT[j][p];
+        for (int j = 0; j < NV; j++) {
+            const real y = s.YT[j][p];     // read by every lane (a joint lane's p < 18 is a valid column): 24 loads in flight, not 24 divergent branches with a wait each
+            Jr[j] = is_joint ? (j == 6 + p ? (real)1 : (real)0) : y;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NV; j++) Jr[j] = is_joint ? (j == 6 + p ? (real)1 : (real)0) : s.YT[j][p];
+    }
     real bvel = 0;
 #pragma unroll
     for (int j = 0; j < NV; j++) bvel += Jr[j] * s.v[j];
     // (the inverse diagonal of L is in s.col since phase C)
-    static_for<NV>([&](auto ic) {                 // L^T y = J^T, descending; only the supported entries of L
-        constexpr int I = NV - 1 - decltype(ic)::value;
-        real acc = Jr[I];
-        static_for<NV - 1 - I>([&](auto rc) {
-            constexpr int R = I + 1 + decltype(rc)::value;
-            if constexpr (l_nz(R, I)) acc -= s.M[I][R] * Jr[R];
+    // L^T y = J^T, descending; only the supported entries of L.
+    if constexpr (sizeof(real) == 8) {
+        // f64: the coefficients (row I of L^T, wave-uniform LDS reads) do not depend on the chain through Jr: row I - 1's are requested in the source
+        // before row I's chain (measured +0.5 %; f32: -0.9 %, kept in the plain form below).  Forcing the order with scheduling barriers makes the
+        // register allocator spill 267 VGPRs to scratch: the region is register-tight, the compiler's placement is what it can afford.
+        real c[2][NV], cd[2];
+        auto load_row = [&](auto ic, real (&cr)[NV], real &d) {
+            constexpr int I = decltype(ic)::value;
+            static_for<NV - 1 - I>([&](auto rc) {
+                constexpr int R = I + 1 + decltype(rc)::value;
+                if constexpr (l_nz(R, I)) cr[R] = s.M[I][R];
+            });
+            d = s.col[I];
+        };
+        load_row(std::integral_constant<int, NV - 1>{}, c[0], cd[0]);
+        static_for<NV>([&](auto ic) {
+            constexpr int I = NV - 1 - decltype(ic)::value, B = decltype(ic)::value & 1;
+            if constexpr (I > 0) load_row(std::integral_constant<int, I - 1>{}, c[B ^ 1], cd[B ^ 1]);
+            real acc = Jr[I];
+            static_for<NV - 1 - I>([&](auto rc) {
+                constexpr int R = I + 1 + decltype(rc)::value;
+                if constexpr (l_nz(R, I)) acc -= c[B][R] * Jr[R];
+            });
+            Jr[I] = acc * cd[B];
         });
-        Jr[I] = acc * s.col[I];
-    });
+    } else {
+        static_for<NV>([&](auto ic) {
+            constexpr int I = NV - 1 - decltype(ic)::value;
+            real acc = Jr[I];
+            static_for<NV - 1 - I>([&](auto rc) {
+                constexpr int R = I + 1 + decltype(rc)::value;
+                if constexpr (l_nz(R, I)) acc -= s.M[I][R] * Jr[R];
+            });
+            Jr[I] = acc * s.col[I];
+        });
+    }
     if (valid_port) {
 #pragma unroll
         for (int j = 0; j < NV; j++) s.YT[j][p] = Jr[j];
