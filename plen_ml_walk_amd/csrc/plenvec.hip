@@ -41,6 +41,9 @@
 #define NPORT 48
 #define REC 64          // reals per env state record
 #define AUXN 8          // int32 per env aux record
+#ifndef WPE64
+#define WPE64 2         /* f64 kernel: waves per SIMD the register budget is set for (1: experiments only) */
+#endif
 #ifndef WPE32
 #define WPE32 4        // waves per SIMD the f32 kernel is register-allocated for
 #endif
@@ -1315,7 +1318,8 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     if constexpr (sizeof(real) == 8) {
         // f64: the coefficients (row I of L^T, wave-uniform LDS reads) do not depend on the chain through Jr: row I - 1's are requested in the source
         // before row I's chain (measured +0.5 %; f32: -0.9 %, kept in the plain form below).  Forcing the order with scheduling barriers makes the
-        // register allocator spill 267 VGPRs to scratch: the region is register-tight, the compiler's placement is what it can afford.
+        // register allocator spill 267 VGPRs to scratch -- an artefact of the split scheduling regions, not a shortage: built for one wave per SIMD
+        // (-DWPE64=1, 512 registers allowed) the kernel still takes 254.
         real c[2][NV], cd[2];
         auto load_row = [&](auto ic, real (&cr)[NV], real &d) {
             constexpr int I = decltype(ic)::value;
@@ -1750,7 +1754,7 @@ __device__ inline double agent_to_env(int j, double a) {
 }
 
 template <typename real, bool FAST>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real) == 8 ? 2 : WPE32, sizeof(real) == 8 ? 2 : WPE32))) void plen_env_kernel(StepArgs<real> a_by_value) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real) == 8 ? WPE64 : WPE32, sizeof(real) == 8 ? WPE64 : WPE32))) void plen_env_kernel(StepArgs<real> a_by_value) {
     __shared__ Smem<real> s;
     // The 16-dword argument block is read through the kernarg pointer at the two places that need it (prologue, env epilogue) with
     // scalar loads, the pointer being laundered so that the loads are not merged into one tuple held (and spilled into VGPR lanes,
