@@ -1763,6 +1763,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real)
     typedef const StepArgs<real> __attribute__((address_space(4))) KArgs;
 #define KARGS() ({ KArgs *p_ = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(p_)); p_; })
     KArgs *a = KARGS();
+#ifdef PLENVEC_WAVE_PRIO      // experiment: issue priority of the env waves over co-resident kernels' waves (the TD3 update's row blocks)
+    __builtin_amdgcn_s_setprio(PLENVEC_WAVE_PRIO);
+#endif
 #ifdef PGS_STAMPS
     const long long wave_t0 = (long long)__builtin_amdgcn_s_memtime();
 #endif
