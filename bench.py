@@ -14,6 +14,8 @@ plen_env.py computes in NumPy float64); the same JSON line carries two more legs
   legs.td3 : BASELINE.json configs[2]/[3]: 4096 envs per GPU + the full TD3 loop (actor/critic/replay in
              PyTorch-ROCm on the same device, f32 env, hipGraph-captured; RCCL gradient all-reduce for N > 1):
              env-steps/s AND gradient-steps/s, batch and update-to-data ratio stated.
+  legs.policy : SURVEY 8(f) row 1 at scale: the reference's shipped walking policy in the loop (actor forward + N(0, 0.01) + env step for every
+             env and step): a contact-rich workload -- robots that stand and walk -- beside the headline's random flailing.
 and `pybullet` records whether the reference's physics engine exists on this machine (it never has so far).  Outside every timed region, at
 N = 1, the line also carries `obs_err_vs_oracle` (SURVEY 8(d) Config 2: 64 envs x 64 steps, f64 kernel against the f64 oracle on identical
 actions) and `pybullet_pin` (the kernel's residuals against the PyBullet-held pin, tests/pybullet_pin.py).  The timed block of exactly K steps is
@@ -323,6 +325,83 @@ def td3_leg(a, dev, rank, world, dist, steps, warmup):
     return out
 
 
+def policy_leg(a, dev, rank, world, dist, steps, warmup):
+    """SURVEY 8(f) row 1 at scale: the reference's shipped walking policy (walk_eval.py:48-54, models/plen_walk_gazebo_3229999_*; fixture
+    tests/golden/policy_3229999.npz) IN the loop -- actor forward (row-block MFMA kernel) + N(0, 0.01) + env step for every env and step, two
+    sub-batches on two HIP streams, each step replayed as a hipGraph.  A contact-rich workload (robots that stand and walk) beside the headline's
+    random flailing; its episode statistics come with it."""
+    import numpy as np
+    import torch
+    from plen_ml_walk_amd import sharding
+    from plen_ml_walk_amd.vec_env import PlenVecEnv, worker_stream
+    from plen_ml_walk_amd.td3 import TD3Agent
+    from plen_ml_walk_amd.td3_fused import FusedTD3
+    n, H, sigma = a.envs_per_gpu, 2, 0.01
+    agent = TD3Agent(26, 18, 1.0, device=dev, data_parallel=False)
+    agent.load_arrays(np.load(os.path.join(ROOT, "tests", "golden", "policy_3229999.npz")))
+    fused = FusedTD3(agent, seed=1, rows=True)
+    envs = [PlenVecEnv(n // H, device=dev) for _ in range(H)]
+    streams = [worker_stream(dev, h) for h in range(H)]
+    state = [e.reset().to(torch.float32).clone() for e in envs]
+    rngs = [FusedTD3.new_rng(dev, 4242 + h + 1000 * rank) for h in range(H)]
+    cur = [torch.zeros(n // H, dtype=torch.long, device=dev) for _ in range(H)]
+    stats = [torch.zeros(2, dtype=torch.long, device=dev) for _ in range(H)]          # episodes that ended: count, sum of lengths
+    torch.cuda.synchronize(dev)
+
+    def collect(h):
+        act = fused.explore(state[h], sigma, actor=agent.actor, rng=rngs[h])
+        rngs[h][1] += 1
+        _, _, d, info = envs[h].step(act)
+        cur[h] += 1
+        ended = d != 0
+        stats[h] += torch.stack([ended.sum(), (cur[h] * ended).sum()])
+        cur[h] *= ~ended
+        state[h].copy_(info["obs"])
+
+    graphs, runs = {}, {}
+
+    def step():
+        for h in range(H):
+            with torch.cuda.stream(streams[h]):
+                g = graphs.get(h)
+                if g is None:
+                    if runs.get(h, 0) < 2:
+                        collect(h); runs[h] = runs.get(h, 0) + 1
+                        continue
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=streams[h], capture_error_mode="thread_local"):
+                        collect(h)
+                    graphs[h] = g
+                g.replay()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(warmup, 60)):            # past the graph captures and the synchronous start (every episode begins at step 0)
+        step()
+    barrier()
+    for st in stats:
+        st.zero_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    dt = sharding.max_over_ranks(time.perf_counter() - t0, dev)
+    tot = sum(st.cpu().numpy() for st in stats)
+    for e in envs:
+        e.close()
+    return {"value": world * n * steps / dt, "unit": "env-steps/s", "env_dtype": "f32", "steps": steps, "ms_per_step": dt / steps * 1e3, "action_noise_sigma": sigma,
+            "episodes_finished_in_window": int(tot[0]), "mean_length_of_those": float(tot[1]) / max(int(tot[0]), 1),
+            "episode_note": "every env starts an episode at step 0 and the window is %d + %d steps: the episodes that END inside it are the short ones; unbiased statistics of this "
+                            "policy: tests/test_pin_gpu.py (2048 episodes: mean length ~206, ~20 %% reach the 500-step limit)" % (max(warmup, 60), steps),
+            "workload": "SURVEY 8(f) row 1: %d envs per GPU driven by the reference's shipped policy 3229999 (actor forward as a row-block MFMA kernel + N(0, %.2f) "
+                        "exploration noise in the loop), 2 sub-batches on 2 HIP streams, hipGraph replays" % (n, sigma)}
+
+
 def _td3_run(a, dev, rank, world, dist, steps, warmup, batch):
     import torch
     from plen_ml_walk_amd import sharding
@@ -395,7 +474,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--dtype", default="f64", choices=["f32", "f64"], help="arithmetic of the headline leg (f64 = the reference's)")
-    ap.add_argument("--legs", default="f64,f32,td3,dr", help="comma list of legs to run besides the headline one (f64, f32, td3, dr)")
+    ap.add_argument("--legs", default="f64,f32,td3,policy,dr", help="comma list of legs to run besides the headline one (f64, f32, td3, policy, dr)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the obs_err_vs_oracle / pybullet_pin blocks (outside the timed regions, rank 0, N = 1)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: --envs-per-gpu envs on every rank; strong: --envs-per-gpu envs in "
@@ -448,6 +527,8 @@ def main():
                 legs[name] = env_leg(a, name, dev, rank, world, dist, a.steps, a.warmup)
             elif name == "td3":
                 legs[name] = td3_leg(a, dev, rank, world, dist, a.td3_steps, a.warmup)
+            elif name == "policy":
+                legs[name] = policy_leg(a, dev, rank, world, dist, a.td3_steps, a.warmup)
             elif name == "dr" and not a.dr:          # configs[4] on this many GPUs: the headline workload with per-env mass / friction
                 r = env_leg(a, a.dtype, dev, rank, world, dist, a.steps, a.warmup, dr=True)
                 legs[name] = {k: r[k] for k in ("value", "unit", "dtype", "ms_per_step", "kernel_ms_per_launch", "nonfinite_resets")}

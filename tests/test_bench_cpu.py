@@ -37,3 +37,25 @@ def test_no_gpu_means_no_number():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--legs", ""],
                          capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and not any(l.startswith("{") for l in out.stdout.splitlines())       # no JSON line from a machine without the MI355X
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_bench_line_small_run_carries_every_block():
+    """bench.py end to end at a small size on the GPU: one JSON line with the contract's fields, the roofline and cpu_baseline objects, every leg
+    (f32, td3, policy, dr) with a value, and the parity blocks."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--envs-per-gpu", "512", "--td3-steps", "40", "--td3-batch", "512"],
+                         capture_output=True, text=True, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-800:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["steps"] == 20 and d["n_gpus"] == 1 and d["dtype"] == "f64" and d["value"] > 1e5 and d["vs_baseline"] is None
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    for leg in ("f32", "td3", "policy", "dr"):
+        assert d["legs"][leg].get("value"), (leg, d["legs"][leg])
+    assert d["legs"]["td3"]["grad_steps_per_s"] > 0 and d["legs"]["policy"]["action_noise_sigma"] == 0.01
+    assert d["obs_err_vs_oracle"]["rolling_friction_off"]["frac_le_1e-4"] > 0.95 and d["pybullet_pin"]["R"][0] < 0.015
