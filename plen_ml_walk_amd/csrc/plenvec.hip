@@ -1592,16 +1592,27 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             // because u_n only changes in the normal pass and uk only at its own row.  Bullet skips the row
             // while the normal impulse is not positive: bounds (0, 0) leave e and uk untouched.
             if (has_spin || has_roll) {
-                const real nbv0 = gather_addr(blo, tors_addr), nbv1 = gather_addr(blo, tors_addr + 16);
-                const real nbv2 = gather_addr(blo, tors_addr + 32), nbv3 = gather_addr(blo, tors_addr + 48);     // -u_n of point k of this lane's foot
-                const real lim0 = mul_rn_(fc0, nbv0), lim1 = mul_rn_(fc1, nbv1), lim2 = mul_rn_(fc2, nbv2), lim3 = mul_rn_(fc3, nbv3);
-                // bounds of point k's rows: [-(lim + u), lim - u] while its normal impulse is positive (nbv = -u_n < 0), else [0, 0].  As two fused
-                // operations on a 0/1 factor m instead of an add, a subtract, a negation and two selects each: u * m is exact, so fma(u, m, lim) rounds
-                // exactly like lim + u; with m = 0 it leaves lim = fc * 0 = +-0, the empty interval.  pt1 is the NEGATED lower bound (the rows negate it
-                // with a source modifier).  f64: 32 -> 16 vector instructions per iteration.
-                const real m0 = nbv0 < 0 ? (real)1 : (real)0, m1 = nbv1 < 0 ? (real)1 : (real)0, m2 = nbv2 < 0 ? (real)1 : (real)0, m3 = nbv3 < 0 ? (real)1 : (real)0;
-                const real nt10 = fma_(u0, m0, lim0), nt11 = fma_(u1, m1, lim1), nt12 = fma_(u2, m2, lim2), nt13 = fma_(u3, m3, lim3);
-                const real t20 = fma_(-u0, m0, lim0), t21 = fma_(-u1, m1, lim1), t22 = fma_(-u2, m2, lim2), t23 = fma_(-u3, m3, lim3);
+                // f64: the bounds of a foot's third and fourth point only when some foot has a third point (a foot's points are a prefix; in use a touching foot
+                // has one or two, scripts/gpu_slot_distribution_actor.py): +0.65 % (f32: -0.3 ... -0.7 %, the branch costs more than two gathers: eager there)
+                real nt10, nt11, nt12 = 0, nt13 = 0, t20, t21, t22 = 0, t23 = 0;
+                {
+                    const real nbv0 = gather_addr(blo, tors_addr), nbv1 = gather_addr(blo, tors_addr + 16);     // -u_n of point k of this lane's foot
+                    const real lim0 = mul_rn_(fc0, nbv0), lim1 = mul_rn_(fc1, nbv1);
+                    // bounds of point k's rows: [-(lim + u), lim - u] while its normal impulse is positive (nbv = -u_n < 0), else [0, 0].  As two fused
+                    // operations on a 0/1 factor m instead of an add, a subtract, a negation and two selects each: u * m is exact, so fma(u, m, lim) rounds
+                    // exactly like lim + u; with m = 0 it leaves lim = fc * 0 = +-0, the empty interval.  pt1 is the NEGATED lower bound (the rows negate it
+                    // with a source modifier).  f64: 32 -> 16 vector instructions per iteration.
+                    const real m0 = nbv0 < 0 ? (real)1 : (real)0, m1 = nbv1 < 0 ? (real)1 : (real)0;
+                    nt10 = fma_(u0, m0, lim0); nt11 = fma_(u1, m1, lim1);
+                    t20 = fma_(-u0, m0, lim0); t21 = fma_(-u1, m1, lim1);
+                }
+                if (sizeof(real) == 4 || (act & 0xccu)) {
+                    const real nbv2 = gather_addr(blo, tors_addr + 32), nbv3 = gather_addr(blo, tors_addr + 48);
+                    const real lim2 = mul_rn_(fc2, nbv2), lim3 = mul_rn_(fc3, nbv3);
+                    const real m2 = nbv2 < 0 ? (real)1 : (real)0, m3 = nbv3 < 0 ? (real)1 : (real)0;
+                    nt12 = fma_(u2, m2, lim2); nt13 = fma_(u3, m3, lim3);
+                    t22 = fma_(-u2, m2, lim2); t23 = fma_(-u3, m3, lim3);
+                }
                 real dv0 = 0, dv1 = 0, dv2 = 0, dv3 = 0;
                 ISTAMP(3);
                 if (has_spin) {
