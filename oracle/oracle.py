@@ -29,6 +29,7 @@ def _lib(dtype="f64"):
         lib.oracle_create.restype = C.c_void_p
         lib.oracle_create.argtypes = [C.c_int]
         lib.oracle_destroy.argtypes = [C.c_void_p]
+        lib.oracle_copy.argtypes = [C.c_void_p, C.c_void_p]
         lib.oracle_set_params.argtypes = [C.c_void_p, C.c_double, C.c_double]
         lib.oracle_set_world.argtypes = [C.c_void_p, C.c_int, C.c_double]
         lib.oracle_set_friction.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
@@ -41,6 +42,7 @@ def _lib(dtype="f64"):
         lib.oracle_get_aux.argtypes = [C.c_void_p, ip]
         lib.oracle_set_targets.argtypes = [C.c_void_p, dp]
         lib.oracle_substep.argtypes = [C.c_void_p]
+        lib.oracle_set_trace.argtypes = [dp, C.c_int]
         lib.oracle_contacts.argtypes = [C.c_void_p, ip]
         lib.oracle_contact_slots.argtypes = [C.c_void_p, C.c_int, ip, dp]
         lib.oracle_set_body_contacts.argtypes = [C.c_void_p, C.c_int]
@@ -138,6 +140,10 @@ class OracleEnv(object):
             self.lib.oracle_destroy(self.h)
         except Exception:
             pass
+
+    def copy_from(self, other):
+        """Make this environment an exact copy of `other` (state, contact cache, parameters)."""
+        self.lib.oracle_copy(self.h, other.h)
 
     def set_params(self, mass_scale=1.0, lateral_friction=-1.0):
         self.lib.oracle_set_params(self.h, float(mass_scale), float(lateral_friction))

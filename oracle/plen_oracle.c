@@ -234,6 +234,8 @@ typedef struct {
     int nc_order;            /* 1: motors visited in DoF order instead of btAlignedObjectArray::quickSort's scramble of equal island keys; 2: reverse DoF order */
     int no_order_flip;       /* 1: the non-contact rows are not reversed on even iterations */
     int torsional_points;    /* > 0: only the first n points of a manifold get spinning / rolling rows */
+    int tors_freeze;         /* > 0: the bounds of the spinning / rolling rows are no longer rewritten from the normal impulse after this many iterations
+                                (mechanism A/B of the expanding mode, scripts/pin/expanding_mode.py; Bullet rewrites them in every iteration) */
 } World;
 
 typedef struct {
@@ -696,6 +698,8 @@ static void collide(Oracle *o) {
 }
 
 /* ---------------------------------------------------------------- one 1/240 s substep */
+/* optional solver trace (scripts/pin/expanding_mode.py): per iteration the residual and the delta-velocity vector; not thread safe, debugging only */
+static double *g_trace = 0; static int g_trace_cap = 0;
 static void substep(Oracle *o) {
     const World *w = &o->w;
     const real dt = w->dt;
@@ -812,12 +816,12 @@ static void substep(Oracle *o) {
         for (int j = 0; j < n_n; j++) { real r = resolve_row(&nrm[j], dv); if (r * r > residual) residual = r * r; }
         for (int j = 0; j < n_spin; j++) {
             real tot = nrm[spin[j].friction_index].applied;
-            if (tot > 0) { spin[j].lo = -spin[j].friction * tot; spin[j].hi = spin[j].friction * tot;
+            if (tot > 0) { if (!(w->tors_freeze > 0 && it >= w->tors_freeze)) { spin[j].lo = -spin[j].friction * tot; spin[j].hi = spin[j].friction * tot; }
                 real r = resolve_row(&spin[j], dv); if (r * r > residual) residual = r * r; }
         }
         for (int j = 0; j < n_roll; j++) {
             real tot = nrm[roll[j].friction_index].applied;
-            if (tot > 0) { roll[j].lo = -roll[j].friction * tot; roll[j].hi = roll[j].friction * tot;
+            if (tot > 0) { if (!(w->tors_freeze > 0 && it >= w->tors_freeze)) { roll[j].lo = -roll[j].friction * tot; roll[j].hi = roll[j].friction * tot; }
                 real r = resolve_row(&roll[j], dv); if (r * r > residual) residual = r * r; }
         }
         for (int j = 0; j + 1 < n_fric; j += 2) {
@@ -828,6 +832,7 @@ static void substep(Oracle *o) {
                 if (tot > 0) for (int a = 0; a < 2; a++) { real r = resolve_row(&fric[j + a], dv); if (r * r > residual) residual = r * r; }
             } else { real r = resolve_cone(&fric[j], &fric[j + 1], dv); if (r * r > residual) residual = r * r; }
         }
+        if (g_trace && it < g_trace_cap) { double *tr = g_trace + (size_t)it * (2 + NV + 8); tr[0] = residual; tr[1] = n_nc; for (int k = 0; k < NV; k++) tr[2 + k] = dv[k]; for (int j = 0; j < 8; j++) tr[2 + NV + j] = j < n_n ? nrm[j].applied : 0; }
         if (residual <= w->residual_threshold || it >= w->num_iterations - 1) { it++; break; }
     }
     o->last_iterations = it; o->last_residual = residual;
@@ -1017,6 +1022,8 @@ API Oracle *oracle_create(int joint_act) {
     return o;
 }
 API void oracle_destroy(Oracle *o) { free(o); }
+/* whole-environment copy (physics, env-level and manifold state, parameters): finite differences of a step (tests/pybullet_pin.py) */
+API void oracle_copy(Oracle *dst, const Oracle *src) { memcpy(dst, src, sizeof(Oracle)); }
 
 /* domain randomisation hooks: scale every link mass (and inertia with it), override lateral friction */
 API void oracle_set_params(Oracle *o, double mass_scale, double lateral_friction) {
@@ -1044,6 +1051,7 @@ API int oracle_set_hyp(Oracle *o, int key, double v) {
     case 21: w->manifold_mode = (int)v; break;  case 22: w->warmstart = (real)v; break;
     case 23: w->pyramid_friction = (int)v; break; case 24: w->base_gyro_off = (int)v; break;
     case 25: w->torsional_points = (int)v; break;
+    case 42: w->tors_freeze = (int)v; break;
     case 30: w->man_cand = (int)v; break; case 31: w->man_drift = (real)v; break; case 32: w->man_add_all = (int)v; break;
     case 37: w->sole_grow = (real)v; break; case 38: w->sole_dz = (real)v; break;
     case 39: w->man_p1 = (int)v; break; case 40: w->man_p1x = (real)v; break; case 41: w->man_p1y = (real)v; break;
@@ -1088,6 +1096,7 @@ API void oracle_get_aux(const Oracle *o, int *a) {
 }
 API void oracle_set_targets(Oracle *o, const double *t) { for (int d = 0; d < ND; d++) o->target[d] = (real)t[d]; }
 API void oracle_substep(Oracle *o) { substep(o); }
+API void oracle_set_trace(double *buf, int cap_iterations) { g_trace = buf; g_trace_cap = cap_iterations; }   /* rows of 2 + 24 + 8 doubles */
 API void oracle_contacts(const Oracle *o, int *flags) { flags[0] = o->right_contact; flags[1] = o->left_contact; flags[2] = o->ncp; flags[3] = o->last_iterations; }
 /* contact slots of the last collision pass: box[8] = -2 empty, -1 foot point, else box index; pos[8][3]; also runs a collision pass on demand */
 API void oracle_contact_slots(Oracle *o, int run_collide, int *box8, double *pos24) {

@@ -6,8 +6,8 @@ import numpy as np
 from pybullet_pin import ACTS, SD, HYP, pre, target, jac, make_oracle, residuals as _residuals
 
 
-def make_env(hyp=None, urdf_inertia=False):
-    return make_oracle(hyp=hyp, urdf_inertia=urdf_inertia)
+def make_env(hyp=None, urdf_inertia=False, inertia=None):
+    return make_oracle(hyp=hyp, urdf_inertia=urdf_inertia, inertia=inertia)
 
 
 def residuals(e, K=12):

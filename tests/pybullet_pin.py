@@ -23,7 +23,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 # oracle_set_hyp keys (oracle/plen_oracle.c)
 HYP = dict(erp=0, erp2=1, friction_erp=2, cfm=3, slop=4, resid=5, rest_thr=6, maxvel=7, mu=8, box_mu=9, spin=10, roll=11, rest=12,
            lin_damp=13, ang_damp=14, kp=15, kd=16, max_force=17, iters=18, body_contacts=19, dt=20, manifold=21, warm=22, pyramid=23,
-           gyro_off=24, tors_pts=25, rhs_clamp=26, joint_damping=27, nc_order=28, no_flip=29, man_cand=30, man_drift=31, man_add_all=32, man_fresh=33, man_order=34, man_cache=35, man_range=36, sole_grow=37, sole_dz=38, man_p1=39, man_p1x=40, man_p1y=41)
+           gyro_off=24, tors_pts=25, rhs_clamp=26, joint_damping=27, nc_order=28, no_flip=29, man_cand=30, man_drift=31, man_add_all=32, man_fresh=33, man_order=34, man_cache=35, man_range=36, sole_grow=37, sole_dz=38, man_p1=39, man_p1x=40, man_p1y=41, tors_freeze=42)
 
 
 def load():
@@ -88,9 +88,13 @@ def residuals(reset, step, K=8):
 
 
 # ---- the oracle under the pin (tests and scripts/pin only) ----
-def make_oracle(hyp=None, urdf_inertia=False):
+def make_oracle(hyp=None, urdf_inertia=False, inertia=None):
+    """inertia: optional [33][3] table of link inertia diagonals (base first) for model-table hypotheses (scripts/pin/)."""
     from oracle.oracle import OracleEnv
     e = OracleEnv()
+    if inertia is not None:
+        for b, I in enumerate(inertia):
+            e.lib.oracle_set_link_inertia(e.h, b, float(I[0]), float(I[1]), float(I[2]))
     for k, v in (hyp or {}).items():
         assert e.lib.oracle_set_hyp(e.h, HYP[k], float(v)) == 0, k
     if urdf_inertia:
@@ -108,3 +112,123 @@ def oracle_residuals(K=8, **kw):
         o, _, d, _ = e.step(np.asarray(a, dtype=np.float64))
         return o, d
     return residuals(e.reset, step, K)
+
+
+# ---- round 4: the WHOLE 500-step log as a one-step-ahead pin --------------------------------------------------
+# Open loop, R_2.. are dominated by the accumulated (chaotic) trajectory error.  To test the steady walking regime the simulator under
+# test is instead run as an OBSERVER of PyBullet's episode: at every logged step t its observation is min-norm-corrected onto the 18
+# actor equations a_t = actor(obs_t^PyBullet), the correction is written back into its state (joint angles, base height / y / attitude,
+# v_x; every velocity it cannot see is carried), and it is stepped ONCE with the logged a_t.  The residual of the prediction BEFORE the
+# correction,
+#     Rhat_t = rms over the unsaturated channels of  atanh(a_t) - preactivation(actor(obs_t^predicted)),      t = 0 .. 499,
+# is a one-step-ahead error along PyBullet's own trajectory: 500 samples of "one control step from (nearly) PyBullet's state".
+# The two contact flags are decoded, not corrected: a flipped flag moves the pre-activations by 30-180, so the combination with the smallest
+# residual is PyBullet's while the prediction is close; flag agreement is reported beside Rhat.
+OBS_W = np.array([1e-2] * 18 + [1e-3, 2e-2, 1e-2, 1e-2, 1e-2, 1e-3])      # scales of the min-norm correction (as min_norm_obs_correction)
+FLAGS = [(0.0, 0.0), (0.0, 1.0), (1.0, 0.0), (1.0, 1.0)]
+
+
+def _jac24(x, eps=1e-6):
+    J = np.zeros((18, 24))
+    for i in range(24):
+        d = np.zeros(26); d[i] = eps
+        J[:, i] = (pre(x + d) - pre(x - d)) / (2 * eps)
+    return J
+
+
+def decode_flags(obs, t):
+    """(residual rms per flag combination, index of the best) for the continuous part of obs at logged step t."""
+    tgt, un = target(ACTS[t])
+    x = np.array(obs, dtype=np.float64)
+    r = []
+    for f in FLAGS:
+        x[24], x[25] = f
+        d = (pre(x) - tgt)[un]
+        r.append(float(np.sqrt((d ** 2).mean())))
+    return np.array(r), int(np.argmin(r))
+
+
+def correct_obs(obs, t, flags, iters=3, rcond=1e-3, cap=None):
+    """Min-norm (scaled by OBS_W) correction of the 24 continuous entries such that the actor reproduces a_t on its unsaturated channels
+    (Gauss-Newton on the min-norm problem).  Returns the correction [24]."""
+    tgt, un = target(ACTS[t])
+    x0 = np.array(obs, dtype=np.float64); x0[24], x0[25] = flags
+    d = np.zeros(24)
+    for _ in range(iters):
+        x = x0.copy(); x[:24] += d
+        J = _jac24(x)[un]
+        r = (tgt - pre(x))[un] + J @ d                     # linearised about x: J (d_new) = tgt - pre(x0 + d) + J d
+        d = OBS_W * np.linalg.lstsq(J * OBS_W, r, rcond=rcond)[0]
+        if cap is not None:
+            d = np.clip(d, -cap * OBS_W, cap * OBS_W)
+    return d
+
+
+def rpy_to_quat(r, p, y):
+    """pybullet getQuaternionFromEuler (x, y, z, w), the inverse of getEulerFromQuaternion for |pitch| < pi/2."""
+    cr, sr, cp, sp, cy, sy = np.cos(r / 2), np.sin(r / 2), np.cos(p / 2), np.sin(p / 2), np.cos(y / 2), np.sin(y / 2)
+    return np.array([sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy])
+
+
+def apply_correction(state49, obs, d):
+    """Write an observation correction d[24] into the 49-real state (pos3 quat4 omega3 vel3 q18 qd18)."""
+    s = np.array(state49, dtype=np.float64)
+    s[13:31] += d[:18]
+    s[2] += d[18]; s[10] += d[19]; s[1] += d[23]
+    s[3:7] = rpy_to_quat(obs[20] + d[20], obs[21] + d[21], obs[22] + d[22])
+    return s
+
+
+def track(env, T=500, correct=True, cap=30.0, vel_gain=0.0):
+    """Run `env` (reset / step / get_state / set_state, e.g. OracleEnv or the kernel facade) as an observer of the logged PyBullet episode.
+    Returns dict(Rhat[T], flags_sim[T,2], flags_dec[T,2], margin[T], corr[T,24], done_at)."""
+    obs = np.array(env.reset(), dtype=np.float64)
+    Rhat, fs, fd, mg, corr = [], [], [], [], []
+    done_at = None
+    for t in range(T):
+        r4, k = decode_flags(obs, t)
+        Rhat.append(r4[k]); fs.append((obs[24], obs[25])); fd.append(FLAGS[k]); mg.append(float(np.sort(r4)[1] - r4[k]))
+        if correct:
+            d = correct_obs(obs, t, FLAGS[k], cap=cap)
+            s = apply_correction(env.get_state(), obs, d)
+            if vel_gain:
+                s[31:49] += vel_gain * d[:18] * 60.0           # optional: joint rates follow the angle correction (one control step = 1/60 s)
+            env.set_state(s)
+        else:
+            d = np.zeros(24)
+        corr.append(d)
+        out = env.step(ACTS[t].astype(np.float64))
+        obs = np.array(out[0], dtype=np.float64)
+        if out[2] and done_at is None:
+            done_at = t + 1
+        if not np.all(np.isfinite(obs)):
+            break
+    n = len(Rhat)
+    return dict(Rhat=np.array(Rhat), flags_sim=np.array(fs), flags_dec=np.array(fd), margin=np.array(mg), corr=np.array(corr), done_at=done_at, steps=n)
+
+
+def track_summary(tr, skip=5):
+    """Robust summary of a track: the spawn transient (first `skip` steps) is reported apart from the steady walking regime."""
+    R = tr["Rhat"]; ok = np.isfinite(R)
+    same = (tr["flags_sim"] == tr["flags_dec"]).all(1)
+    st = R[skip:][ok[skip:]]
+    return dict(steps=int(tr["steps"]), median=float(np.median(st)), mean=float(st.mean()), p90=float(np.quantile(st, 0.9)),
+                rms=float(np.sqrt((st ** 2).mean())), first=[float(x) for x in R[:skip]], flags_agree=float(same.mean()),
+                median_flags_agree=float(np.median(R[same & ok])) if (same & ok).any() else None,
+                corr_rms_joint=float(np.sqrt((tr["corr"][:, :18] ** 2).mean())), done_at=tr["done_at"])
+
+
+def closed_loop_len(env, T=500, sigma=0.0, seed=0):
+    """Deterministic shipped actor 3229999 from reset (walk_eval.py:83-85): (steps survived, return).  The reference's own episode under this
+    actor is the 500-step log."""
+    rng = np.random.default_rng(seed)
+    obs = np.array(env.reset(), dtype=np.float64); ret = 0.0
+    for t in range(T):
+        a = np.tanh(pre(obs)).astype(np.float32)
+        if sigma:
+            a = np.clip(a + sigma * rng.standard_normal(18), -1, 1).astype(np.float32)
+        out = env.step(a.astype(np.float64))
+        obs = np.array(out[0], dtype=np.float64); ret += float(out[1])
+        if out[2]:
+            return t + 1, ret
+    return T, ret
