@@ -120,6 +120,10 @@ typedef struct PlenModel {
     double box_break[PLENVEC_MAXBOX];           /* contact breaking threshold */
     double box_link_restitution[PLENVEC_MAXBOX];/* 0.5 (plen_env.py:472-481), base link 0 */
 } PlenModel;
+/* What a PlenModel can NOT change (compiled into the kernels): the tree topology, which bodies are the feet (6 and 12), the joint
+ * limits (+-1.7 rad, plen.urdf:1310 -- every revolute joint of the PLEN has the same), the solver's row order.  plenvec_create_from_model
+ * rejects (PLENVEC_E_INVAL) non-finite numbers, a non-orthonormal joint_R, an inertia that is not positive definite, member masses that do
+ * not sum to the body's mass and sole_rep outside {0, 1}. */
 /* Fills *model with the compiled-in PLEN robot (plen.urdf + rfoot.stl / lfoot.stl through tools/extract_model.py). */
 int plenvec_default_model(PlenModel *model);
 

@@ -24,6 +24,7 @@
 // The library never falls back to the CPU; the oracle under oracle/ is never linked or called.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <cmath>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -429,6 +430,17 @@ __device__ __forceinline__ void f64_row_asm(double &e, const double lo, const do
 // EXEC narrowed around a SEPARATE commit instruction -- `v_sub` pair, LDS slot, v_mov_b64 --; skipping the broadcast of zero deltas with a
 // scalar branch.)  The compiler path does the same arithmetic in the same order and tests assert the two
 // are bit-identical.
+// INVARIANT of every hand-written row below (pgs_row2d, pgs_rowTd, pgs_cone, f64_row_asm, the generated motor passes): they narrow EXEC to the row's
+// lane(s) and restore it with `s_mov_b64 exec, -1`, not with a saved copy, and EXEC is not declared to the compiler.  That is correct only while
+// (a) the workgroup is one full wave with all 64 lanes active and (b) every call site is reached under WAVE-UNIFORM control flow (act, lent, lim_mask,
+// has_spin / has_roll, the iteration count are scalar).  A row reached under a divergent branch would silently re-enable the masked-off lanes.
+// -DPLENVEC_DEBUG_EXEC traps at solver entry and after every iteration if EXEC is not all ones; the asm-vs-compiler bitwise test
+// (test_asm_path_bitwise_equals_compiler_path) is the merge gate for any new call site.
+#ifdef PLENVEC_DEBUG_EXEC
+#define PLEN_ASSERT_FULL_EXEC() do { if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap(); } while (0)
+#else
+#define PLEN_ASSERT_FULL_EXEC() do { } while (0)
+#endif
 template <bool FAST, int PP, typename real>
 __device__ __forceinline__ void pgs_row2d(real &e, const real blo, const real bhi, real &dvec, const real acol, const int lane) {
     if constexpr (FAST && sizeof(real) == 4) {
@@ -1542,8 +1554,10 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     const bool has_spin = P.mu_spin > 0, has_roll = P.mu_roll > 0;
     STAMP();
     int it = 0;
+    PLEN_ASSERT_FULL_EXEC();
     for (it = 0; it < n_iter; it++) {
         res_i = 0;
+        PLEN_ASSERT_FULL_EXEC();
         ISTAMP(0);
         // Bullet's leastSquaresResidual test: does any row of this iteration move by more than sqrt(threshold)?  One compare per pass
         // on the deferred deltas, the lane masks OR-ed on the scalar unit.
@@ -2135,7 +2149,34 @@ static int check_model(const PlenModel &m) {
         if (m.n_member[b] < 1 || m.n_member[b] > PLENVEC_MAXMEMB) return fail(PLENVEC_E_INVAL, "PlenModel.n_member out of range");
         if (b > 0) { double n2 = m.axis[b][0] * m.axis[b][0] + m.axis[b][1] * m.axis[b][1] + m.axis[b][2] * m.axis[b][2]; if (fabs(n2 - 1.0) > 1e-6) return fail(PLENVEC_E_INVAL, "PlenModel.axis must be unit vectors"); }
     }
+    // numbers that were compile-time constants before plenvec_create_from_model existed: reject what the kernel cannot digest
+    auto finite3 = [](const double *v, int n) { for (int i = 0; i < n; i++) if (!std::isfinite(v[i])) return false; return true; };
+    if (!std::isfinite(m.margin) || !finite3(m.foot_break, 2)) return fail(PLENVEC_E_INVAL, "PlenModel.margin / foot_break must be finite");
+    for (int b = 0; b < NB; b++) {
+        if (!finite3(m.joint_R[b], 9) || !finite3(m.joint_t[b], 3) || !finite3(m.com[b], 3) || !finite3(m.inertia[b], 6) || !std::isfinite(m.mass[b]))
+            return fail(PLENVEC_E_INVAL, "PlenModel: non-finite joint_R / joint_t / com / inertia / mass");
+        const double *R = m.joint_R[b];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+            const double d = R[3 * i] * R[3 * j] + R[3 * i + 1] * R[3 * j + 1] + R[3 * i + 2] * R[3 * j + 2] - (i == j ? 1.0 : 0.0);
+            if (fabs(d) > 1e-6) return fail(PLENVEC_E_INVAL, "PlenModel.joint_R must be orthonormal");
+        }
+        // inertia (xx yy zz xy xz yz) about the COM must be positive definite: leading minors
+        const double *I = m.inertia[b];
+        const double m2 = I[0] * I[1] - I[3] * I[3];
+        const double det = I[0] * (I[1] * I[2] - I[5] * I[5]) - I[3] * (I[3] * I[2] - I[5] * I[4]) + I[4] * (I[3] * I[5] - I[1] * I[4]);
+        if (!(I[0] > 0 && m2 > 0 && det > 0)) return fail(PLENVEC_E_INVAL, "PlenModel.inertia must be positive definite");
+        double ms = 0;
+        for (int i = 0; i < m.n_member[b]; i++) { if (!finite3(m.member_com[b][i], 3) || !(m.member_mass[b][i] > 0)) return fail(PLENVEC_E_INVAL, "PlenModel.member_com / member_mass invalid"); ms += m.member_mass[b][i]; }
+        if (fabs(ms - m.mass[b]) > 1e-9 * (1.0 + m.mass[b])) return fail(PLENVEC_E_INVAL, "PlenModel.member_mass must sum to mass");
+    }
+    for (int f = 0; f < 2; f++) for (int v = 0; v < 32; v++) {
+        if (!finite3(m.sole[f][v], 3)) return fail(PLENVEC_E_INVAL, "PlenModel.sole must be finite");
+        if (m.sole_rep[f][v] != 0 && m.sole_rep[f][v] != 1) return fail(PLENVEC_E_INVAL, "PlenModel.sole_rep must be 0 or 1");
+    }
     if (m.num_boxes < 0 || m.num_boxes > GEN_NBOX) return fail(PLENVEC_E_INVAL, "PlenModel.num_boxes out of range");
+    for (int x = 0; x < m.num_boxes; x++)
+        if (!finite3(m.box_R[x], 9) || !finite3(m.box_t[x], 3) || !finite3(m.box_half[x], 3) || !std::isfinite(m.box_break[x]) || !std::isfinite(m.box_link_restitution[x]))
+            return fail(PLENVEC_E_INVAL, "PlenModel: non-finite box collider");
     for (int x = 0; x < m.num_boxes; x++) if (m.box_body[x] < 0 || m.box_body[x] >= NB) return fail(PLENVEC_E_INVAL, "PlenModel.box_body out of range");
     for (int f = 0; f < 2; f++) for (int k = 0; k < 4; k++) for (int v = 0; v < 32; v++)
         if (m.sole_order[f][k][v] < 0 || m.sole_order[f][k][v] >= 32) return fail(PLENVEC_E_INVAL, "PlenModel.sole_order out of range");
@@ -2173,8 +2214,11 @@ static void fill_params(const PlenCfg &c, const PlenModel &m, DevParams<real> &p
         }
     }
     for (int x = 0; x < GEN_NBOX; x++) {
-        if (x >= m.num_boxes) {          // unused box slots: a point box far above the ground never comes into range
-            p.box[x][0] = p.box[x][4] = p.box[x][8] = 1; p.box[x][11] = (real)1e6; p.box[x][15] = (real)-1; p.box_body[x] = 0;
+        if (x >= m.num_boxes) {
+            // unused box slots: a point box at the body origin whose breaking threshold no height can reach, whatever the orientation of the body
+            // (round 3 parked it 1e6 m "above" the base in the BASE frame: a base tilted past 90 degrees turned that into 1e6 m below the ground,
+            // ADVICE r03).  Both tests of the slot, `zmin <= bx[15]` (near) and `cw[2] <= bx[15]` (corner), are false for every finite height.
+            p.box[x][0] = p.box[x][4] = p.box[x][8] = 1; p.box[x][15] = (real)-1e30; p.box_body[x] = 0;
             continue;
         }
         for (int i = 0; i < 9; i++) p.box[x][i] = (real)m.box_R[x][i];

@@ -192,7 +192,11 @@ class FusedTD3(object):
         self._zeroed = {"critic": True, "actor": True}            # gradient buckets known to be zero (left so by the last fused Adam step)
 
     def _zero_grads(self, which):
-        """Zero a gradient bucket before a backward pass unless the last Adam step already did."""
+        """Zero a gradient bucket before a backward pass unless the last Adam step already did.
+        The zero-or-skip decision is a HOST decision: inside a captured hipGraph (GraphedVecTD3Trainer / PipelinedVecTD3Trainer) it is frozen at
+        capture time.  After capture the fused graphs and the autograd path (TD3Agent.train, which also writes critic gradients) must therefore not
+        be interleaved on one agent: a replay would skip a zeroing the eager path has made necessary.  The trainers never do; a caller who needs
+        both re-captures (trainer.recapture()) after using the autograd path."""
         grads = self.agent._critic_grads if which == "critic" else self.agent._actor_grads
         if self._zeroed.get(which) and not grads.dirty:
             self._zeroed[which] = False
@@ -283,6 +287,11 @@ class FusedTD3(object):
             assert t.dtype == torch.float32 and t.is_contiguous()
         assert done.dtype == torch.uint8 and total.dtype == torch.long
         ep, st = episodes if episodes is not None else (None, None)
+        if st is not None:
+            # k_store adds into stats[0..2] with 8-byte atomics (float64 since round 3) and reads / writes ep_ret[e][0..1] as float32: a caller on the
+            # round-2 contract (float32 stats, 12 bytes) would have its neighbouring allocation overwritten
+            assert st.dtype == torch.float64 and st.numel() >= 3 and st.is_contiguous(), "episode stats must be a contiguous float64 tensor of >= 3 elements"
+            assert ep is not None and ep.dtype == torch.float32 and tuple(ep.shape) == (n, 2) and ep.is_contiguous(), "ep_ret must be float32 [n, 2]"
         _chk(self.lib.plentd3_store(_p(data), _p(total), int(data.shape[0]), _p(state), _p(action), _p(next_obs), _p(reward), _p(done), _p(rng), _p(ep), _p(st), n, self._stream()))
 
     def critic_backward(self, data, idx, noise=None, total=None, guard=0):

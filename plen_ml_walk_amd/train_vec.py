@@ -344,6 +344,13 @@ class GraphedVecTD3Trainer(object):
         self.total_t.fill_(self.host_total)
         self.env_steps, self.grad_steps = int(c["env_steps"]), int(c["grad_steps"])
 
+    def recapture(self):
+        """Drop the captured graphs (they are re-captured on the next steps).  Needed after anything that changes a HOST decision frozen into them --
+        e.g. the autograd path (TD3Agent.train) used on the same agent leaves the gradient buckets dirty, and a captured fused update would skip
+        the zeroing (td3_fused.FusedTD3._zero_grads)."""
+        torch.cuda.synchronize()
+        self._graphs.clear(); self._eager_runs.clear()
+
     def _run(self, key, fn, *args):
         """Execute `fn(*args)` once: eagerly on the side stream the first two times this key is seen (allocator / lazy-init warm-up,
         and real work), from then on as a replay of its captured graph."""
@@ -512,6 +519,13 @@ class PipelinedVecTD3Trainer(object):
         self.agent.actor_optimizer.step()
         self.fused.polyak()
         self._finish(buf_out)
+
+    def recapture(self):
+        """Drop the captured graphs (they are re-captured on the next steps).  Needed after anything that changes a HOST decision frozen into them --
+        e.g. the autograd path (TD3Agent.train) used on the same agent leaves the gradient buckets dirty, and a captured fused update would skip
+        the zeroing (td3_fused.FusedTD3._zero_grads)."""
+        torch.cuda.synchronize()
+        self._graphs.clear(); self._eager_runs.clear()
 
     def _run(self, key, stream, fn, *args):
         """fn(*args) on `stream`: eagerly the first two times the key is seen, then as a replay of its graph captured on that stream."""

@@ -21,16 +21,6 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pin_eval import make_env, ACTS, ROOT
 from pin_eval import pre
 
-REF_LAST1000 = None
-
-
-def ref_returns():
-    global REF_LAST1000
-    if REF_LAST1000 is None:
-        REF_LAST1000 = np.load(os.path.join(ROOT, "tests", "golden", "ref_training_log_summary.npz"))["last1000_returns"]
-    return REF_LAST1000
-
-
 def _episodes(args):
     kw, sigma, seed, n = args
     rng = np.random.default_rng(seed)
@@ -50,41 +40,17 @@ def _episodes(args):
     return out
 
 
-def action_features(A):
-    """Steady-gait statistics of a 500-step action sequence (first 100 steps dropped)."""
-    A = np.asarray(A, dtype=np.float64)[100:]
-    X = A - A.mean(0)
-    u, s, vt = np.linalg.svd(X, full_matrices=False)
-    pc = u[:, 0] * s[0]
-    ac = np.correlate(pc, pc, "full")[len(pc) - 1:]; ac /= ac[0]
-    k0 = int(np.argmin(ac[:60])); k = k0 + int(np.argmax(ac[k0:k0 + 80]))
-    return dict(mean=A.mean(0), std=A.std(0), sat=(np.abs(A) > 0.995).mean(0), period=k, ac_peak=float(ac[k]))
-
-
-LOG_FEAT = action_features(ACTS)
-
-
-def w1(a, b):
-    """1-Wasserstein distance between two samples (quantile form)."""
-    q = np.linspace(0.005, 0.995, 199)
-    return float(np.abs(np.quantile(a, q) - np.quantile(b, q)).mean())
+from pybullet_pin import action_features, survivor_action_stats, w1, closed_loop_summary
 
 
 def evaluate(kw, sigma=0.1, episodes=512, procs=8, pool=None):
     jobs = [(kw, sigma, 1000 * s + 7, episodes // procs) for s in range(procs)]
     res = sum((pool.map(_episodes, jobs) if pool else map(_episodes, jobs)), [])
-    L = np.array([r[0] for r in res]); R = np.array([r[1] for r in res])
-    ref = ref_returns()
-    out = dict(sigma=sigma, episodes=len(res), mean_length=float(L.mean()), early_falls_lt50=float((L < 50).mean()), full_length=float((L >= 500).mean()),
-               ret_mean=float(R.mean()), ret_q=[float(v) for v in np.quantile(R, [0.05, 0.25, 0.5, 0.75, 0.95])], ret_max=float(R.max()),
-               w1_to_reference_last1000=w1(R, ref))
+    out = closed_loop_summary([r[0] for r in res], [r[1] for r in res], sigma)
+    out["ret_q"] = out["ret_q_5_25_50_75_95"]
     surv = [r[2] for r in res if r[2] is not None]
     if surv:
-        F = [action_features(a) for a in surv]
-        d = lambda k: float(np.abs(np.mean([f[k] for f in F], 0) - LOG_FEAT[k]).mean())
-        out["survivor_action_stats"] = dict(n=len(surv), mean_abs_diff_of_channel_means=d("mean"), of_stds=d("std"), of_saturation=d("sat"),
-                                            period_median=float(np.median([f["period"] for f in F])), period_log=LOG_FEAT["period"],
-                                            ac_peak=float(np.mean([f["ac_peak"] for f in F])), ac_peak_log=LOG_FEAT["ac_peak"])
+        out["survivor_action_stats"] = survivor_action_stats(surv)
     return out
 
 

@@ -232,3 +232,52 @@ def closed_loop_len(env, T=500, sigma=0.0, seed=0):
         if out[2]:
             return t + 1, ret
     return T, ret
+
+
+# ---- round 4: chaos-averaged closed-loop pins (scripts/pin/closed_loop_stats.py, bench.py, tests/test_pin_gpu.py) -------------------------
+# In the reference configuration one control step amplifies a 1e-9 state perturbation by > 1e6 in ~20 % of the steps (the rolling-friction bounds
+# are rewritten from the normal impulse inside every solver iteration with a 0.08 m coefficient, larger than the foot; profiles/r04_expanding_mode.json),
+# so PyBullet's recorded episode is ONE sample path of a chaotic system: it cannot be followed step by step, by anything.  What survives chaos:
+#   * the recorded episode did not fall in 500 steps and its ACTION STATISTICS describe the steady gait (per-channel mean / std / saturation, period);
+#   * the returns of the reference's last 1000 training episodes (results/plen_walk_gazebo_.npy -> ref_training_log_summary.npz: last1000_returns),
+#     collected by the policies around the shipped checkpoints under N(0, 0.1) exploration noise (plen_td3.py:101-104).
+def action_features(A):
+    """Steady-gait statistics of a 500-step action sequence [500, 18] (first 100 steps dropped): per-channel mean / std / saturated fraction, period of the
+    first principal component's autocorrelation (control steps) and its peak height."""
+    A = np.asarray(A, dtype=np.float64)[100:]
+    X = A - A.mean(0)
+    u, s, vt = np.linalg.svd(X, full_matrices=False)
+    pc = u[:, 0] * s[0]
+    ac = np.correlate(pc, pc, "full")[len(pc) - 1:]; ac /= ac[0]
+    k0 = int(np.argmin(ac[:60])); k = k0 + int(np.argmax(ac[k0:k0 + 80]))
+    return dict(mean=A.mean(0), std=A.std(0), sat=(np.abs(A) > 0.995).mean(0), period=k, ac_peak=float(ac[k]))
+
+
+LOG_FEATURES = action_features(ACTS)
+
+
+def survivor_action_stats(action_seqs):
+    """Distance of the survivors' steady-gait action statistics from the PyBullet log's: mean over the 18 channels of |difference of the ensemble-mean
+    statistic|.  (One 400-step episode estimates a channel mean to ~0.1; the ensemble mean is sharper.)"""
+    F = [action_features(a) for a in action_seqs]
+    d = lambda k: float(np.abs(np.mean([f[k] for f in F], 0) - LOG_FEATURES[k]).mean())
+    return dict(n=len(F), mean_abs_diff_of_channel_means=d("mean"), of_stds=d("std"), of_saturation=d("sat"),
+                period_median=float(np.median([f["period"] for f in F])), period_log=int(LOG_FEATURES["period"]),
+                ac_peak=float(np.mean([f["ac_peak"] for f in F])), ac_peak_log=float(LOG_FEATURES["ac_peak"]))
+
+
+def reference_last1000_returns():
+    return np.load(os.path.join(GOLD, "ref_training_log_summary.npz"))["last1000_returns"].astype(np.float64)
+
+
+def w1(a, b):
+    """1-Wasserstein distance between two samples (quantile form)."""
+    q = np.linspace(0.005, 0.995, 199)
+    return float(np.abs(np.quantile(a, q) - np.quantile(b, q)).mean())
+
+
+def closed_loop_summary(lengths, returns, sigma):
+    L, R = np.asarray(lengths), np.asarray(returns, dtype=np.float64)
+    return dict(sigma=sigma, episodes=int(len(L)), mean_length=float(L.mean()), early_falls_lt50=float((L < 50).mean()), full_length=float((L >= 500).mean()),
+                ret_mean=float(R.mean()), ret_q_5_25_50_75_95=[float(v) for v in np.quantile(R, [0.05, 0.25, 0.5, 0.75, 0.95])], ret_max=float(R.max()),
+                w1_to_reference_last1000=w1(R, reference_last1000_returns()))

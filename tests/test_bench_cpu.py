@@ -55,7 +55,33 @@ def test_bench_line_small_run_carries_every_block():
         assert k in d, k
     assert d["steps"] == 20 and d["n_gpus"] == 1 and d["dtype"] == "f64" and d["value"] > 1e5 and d["vs_baseline"] is None
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
-    for leg in ("f32", "td3", "policy", "dr"):
+    for leg in ("f32", "td3", "td3_reference", "policy", "dr"):
         assert d["legs"][leg].get("value"), (leg, d["legs"][leg])
+    ref = d["legs"]["td3_reference"]
+    assert ref["batch"] == 100 and abs(ref["updates_per_env_step"] - 1.0) < 1e-9 and ref["grad_steps_per_s"] > 100        # the reference's recipe: one batch-100 update per env-step
+    assert d["roofline_valu"] == d["roofline"]["valu_issue"] and 0 < d["roofline_valu"]["frac_nominal_2cycle"] < 1
+    assert d["timed_region"]["seconds_total"] >= 2.0
+    cl = d["pybullet_pin"]["closed_loop"]
+    assert 1 <= cl["closed_loop_len"] <= 500 and cl["sigma_0.0001"]["episodes"] == 2048 and 0 < cl["sigma_0.1"]["mean_length"] <= 500
     assert d["legs"]["td3"]["grad_steps_per_s"] > 0 and d["legs"]["policy"]["action_noise_sigma"] == 0.01
     assert d["obs_err_vs_oracle"]["rolling_friction_off"]["frac_le_1e-4"] > 0.95 and d["pybullet_pin"]["R"][0] < 0.015
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_on_one_gpu(scaling):
+    """the command the driver will use on an 8-GPU node (`bench.py --gpus N`, ranks spawned through torch.distributed.run), kept alive on
+    the one-GPU boxes: two ranks share the GPU, gloo carries the collectives (RCCL refuses two ranks on one device).  One JSON line, n_gpus 2, the
+    env count of the chosen scaling, and a TD3 leg whose gradient all-reduces really ran."""
+    env = dict(os.environ, PLEN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scaling", scaling, "--steps", "10", "--warmup", "3", "--envs-per-gpu", "256",
+                          "--legs", "f32,td3", "--td3-steps", "30", "--td3-batch", "256", "--no-cpu-baseline", "--no-parity"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.stdout[-500:], out.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["value"] > 0
+    assert d["config"]["total_envs"] == (512 if scaling == "weak" else 256) and d["config"]["envs_per_gpu"] == (256 if scaling == "weak" else 128)
+    assert d["legs"]["f32"]["value"] > 0
+    td3 = d["legs"]["td3"]
+    assert td3.get("value") and td3["collective"] and "all-reduce" in td3["collective"] and td3["grad_steps_per_s"] > 0, td3

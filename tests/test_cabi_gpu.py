@@ -85,3 +85,57 @@ def test_step2_pair_matches_the_done_bits():
         seen_t += int(tr.sum()); seen_d += int(d.sum())
     assert seen_t > 0 and seen_d > 0
     e1.close(); e2.close()
+
+
+@pytest.mark.gpu
+def test_unused_box_slots_stay_out_of_contact_when_the_base_turns_over():
+    """a PlenModel with num_boxes < 31 leaves unused box slots.  Round 3 parked them 1e6 m 'above' the base in the BASE frame -- a base
+    tilted past 90 degrees (reachable with auto_reset off: compute_done is one-sided, plen_env.py:1082-1083) turned that into a phantom corner 1e6 m
+    below the ground that took a foot's contact slot with a 1e6 m penetration.  Now the slot's breaking threshold is unreachable for any pose: a robot
+    turned upside down in the air, with NO box collider at all, has no contact point (slot mask 0), falls freely for a substep and stays finite."""
+    from plen_ml_walk_amd import _lib as L
+    from plen_ml_walk_amd.vec_env import PlenVecEnv
+    import numpy as np
+    m = L.default_model()
+    m.num_boxes = 0
+    n = 8
+    env = PlenVecEnv(n, device="cuda:0", dtype=torch.float64, model=m, auto_reset=False)
+    env.reset()
+    st = torch.zeros(n, 49, dtype=torch.float64, device="cuda")
+    # base upside down (rotation by pi - 0.2 * e about x), 0.3 m above the ground: feet in the air, nothing near the ground
+    for e in range(n):
+        ang = np.pi - 0.2 * e / n
+        st[e, 2] = 0.3; st[e, 3] = np.sin(ang / 2); st[e, 6] = np.cos(ang / 2)
+    env.set_state(st)
+    dump = env.debug_substeps(torch.zeros(n, 18, dtype=torch.float64, device="cuda"), 1)
+    aux = env.get_aux().cpu().numpy()
+    assert (aux[:, 7] == 0).all(), aux[:, 7]                      # no slot lent, no slot occupied
+    s1 = env.get_state().cpu().numpy()
+    assert np.isfinite(s1).all()
+    assert np.allclose(s1[:, 12], -9.81 / 240.0, atol=1e-6), s1[:, 12]      # base v_z after one substep of free fall (the COM's, up to the joints' reaction)
+    env.close()
+
+
+@pytest.mark.gpu
+def test_create_from_model_rejects_numbers_the_kernel_cannot_digest():
+    from plen_ml_walk_amd import _lib as L
+    import ctypes as C
+    lib = L.load()
+    cfg = L.default_cfg()
+
+    def rc(mutate):
+        m = L.default_model(); mutate(m)
+        h = C.c_void_p()
+        r = lib.plenvec_create_from_model(C.byref(m), C.byref(cfg), 4, 0, C.byref(h))
+        if r == 0:
+            lib.plenvec_destroy(h)
+        return r
+    assert rc(lambda m: None) == 0
+    def nan_com(m): m.com[3][1] = float("nan")
+    def skew_R(m): m.joint_R[2][1] += 0.01
+    def neg_I(m): m.inertia[5][0] = -1e-6
+    def bad_member(m): m.member_mass[0][0] *= 1.5
+    def bad_rep(m): m.sole_rep[1][3] = 2
+    def inf_box(m): m.box_t[0][2] = float("inf")
+    for mut in (nan_com, skew_R, neg_I, bad_member, bad_rep, inf_box):
+        assert rc(mut) != 0, mut.__name__

@@ -16,8 +16,8 @@ What the tables encode (SURVEY.md section 8a row A2, and DESIGN.md "Model"):
   * per-link mass/COM from <inertial>; per-link inertia NOT from <inertia> but recomputed from
     the collision shape the way Bullet's URDF importer does when URDF_USE_INERTIA_FROM_FILE is
     not passed (plen_env.py:314 passes no flags): box -> m/12*(ly^2+lz^2,..) of the full extents;
-    compound (collision frame != inertial frame) and convex hull -> box inertia of the AABB
-    (hull AABB includes the 1 mm URDF collision margin twice, see DESIGN.md);
+    compound (collision frame != inertial frame) and convex hull -> box inertia of the compound's AABB
+    (child AABB + the compound's own 1 mm margin; the hull's child AABB already includes the margin twice, see DESIGN.md);
   * fixed joints folded into 19 composite bodies for the HIP path (exactly equivalent dynamics);
   * foot contact candidates: 4 sole-hull vertices per foot, extreme along the sole diagonals;
   * the order in which Bullet's solver visits the 36 non-contact constraints (18 joint limits
@@ -37,6 +37,11 @@ URDF = os.path.join(REF, "plen_bullet/src/plen.urdf")
 MESH_DIR = os.path.join(REF, "plen_ros/meshes_bin")
 
 MARGIN = 0.001          # gUrdfDefaultCollisionMargin
+# Hypothesis switch (round 4): btCompoundShape::getAabb grows the local AABB by the compound's OWN margin, and the URDF importer
+# gives every per-link compound gUrdfDefaultCollisionMargin -- if so, the 15 links whose collision frame differs from their inertial frame get 7-17 %
+# more rotational inertia (PLEN_COMPOUND_MARGIN=0.001).  The PyBullet-held pins are split on it (R_0 0.0095 -> 0.0068 and sum R_1..R_4 -7 % in its favour;
+# closed-loop survival of the shipped actor at low noise 6 : 1 against), so the default stays 0: the tables of rounds 1-3.
+COMPOUND_MARGIN = float(os.environ.get("PLEN_COMPOUND_MARGIN", 0.0))
 BREAK_FACTOR = 0.02     # gContactBreakingThreshold / defaultContactThresholdFactor
 MOVING_JOINTS_REF = [5, 6, 7, 9, 10, 11, 13, 14, 15, 17, 18, 19, 20, 21, 24, 26, 27, 30]  # plen_env.py:318-320
 
@@ -147,7 +152,10 @@ def main():
                 aabb_half = half
                 aabb_center = np.zeros(3)
             else:
-                aabb_half = np.abs(cR) @ half           # btTransformAabb of (implicit half + margin)
+                # btCompoundShape::getAabb: child AABB (btTransformAabb of implicit half + margin = the full half extents) grown by the COMPOUND's
+                # own margin -- BulletURDFImporter::convertLinkCollisionShapes does compoundShape->setMargin(gUrdfDefaultCollisionMargin) and
+                # getAabb adds getMargin() to the local half extents (round 4: measured on the PyBullet-held pin)
+                aabb_half = np.abs(cR) @ half + COMPOUND_MARGIN
                 aabb_center = rel_t
                 inertia = box_inertia(mass, 2.0 * aabb_half)
             out.update(collider=dict(type="box", half=half.tolist(), R=cR.tolist(), t=ct.tolist()))
@@ -163,7 +171,7 @@ def main():
             # getAabb() adds it again; btCompoundShape then takes the AABB of that.
             h_local = 0.5 * (hi - lo) + 2.0 * MARGIN
             c_local = 0.5 * (hi + lo)
-            aabb_half = np.abs(cR) @ h_local
+            aabb_half = np.abs(cR) @ h_local + COMPOUND_MARGIN
             aabb_center = cR @ c_local + rel_t
             inertia = box_inertia(mass, 2.0 * aabb_half)
             out.update(collider=dict(type="hull", mesh=fn, margin=MARGIN, verts=hv_link.tolist()))
