@@ -57,15 +57,25 @@ def algo_bytes_per_env_step(real_size):
     return (49 + 25) * real_size + 18 * 4 + (49 + 25 + 26 + 1) * real_size + 4
 
 
-def _pmc_summary(dtype):
+def _pmc_summary(dtype, groups=None):
     """HBM traffic and instruction counts per launch are PMC measurements (rocprofv3 --pmc, separate passes, gfx950 FETCH_SIZE
-    correction applied); bench.py cannot collect them itself, so it reports the newest committed summary under profiles/ for the dtype."""
+    correction applied); bench.py cannot collect them itself, so it reports the newest committed summary under profiles/ for the dtype:
+    the HEADLINE schedule's (scripts/gpu_profile_headline.sh, r04+: `groups` sub-batch launches) when there is one for this many groups,
+    else the one-launch-per-step summary of earlier rounds.  Returns (per-launch dict incl. envs_per_launch, file)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary%s.json" % ("" if dtype == "f32" else "_" + dtype))))
+    if groups and groups > 1:
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_groups_pmc_summary_%s.json" % dtype)), reverse=True):
+            with open(f) as fh:
+                per = json.load(fh)["env_kernel_per_launch"]
+            if per.get("envs_per_launch") == ENVS_PER_GPU // groups:
+                return per, os.path.relpath(f, ROOT)
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary%s.json" % ("" if dtype == "f32" else "_" + dtype))) if "_groups_" not in f)
     if not files:
         return None, None
     with open(files[-1]) as f:
-        return json.load(f)["env_kernel_per_launch"], os.path.relpath(files[-1], ROOT)
+        per = json.load(f)["env_kernel_per_launch"]
+    per.setdefault("envs_per_launch", ENVS_PER_GPU)
+    return per, os.path.relpath(files[-1], ROOT)
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline (rank 0, N = 1)
@@ -183,36 +193,14 @@ def closed_loop_pin(dev, n=2048):
     import torch
     import pybullet_pin as P
     from plen_ml_walk_amd.vec_env import PlenVecEnv
-    W = {k: torch.from_numpy(v).to(dev) for k, v in P.SD.items()}
-
-    def actor(o):
-        h = torch.relu(o @ W["fc1.weight"].T + W["fc1.bias"])
-        h = torch.relu(h @ W["fc2.weight"].T + W["fc2.bias"])
-        return torch.tanh(h @ W["fc3.weight"].T + W["fc3.bias"])
     out = {"episodes_per_sigma": n, "dtype": "f64", "reference": {"deterministic_episode_length": 500, "last1000_training_returns_sigma_0.1": {
         "mean": 50.4, "q_5_25_50_75_95": [-113, -15, 55, 119, 200], "max_over_all_24832_episodes": 328}}}
     for sigma in (1e-4, 0.1):
-        env = PlenVecEnv(n, device=dev, dtype=torch.float64, auto_reset=False)
-        obs = env.reset().clone()
-        g = torch.Generator(device=dev).manual_seed(7)
-        alive = torch.ones(n, dtype=torch.bool, device=dev)
-        length = torch.zeros(n, dtype=torch.long, device=dev); ret = torch.zeros(n, dtype=torch.float64, device=dev)
-        acts = torch.empty(500, n, 18, dtype=torch.float32, device=dev)
-        for t in range(500):
-            noise = sigma * torch.randn(n, 18, generator=g, device=dev, dtype=torch.float64)
-            noise[0] = 0
-            a = torch.clamp(actor(obs) + noise, -1, 1).to(torch.float32)
-            acts[t] = a
-            o, r, d, _ = env.step(a)
-            ret += torch.where(alive, r, torch.zeros_like(r)); length += alive.long()
-            alive &= (d & 1) == 0
-            obs = torch.where(torch.isfinite(o), o, torch.zeros_like(o))          # (dead envs keep stepping with auto_reset off: their garbage is masked, never used)
-        env.close()
-        L, R = length.cpu().numpy(), ret.cpu().numpy()
+        L, R, acts = P.kernel_ensemble(n, torch.float64, sigma=sigma, device=dev, keep_actions=True)
         row = P.closed_loop_summary(L, R, sigma)
         surv = np.nonzero(L >= 500)[0]
         if len(surv):
-            row["survivor_action_stats_vs_pybullet_log"] = P.survivor_action_stats(acts[:, torch.from_numpy(surv[:256]).to(dev)].permute(1, 0, 2).cpu().numpy())
+            row["survivor_action_stats_vs_pybullet_log"] = P.survivor_action_stats(acts[:, torch.from_numpy(surv[:256]).to(acts.device)].permute(1, 0, 2).cpu().numpy())
         if sigma == 1e-4:
             out["closed_loop_len"] = int(L[0]); out["closed_loop_return"] = float(R[0])
         out["sigma_%g" % sigma] = row
@@ -324,13 +312,17 @@ def env_leg(a, dtype_name, dev, rank, world, dist, steps, warmup, dr=None):
     else:
         launch1_ms = None
     n_sub = n // groups
-    launch_ms, n_launch = (launch1_ms, n) if groups > 1 else (slot_ms, n)
+    # The roofline is priced in the HEADLINE schedule (VERDICT r03 weak point 6): a launch = one sub-batch of n_sub envs; its duration = HIP events on
+    # its stream across the timed region / the launches that stream made (each stream runs its launches back to back, so `groups` launches are in
+    # flight at any time: profiles/r04_*_groups*_kernel_stats_*.csv shows the concurrency from the kernel trace).
+    launch_ms, n_launch, in_flight = slot_ms, n_sub, groups
     real_size = 4 if dtype_name == "f32" else 8
     ab = algo_bytes_per_env_step(real_size)
-    achieved = n_launch * ab / (launch_ms * 1e-3) / 1e9
+    achieved_launch = n_launch * ab / (launch_ms * 1e-3) / 1e9
+    achieved = achieved_launch * in_flight                       # whole chip: what `peak` is a property of
     value = world * n * steps / elapsed
-    pmc, pmc_file = _pmc_summary(dtype_name)
-    traffic = pmc["hbm_traffic_bytes"] * n_launch / ENVS_PER_GPU if (pmc and n == ENVS_PER_GPU) else None
+    pmc, pmc_file = _pmc_summary(dtype_name, groups)
+    traffic = pmc["hbm_traffic_bytes"] * n_launch / pmc["envs_per_launch"] if (pmc and n == ENVS_PER_GPU) else None
     valu = None
     if pmc:
         ginst = pmc["valu_insts_per_env_step"] * value / world / 1e9      # whole-GPU issue rate (all concurrent launches)
@@ -351,14 +343,15 @@ def env_leg(a, dtype_name, dev, rank, world, dist, steps, warmup, dr=None):
         "sub_batches": "%d x %d envs per GPU on %d HIP streams: every env advances one control step per bench step, sub-batches are not "
                        "synchronised with each other between steps (PlenVecEnvPipelined); --groups 1 = one launch per step" % (groups, n_sub, groups),
         "one_launch_per_step": None if single is None else {"ms_per_step": single * 1e3, "value": world * n / single},
-        "kernel_ms_per_launch": launch_ms, "pipelined_ms_per_launch_slot": slot_ms,
+        "kernel_ms_per_launch": launch_ms, "pipelined_ms_per_launch_slot": slot_ms, "one_launch_of_all_envs_ms": launch1_ms,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_env_step": ab, "env_steps_per_launch": n_launch, "valu_issue": valu,
-                     "note": "achieved = algorithmic %d B/env-step (SURVEY 8d layout at %d-byte reals) x %d env-steps per launch / %.3f ms per launch (HIP events on "
-                             "the launch stream, launches of all envs back to back); traffic = PMC FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per "
-                             "launch from %s.  The contract's hbm/mfma bounds do not bind this kernel (a serial projected-Gauss-Seidel chain per env): "
-                             "valu_issue prices its measured instruction count against MEASURED issue rates (scripts/ubench/valu_issue.hip): the solver "
-                             "row's own instruction mix, the FMA class, and the guide's nominal 2-cycle rate" % (ab, real_size, n_launch, launch_ms, pmc_file)},
+                     "algorithmic_bytes_per_env_step": ab, "env_steps_per_launch": n_launch, "algorithmic_bytes_per_launch": n_launch * ab,
+                     "launch_ms": launch_ms, "launches_in_flight": in_flight, "achieved_per_launch": achieved_launch, "valu_issue": valu,
+                     "note": "headline schedule: a launch = one sub-batch of %d envs; achieved = algorithmic %d B/env-step (SURVEY 8d layout at %d-byte reals) x %d env-steps "
+                             "per launch / %.3f ms per launch (HIP events on the sub-batch's own stream over the timed region) x %d launches in flight (one per stream, "
+                             "back to back); traffic = PMC FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch from %s.  The contract's hbm/mfma bounds do not "
+                             "bind this kernel (a serial projected-Gauss-Seidel chain per env): roofline_valu prices its measured instruction count against MEASURED "
+                             "issue rates (scripts/ubench/valu_issue.hip)" % (n_launch, ab, real_size, n_launch, launch_ms, in_flight, pmc_file)},
         "nonfinite_resets": nonfinite,
     }
 

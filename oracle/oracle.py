@@ -61,6 +61,7 @@ def _lib(dtype="f64"):
         lib.oracle_rollout.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), dp, dp, C.POINTER(C.c_uint8)]
         lib.oracle_batch_rollout.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_float), dp, dp, C.c_double, C.c_int, C.c_int, dp, dp, C.POINTER(C.c_uint8)]
         lib.oracle_set_reward_head.argtypes = [C.c_void_p, C.c_int]
+        lib.oracle_ensemble.argtypes = [C.c_int] + [dp] * 6 + [C.c_double, C.c_uint, C.c_int, C.c_int, ip, dp, ip, dp]
         lib.oracle_foot_forces.argtypes = [C.c_void_p, dp]
         lib.oracle_gazebo_contact.argtypes = [dp]
         lib.oracle_gazebo_contact.restype = C.c_int
@@ -87,6 +88,28 @@ def batch_rollout(actions, mass_scale=None, lateral_friction=None, rolling=-1.0,
     lib.oracle_batch_rollout(n, T, a.ctypes.data_as(C.POINTER(C.c_float)), None if ms is None else _dp(ms), None if mu is None else _dp(mu),
                              float(rolling), int(bool(body_contacts)), int(threads), _dp(obs), _dp(rew), flags.ctypes.data_as(C.POINTER(C.c_uint8)))
     return obs, rew, flags
+
+
+def ensemble(n_episodes, actor=None, sigma=0.0, seed=0, threads=None, hyp=None, dtype="f64"):
+    """n_episodes closed-loop episodes from reset on the oracle (C, threaded): actor = dict of float64 arrays fc1.weight .. fc3.bias (td3.py:19-57) or None
+    for uniform random actions; N(0, sigma) action noise.  hyp: {oracle_set_hyp key number: value}.  Returns (lengths int[n], returns float[n])."""
+    lib = _lib(dtype)
+    if threads is None:
+        try:
+            threads = min(32, len(os.sched_getaffinity(0)))
+        except AttributeError:
+            threads = min(32, os.cpu_count() or 1)
+    L = np.zeros(n_episodes, dtype=np.int32); R = np.zeros(n_episodes)
+    if actor is not None:
+        w = [np.ascontiguousarray(actor[k], dtype=np.float64) for k in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")]
+        assert w[0].shape == (256, 26) and w[2].shape == (256, 256) and w[4].shape == (18, 256)
+        ptrs = [_dp(x) for x in w]
+    else:
+        ptrs = [None] * 6
+    hk = np.array(list((hyp or {}).keys()), dtype=np.int32); hv = np.array(list((hyp or {}).values()), dtype=np.float64)
+    lib.oracle_ensemble(int(n_episodes), *ptrs, float(sigma), int(seed), int(threads), len(hk), hk.ctypes.data_as(C.POINTER(C.c_int)), _dp(hv),
+                        L.ctypes.data_as(C.POINTER(C.c_int)), _dp(R))
+    return L, R
 
 
 def native_lib():

@@ -1294,6 +1294,65 @@ API void oracle_batch_rollout(int n_envs, int T, const float *actions, const dou
     for (int k = 0; k < threads; k++) pthread_join(th[k], NULL);
 }
 
+
+/* ---------------------------------------------------------------- closed-loop ensembles (tests/test_distribution_gpu.py, scripts/pin/): n_episodes
+ * independent episodes from reset, each until done or the 500-step limit, the envs partitioned over POSIX threads.  Actions: the actor MLP
+ * 26-256-256-18 (td3.py:19-57; weights row major [out][in] as torch stores them, NULL = uniform random actions U[-1, 1) like the benchmark's)
+ * plus N(0, sigma) noise clipped to [-1, 1] (plen_td3.py:101-104) and rounded to float32 (the Box dtype).  Per-episode xorshift streams seeded
+ * from `seed`: a statistical sample, not a replay of anybody else's noise.  hyp_keys / hyp_vals: oracle_set_hyp switches applied to every env. */
+typedef struct { int e0, e1; const double *W1, *b1, *W2, *b2, *W3, *b3; double sigma; unsigned seed; int nh; const int *hk; const double *hv;
+                 int *len; double *ret; } EnsJob;
+static double ens_uniform(uint64_t *x) { *x ^= *x << 13; *x ^= *x >> 7; *x ^= *x << 17; return (double)(*x >> 11) * (1.0 / 9007199254740992.0); }
+static double ens_normal(uint64_t *x) {
+    double u1 = ens_uniform(x), u2 = ens_uniform(x);
+    if (u1 < 1e-300) u1 = 1e-300;
+    return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+}
+static void *ens_worker(void *arg) {
+    EnsJob *j = (EnsJob *)arg;
+    Oracle *o = oracle_create(0);
+    for (int k = 0; k < j->nh; k++) oracle_set_hyp(o, j->hk[k], j->hv[k]);
+    double *h1 = (double *)malloc(256 * sizeof(double)), *h2 = (double *)malloc(256 * sizeof(double));
+    for (int e = j->e0; e < j->e1; e++) {
+        uint64_t rng = 0x9E3779B97F4A7C15ull * (uint64_t)(j->seed + 1u + (unsigned)e) | 1ull;
+        for (int w = 0; w < 8; w++) ens_uniform(&rng);
+        double ob[26], a[ND], ret = 0; int done = 0, t = 0;
+        oracle_reset(o, ob);
+        for (t = 0; t < 500 && !done; t++) {
+            if (j->W1) {
+                for (int i = 0; i < 256; i++) { double s = j->b1[i]; for (int k = 0; k < 26; k++) s += j->W1[i * 26 + k] * ob[k]; h1[i] = s > 0 ? s : 0; }
+                for (int i = 0; i < 256; i++) { double s = j->b2[i]; for (int k = 0; k < 256; k++) s += j->W2[i * 256 + k] * h1[k]; h2[i] = s > 0 ? s : 0; }
+                for (int i = 0; i < ND; i++) { double s = j->b3[i]; for (int k = 0; k < 256; k++) s += j->W3[i * 256 + k] * h2[k]; a[i] = tanh(s); }
+            } else for (int i = 0; i < ND; i++) a[i] = ens_uniform(&rng) * 2.0 - 1.0;
+            for (int i = 0; i < ND; i++) {
+                if (j->W1 && j->sigma > 0) a[i] += j->sigma * ens_normal(&rng);
+                if (a[i] > 1) a[i] = 1;
+                if (a[i] < -1) a[i] = -1;
+                a[i] = (double)(float)a[i];
+            }
+            ret += oracle_step(o, a, ob, &done);
+        }
+        j->len[e] = t; j->ret[e] = ret;
+    }
+    free(h1); free(h2); oracle_destroy(o);
+    return NULL;
+}
+API void oracle_ensemble(int n_episodes, const double *W1, const double *b1, const double *W2, const double *b2, const double *W3, const double *b3,
+                         double sigma, unsigned seed, int threads, int n_hyp, const int *hyp_keys, const double *hyp_vals, int *lengths, double *returns) {
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    pthread_t th[256]; EnsJob jobs[256];
+    int per = (n_episodes + threads - 1) / threads;
+    for (int k = 0; k < threads; k++) {
+        EnsJob *j = &jobs[k];
+        j->e0 = k * per < n_episodes ? k * per : n_episodes; j->e1 = (k + 1) * per < n_episodes ? (k + 1) * per : n_episodes;
+        j->W1 = W1; j->b1 = b1; j->W2 = W2; j->b2 = b2; j->W3 = W3; j->b3 = b3; j->sigma = sigma; j->seed = seed; j->nh = n_hyp; j->hk = hyp_keys; j->hv = hyp_vals;
+        j->len = lengths; j->ret = returns;
+        pthread_create(&th[k], NULL, ens_worker, j);
+    }
+    for (int k = 0; k < threads; k++) pthread_join(th[k], NULL);
+}
+
 API double oracle_last_residual(const Oracle *o) { return (double)o->last_residual; }
 API void oracle_set_reward_head(Oracle *o, int head) { o->reward_head = head; }
 API void oracle_foot_forces(const Oracle *o, double *f6) { for (int i = 0; i < 6; i++) f6[i] = o->foot_force[i / 3][i % 3]; }

@@ -281,3 +281,51 @@ def closed_loop_summary(lengths, returns, sigma):
     return dict(sigma=sigma, episodes=int(len(L)), mean_length=float(L.mean()), early_falls_lt50=float((L < 50).mean()), full_length=float((L >= 500).mean()),
                 ret_mean=float(R.mean()), ret_q_5_25_50_75_95=[float(v) for v in np.quantile(R, [0.05, 0.25, 0.5, 0.75, 0.95])], ret_max=float(R.max()),
                 w1_to_reference_last1000=w1(R, reference_last1000_returns()))
+
+
+def kernel_ensemble(n, dtype, sigma=0.0, policy=True, cfg=None, seed=7, device="cuda:0", keep_actions=False):
+    """n closed-loop episodes from reset on the HIP KERNEL through PlenVecEnv (auto-reset off; an env that has ended keeps stepping, masked): the shipped
+    actor in float64 torch on the device + N(0, sigma) noise (env 0 gets none), or uniform random actions.  Returns (lengths, returns[, actions [500, n, 18]])."""
+    import torch
+    from plen_ml_walk_amd.vec_env import PlenVecEnv
+    dev = torch.device(device)
+    W = {k: torch.from_numpy(v).to(dev) for k, v in SD.items()}
+
+    def actor(o):
+        h = torch.relu(o @ W["fc1.weight"].T + W["fc1.bias"])
+        h = torch.relu(h @ W["fc2.weight"].T + W["fc2.bias"])
+        return torch.tanh(h @ W["fc3.weight"].T + W["fc3.bias"])
+    env = PlenVecEnv(n, device=dev, dtype=dtype, auto_reset=False, cfg_overrides=cfg)
+    obs = env.reset().to(torch.float64).clone()
+    g = torch.Generator(device=dev).manual_seed(seed)
+    alive = torch.ones(n, dtype=torch.bool, device=dev)
+    length = torch.zeros(n, dtype=torch.long, device=dev); ret = torch.zeros(n, dtype=torch.float64, device=dev)
+    acts = torch.empty(500, n, 18, dtype=torch.float32, device=dev) if keep_actions else None
+    for t in range(500):
+        if policy:
+            noise = sigma * torch.randn(n, 18, generator=g, device=dev, dtype=torch.float64)
+            noise[0] = 0
+            a = torch.clamp(actor(obs) + noise, -1, 1).to(torch.float32)
+        else:
+            a = torch.rand(n, 18, generator=g, device=dev, dtype=torch.float32) * 2 - 1
+        if keep_actions:
+            acts[t] = a
+        o, r, d, _ = env.step(a)
+        r = r.to(torch.float64)
+        ret += torch.where(alive & torch.isfinite(r), r, torch.zeros_like(r)); length += alive.long()
+        alive &= (d & 1) == 0
+        o = o.to(torch.float64)
+        obs = torch.where(torch.isfinite(o), o, torch.zeros_like(o))
+        if not bool(alive.any()):
+            break
+    env.close()
+    out = (length.cpu().numpy(), ret.cpu().numpy())
+    return out + (acts,) if keep_actions else out
+
+
+def ks(a, b):
+    """Two-sample Kolmogorov-Smirnov statistic D and the large-sample critical value at alpha = 0.001 (c = 1.95)."""
+    a, b = np.sort(np.asarray(a, dtype=np.float64)), np.sort(np.asarray(b, dtype=np.float64))
+    x = np.concatenate([a, b])
+    D = float(np.abs(np.searchsorted(a, x, side="right") / len(a) - np.searchsorted(b, x, side="right") / len(b)).max())
+    return D, 1.95 * float(np.sqrt((len(a) + len(b)) / (len(a) * len(b))))
