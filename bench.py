@@ -518,6 +518,8 @@ def _td3_run(a, dev, rank, world, dist, steps, warmup, batch):
 
     for _ in range(max(warmup, 30)):         # past the random-action phase (3 vector steps at 4096 envs) and every graph capture
         tr.step()
+    while tr.env_steps < 10000 + 8 * n:      # few envs per rank (tests, strong scaling): the random-action phase is start_timesteps / n vector steps long
+        tr.step()
     barrier()
     e0, g0, t0 = tr.env_steps, tr.grad_steps, time.perf_counter()
     for _ in range(steps):
