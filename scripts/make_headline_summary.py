@@ -46,7 +46,7 @@ for dt, groups in (("f64", 4), ("f32", 2)):
             f.write("# headline schedule: %d x %d envs on %d HIP streams; %d sub-batch launches of the timed region traced\n" % (groups, n_sub, groups, len(tr)))
             f.write("# per-launch duration ns: mean %.0f median %.0f min %.0f max %.0f\n" % (dur.mean(), np.median(dur), dur.min(), dur.max()))
             f.write("# mean launches in flight %.2f; fraction of the span with k in flight: %s\n" % (acc / span, json.dumps({int(k): round(v / span, 3) for k, v in sorted(hist.items())})))
-            f.write("# throughput implied by the trace: %d launches x %d envs / %.3f ms = %.3f M env-steps/s; per vector step of 4096 envs: %.4f ms (must be <= the driver's ms_per_step)\n" % (
+            f.write("# throughput implied by the trace: %d launches x %d envs / %.3f ms = %.3f M env-steps/s; per vector step of 4096 envs: %.4f ms (span of the traced launches incl. the barriers between the 100-step blocks; the same run's host-clock ms_per_step is in the bench line below)\n" % (
                 len(tr), n_sub, span / 1e6, len(tr) * n_sub / (span / 1e9) / 1e6, span / 1e6 / (len(tr) / groups)))
             f.write("# dispatch: LDS_Block_Size=%s Scratch_Size=%s VGPR_Count=%s Accum_VGPR_Count=%s SGPR_Count=%s Workgroup=%s Grid=%s\n" % (
                 r0["LDS_Block_Size"], r0["Scratch_Size"], r0["VGPR_Count"], r0["Accum_VGPR_Count"], r0["SGPR_Count"], r0["Workgroup_Size_X"], r0["Grid_Size_X"]))

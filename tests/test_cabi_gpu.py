@@ -53,6 +53,8 @@ def test_create_from_model_variant_equals_the_mass_scale_parameter():
     m2 = L.default_model()
     for b in (13, 14, 15):
         m2.mass[b] *= 2.0
+        for i in range(L.MAXMEMB):
+            m2.member_mass[b][i] *= 2.0           # (the member links' masses must sum to the body's: plenvec_create_from_model checks it)
     ec = PlenVecEnv(n, device="cuda:0", dtype=torch.float64, model=m2, cfg_overrides=cfg)
     oa, ob, oc = ea.reset().clone(), eb.reset().clone(), ec.reset().clone()
     assert float((oa - ob).abs().max()) < 1e-8, float((oa - ob).abs().max())
