@@ -234,6 +234,9 @@ typedef struct {
     int nc_order;            /* 1: motors visited in DoF order instead of btAlignedObjectArray::quickSort's scramble of equal island keys; 2: reverse DoF order */
     int no_order_flip;       /* 1: the non-contact rows are not reversed on even iterations */
     int torsional_points;    /* > 0: only the first n points of a manifold get spinning / rolling rows */
+    int fric_order;          /* torsional rows: 0 = Bullet >= 2.87 (all spinning rows, then all rolling rows: two arrays); 1 = per point interleaved (spin, roll1, roll2: the single
+                                m_multiBodyTorsionalFrictionContactConstraints array of Bullet <= 2.86); 2 = all rolling rows before the spinning rows */
+    int lever_on_plane;      /* 1: the contact rows' Jacobians are taken at the point on the GROUND (cp.getPositionWorldOnA for body A = plane) instead of the point on the foot */
     int tors_freeze;         /* > 0: the bounds of the spinning / rolling rows are no longer rewritten from the normal impulse after this many iterations
                                 (mechanism A/B of the expanding mode, scripts/pin/expanding_mode.py; Bullet rewrites them in every iteration) */
 } World;
@@ -721,6 +724,7 @@ static void substep(Oracle *o) {
     static const real Z3[3] = {0, 0, 0};
     Row nc[36], nrm[MAXCP], spin[MAXCP], roll[2 * MAXCP], fric[2 * MAXCP];
     int n_nc = 0, n_n = 0, n_spin = 0, n_roll = 0, n_fric = 0;
+    int spin_of[MAXCP], roll_of[MAXCP];
     for (int s = 0; s < 36; s++) {
         int d = RAW_NC_DOF[s];
         if (w->nc_order == 1) d = s % 18; else if (w->nc_order == 2) d = 17 - s % 18;
@@ -758,7 +762,8 @@ static void substep(Oracle *o) {
     const real dir1[3] = {0, -1, 0}, dir2[3] = {1, 0, 0};          /* btPlaneSpace1((0,0,1)) */
     for (int c = 0; c < o->ncp; c++) {
         const int link = o->cp_link[c], is_foot = o->cp_foot[c] >= 0;
-        const real *P = o->cp_pos[c];
+        real Pl[3] = {o->cp_pos[c][0], o->cp_pos[c][1], w->lever_on_plane ? (real)0 : o->cp_pos[c][2]};
+        const real *P = Pl;
         Row *r = &nrm[n_n];
         fill_jacobian(o, link, P, Z3, nrmW, r->jac);
         real cfm = w->global_cfm / dt;
@@ -773,7 +778,9 @@ static void substep(Oracle *o) {
         r->friction_index = n_n;
         const int tors_idx = o->cp_man[c] >= 0 ? o->cp_man[c] : (o->cp_slot[c] & 3);          /* position of the point in its foot's manifold */
         const int tors_ok = !(w->torsional_points > 0 && tors_idx >= w->torsional_points);
+        spin_of[n_n] = roll_of[n_n] = -1;
         if (is_foot && tors_ok && w->spinning_friction > 0) {      /* spinning / rolling friction is set on the two foot links only (plen_env.py:439-467) */
+            spin_of[n_n] = n_spin;
             Row *t = &spin[n_spin++];
             fill_jacobian(o, link, P, nrmW, Z3, t->jac);
             real rv = row_finish(o, t, 0);
@@ -781,6 +788,7 @@ static void substep(Oracle *o) {
             t->lo = -t->friction; t->hi = t->friction;
         }
         if (is_foot && tors_ok && w->rolling_friction > 0) {
+            roll_of[n_n] = n_roll;
             for (int a = 0; a < 2; a++) {
                 Row *t = &roll[n_roll++];
                 fill_jacobian(o, link, P, a == 0 ? dir1 : dir2, Z3, t->jac);
@@ -814,15 +822,28 @@ static void substep(Oracle *o) {
             real r = resolve_row(&nc[idx], dv); if (r * r > residual) residual = r * r;
         }
         for (int j = 0; j < n_n; j++) { real r = resolve_row(&nrm[j], dv); if (r * r > residual) residual = r * r; }
+        if (w->fric_order == 1) {          /* per point: spin, roll1, roll2 (rows of point c: spin_of[c], roll_of[c], roll_of[c] + 1; -1 = none) */
+            for (int c = 0; c < n_n; c++) {
+                Row *rs[3] = {spin_of[c] >= 0 ? &spin[spin_of[c]] : 0, roll_of[c] >= 0 ? &roll[roll_of[c]] : 0, roll_of[c] >= 0 ? &roll[roll_of[c] + 1] : 0};
+                for (int q = 0; q < 3; q++) if (rs[q]) {
+                    real tot = nrm[rs[q]->friction_index].applied;
+                    if (tot > 0) { if (!(w->tors_freeze > 0 && it >= w->tors_freeze)) { rs[q]->lo = -rs[q]->friction * tot; rs[q]->hi = rs[q]->friction * tot; }
+                        real r = resolve_row(rs[q], dv); if (r * r > residual) residual = r * r; }
+                }
+            }
+        } else for (int pass = 0; pass < 2; pass++) {
+        if ((pass == 0) == (w->fric_order != 2))
         for (int j = 0; j < n_spin; j++) {
             real tot = nrm[spin[j].friction_index].applied;
             if (tot > 0) { if (!(w->tors_freeze > 0 && it >= w->tors_freeze)) { spin[j].lo = -spin[j].friction * tot; spin[j].hi = spin[j].friction * tot; }
                 real r = resolve_row(&spin[j], dv); if (r * r > residual) residual = r * r; }
         }
+        else
         for (int j = 0; j < n_roll; j++) {
             real tot = nrm[roll[j].friction_index].applied;
             if (tot > 0) { if (!(w->tors_freeze > 0 && it >= w->tors_freeze)) { roll[j].lo = -roll[j].friction * tot; roll[j].hi = roll[j].friction * tot; }
                 real r = resolve_row(&roll[j], dv); if (r * r > residual) residual = r * r; }
+        }
         }
         for (int j = 0; j + 1 < n_fric; j += 2) {
             real tot = nrm[fric[j].friction_index].applied;
@@ -1052,6 +1073,7 @@ API int oracle_set_hyp(Oracle *o, int key, double v) {
     case 23: w->pyramid_friction = (int)v; break; case 24: w->base_gyro_off = (int)v; break;
     case 25: w->torsional_points = (int)v; break;
     case 42: w->tors_freeze = (int)v; break;
+    case 43: w->fric_order = (int)v; break; case 44: w->lever_on_plane = (int)v; break;
     case 30: w->man_cand = (int)v; break; case 31: w->man_drift = (real)v; break; case 32: w->man_add_all = (int)v; break;
     case 37: w->sole_grow = (real)v; break; case 38: w->sole_dz = (real)v; break;
     case 39: w->man_p1 = (int)v; break; case 40: w->man_p1x = (real)v; break; case 41: w->man_p1y = (real)v; break;

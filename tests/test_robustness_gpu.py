@@ -668,3 +668,35 @@ def test_rccl_world_size_one_runs_the_multi_rank_code_path(tmp_path):
     assert p["max_abs_param_diff_vs_no_collectives"] < 2e-2
     lat = r["allreduce_latency_620KB"]
     assert lat["alone"]["device_us_per_call"] < 500 and lat["beside_two_resident_2048_env_launches"]["device_us_per_call"] < 5000
+
+
+@pytest.mark.gpu
+def test_reference_recipe_two_thousand_updates():
+    """the REFERENCE'S recipe -- batch 100, ONE update per env-step (plen_td3.py:119-120), policy_freq 2 (td3.py:329-345), exploration
+    N(0, 0.1) -- through the hipGraph trainer: 16 envs step together, 16 updates follow.  After the random-action phase exactly one update per env-step has
+    run, the actor has moved on every second of them (target networks follow), losses are finite, and the update-to-data ratio is the reference's 1."""
+    from plen_ml_walk_amd.vec_env import PlenVecEnv
+    from plen_ml_walk_amd.td3 import ReplayBuffer, TD3Agent
+    from plen_ml_walk_amd.train_vec import GraphedVecTD3Trainer
+    torch.manual_seed(0)
+    n, start = 16, 1024
+    env = PlenVecEnv(n, device="cuda:0")
+    agent = TD3Agent(26, 18, 1.0, device=torch.device("cuda:0"))
+    replay = ReplayBuffer(100000, device=torch.device("cuda:0")); replay.seed(0)
+    tr = GraphedVecTD3Trainer(env, agent, replay, start_timesteps=start, expl_noise=0.1, batch_size=100, updates_per_step=n, seed=3)
+    a0 = torch.cat([p.detach().flatten().clone() for p in agent.actor.parameters()])
+    c0 = torch.cat([p.detach().flatten().clone() for p in agent.critic.parameters()])
+    while tr.grad_steps < 2000:
+        tr.step()
+    torch.cuda.synchronize()
+    warm_steps = start                                      # env-steps before the first update (start_timesteps is a multiple of n)
+    assert tr.grad_steps == tr.env_steps - warm_steps + n and tr.grad_steps == 2000       # the step that reaches start_timesteps already updates: one update per env-step from there
+    assert agent.total_it == 2000 and replay.size == tr.env_steps
+    a1 = torch.cat([p.detach().flatten() for p in agent.actor.parameters()])
+    c1 = torch.cat([p.detach().flatten() for p in agent.critic.parameters()])
+    at = torch.cat([p.detach().flatten() for p in agent.actor_target.parameters()])
+    assert torch.isfinite(a1).all() and torch.isfinite(c1).all() and float(agent.last_critic_loss) == float(agent.last_critic_loss)
+    assert float((a1 - a0).abs().max()) > 1e-3 and float((c1 - c0).abs().max()) > 1e-3
+    # Polyak tau 0.005 over 1000 policy updates: the target actor has moved most of the way from the initial actor towards the current one
+    assert float((at - a0).abs().max()) > 1e-4 and float((at - a1).abs().mean()) < float((a0 - a1).abs().mean())
+    env.close()
