@@ -7,6 +7,7 @@ max_episode_steps=500 (:15-19), `PlenWalkEnv(render=False, realtime=False, joint
 `joint_names` / `movingJoints`, `close()` (:1095).  One env = one wavefront of libplenvec's kernel,
 computed in float64 (the reference and PyBullet are double precision); use PlenVecEnv for throughput.
 """
+import os
 import numpy as np
 import torch
 
@@ -41,7 +42,7 @@ except Exception:                      # noqa: BLE001 -- gym absent or id alread
 class PlenWalkEnv(Env):
     metadata = {'render.modes': ['human', 'rgb_array'], 'video.frames_per_second': 50}
 
-    def __init__(self, render=False, realtime=False, joint_act=False, device=None, dtype=torch.float64, reward_head=0):
+    def __init__(self, render=False, realtime=False, joint_act=False, device=None, dtype=torch.float64, reward_head=0, quiet=False):
         if render or realtime:
             raise NotImplementedError("the GPU environment has no GUI / wall-clock mode (plen_env.py:275-292 are PyBullet GUI features)")
         self.joint_act = joint_act
@@ -62,6 +63,12 @@ class PlenWalkEnv(Env):
         self.cumulated_episode_reward = 0
         self.episode_timestep = 0
         self.total_timesteps = 0
+        # per-episode reward line + moving average over the last 1000 episodes, printed at reset like plen_env.py:52-55, 575-577, 616-636
+        # (quiet=True, or PLEN_QUIET=1, switches the print off; the bookkeeping stays)
+        self.moving_avg_buffer_size = 1000
+        self.moving_avg_buffer = np.zeros(self.moving_avg_buffer_size)
+        self.moving_avg_counter = 0
+        self.quiet = bool(quiet) or os.environ.get("PLEN_QUIET") == "1"
         # the caller owns resets (plen_td3.py:122-133), the TimeLimit wrapper owns the 500-step limit
         self._vec = PlenVecEnv(1, device=device, dtype=dtype, joint_act=joint_act, auto_reset=False,
                                cfg_overrides={"max_episode_steps": 2 ** 30, "reward_head": int(reward_head)})
@@ -70,9 +77,21 @@ class PlenWalkEnv(Env):
     def _seed(self, seed=None):        # the reference defines _seed, not seed (plen_env.py:28); the env has no RNG
         return [seed]
 
+    def _publish_reward(self, reward, episode_number):
+        """plen_env.py:616-636: this episode's reward and the moving average over the last 1000 episodes (NaN until 1000 exist)."""
+        if self.moving_avg_counter >= self.moving_avg_buffer_size:
+            self.moving_avg_counter = 0
+        self.moving_avg_buffer[self.moving_avg_counter] = self.cumulated_episode_reward
+        moving_avg_reward = np.average(self.moving_avg_buffer) if self.episode_num >= self.moving_avg_buffer_size else np.nan
+        if not self.quiet:
+            print("Episode #{} \tTotal Timesteps: {} \nReward: {} \tMA Reward: {}\n".format(episode_number, self.total_timesteps, reward, moving_avg_reward))
+        return moving_avg_reward
+
     def reset(self):
         obs = self._vec.reset()
+        self._publish_reward(self.cumulated_episode_reward, self.episode_num)          # same order as plen_env.py:574-579
         self.episode_num += 1
+        self.moving_avg_counter += 1
         self.cumulated_episode_reward = 0
         self.episode_timestep = 0
         return obs[0].to(torch.float64).cpu().numpy()

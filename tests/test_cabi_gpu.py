@@ -141,3 +141,24 @@ def test_create_from_model_rejects_numbers_the_kernel_cannot_digest():
     def inf_box(m): m.box_t[0][2] = float("inf")
     for mut in (nan_com, skew_R, neg_I, bad_member, bad_rep, inf_box):
         assert rc(mut) != 0, mut.__name__
+
+
+@pytest.mark.gpu
+def test_facade_publishes_the_episode_reward_like_the_reference(capsys):
+    """plen_env.py:574-579, 616-636: reset() prints the finished episode's cumulated reward and the 1000-episode moving average (NaN until 1000 episodes exist)."""
+    import numpy as np
+    from plen_ml_walk_amd.plen_env import PlenWalkEnv
+    env = PlenWalkEnv()
+    env.reset()
+    first = capsys.readouterr().out
+    assert "Episode #0" in first and "Reward: 0" in first and "MA Reward: nan" in first
+    tot = 0.0
+    for t in range(5):
+        _, r, done, _ = env.step(np.zeros(18, dtype=np.float32)); tot += r
+    env.reset()
+    out = capsys.readouterr().out
+    assert "Episode #1" in out and "Total Timesteps: 5" in out and ("Reward: %s" % tot) in out, (out, tot)
+    assert env.moving_avg_buffer[1] == tot and env.episode_num == 2
+    q = PlenWalkEnv(quiet=True); q.reset()
+    assert capsys.readouterr().out == ""
+    env.close(); q.close()
