@@ -234,6 +234,8 @@ typedef struct {
     int nc_order;            /* 1: motors visited in DoF order instead of btAlignedObjectArray::quickSort's scramble of equal island keys; 2: reverse DoF order */
     int no_order_flip;       /* 1: the non-contact rows are not reversed on even iterations */
     int torsional_points;    /* > 0: only the first n points of a manifold get spinning / rolling rows */
+    int man_key_ground;      /* manifold_mode 1: 1 = getCacheEntry / sortCachedPoints work on m_localPointA of body A = the PLANE (loaded first: lower broadphase id),
+                                i.e. on the points' GROUND positions, not on their foot-frame positions */
     int fric_order;          /* torsional rows: 0 = Bullet >= 2.87 (all spinning rows, then all rolling rows: two arrays); 1 = per point interleaved (spin, roll1, roll2: the single
                                 m_multiBodyTorsionalFrictionContactConstraints array of Bullet <= 2.86); 2 = all rolling rows before the spinning rows */
     int lever_on_plane;      /* 1: the contact rows' Jacobians are taken at the point on the GROUND (cp.getPositionWorldOnA for body A = plane) instead of the point on the foot */
@@ -573,7 +575,8 @@ static void collide(Oracle *o) {
             v3sub(d, pa, O);
             for (int k = 0; k < 3; k++) la[k] = R[k] * d[0] + R[3 + k] * d[1] + R[6 + k] * d[2];      /* R^T (pa - O) */
             int near = -1; real best = o->w.man_cache > 0 ? thr2 * o->w.man_cache * o->w.man_cache : thr2;                          /* getCacheEntry */
-            for (int i = 0; i < o->man[f].n; i++) { real e[3]; v3sub(e, o->man[f].lA[i], la); real q = v3dot(e, e); if (q < best) { best = q; near = i; } }
+            const real gnd[3] = {lw[0], lw[1], 0};
+            for (int i = 0; i < o->man[f].n; i++) { real e[3]; if (o->w.man_key_ground) v3sub(e, o->man[f].wB[i], gnd); else v3sub(e, o->man[f].lA[i], la); real q = v3dot(e, e); if (q < best) { best = q; near = i; } }
             int ins;
             if (near >= 0) ins = near;                                /* replaceContactPoint keeps the applied impulse */
             else if (o->man[f].n < 4) { ins = o->man[f].n++; o->man[f].imp[ins] = 0; }
@@ -585,11 +588,12 @@ static void collide(Oracle *o) {
                     if (di < maxpen) { deep = i; maxpen = di; }
                 }
                 real res[4] = {0, 0, 0, 0}, a[3], bb[3], c[3];
-                const real (*P)[3] = o->man[f].lA;
-                if (deep != 0) { v3sub(a, la, P[1]); v3sub(bb, P[3], P[2]); v3cross(c, a, bb); res[0] = v3dot(c, c); }
-                if (deep != 1) { v3sub(a, la, P[0]); v3sub(bb, P[3], P[2]); v3cross(c, a, bb); res[1] = v3dot(c, c); }
-                if (deep != 2) { v3sub(a, la, P[0]); v3sub(bb, P[3], P[1]); v3cross(c, a, bb); res[2] = v3dot(c, c); }
-                if (deep != 3) { v3sub(a, la, P[0]); v3sub(bb, P[2], P[1]); v3cross(c, a, bb); res[3] = v3dot(c, c); }
+                const real (*P)[3] = o->w.man_key_ground ? o->man[f].wB : o->man[f].lA;
+                const real *la_k = o->w.man_key_ground ? gnd : la;
+                if (deep != 0) { v3sub(a, la_k, P[1]); v3sub(bb, P[3], P[2]); v3cross(c, a, bb); res[0] = v3dot(c, c); }
+                if (deep != 1) { v3sub(a, la_k, P[0]); v3sub(bb, P[3], P[2]); v3cross(c, a, bb); res[1] = v3dot(c, c); }
+                if (deep != 2) { v3sub(a, la_k, P[0]); v3sub(bb, P[3], P[1]); v3cross(c, a, bb); res[2] = v3dot(c, c); }
+                if (deep != 3) { v3sub(a, la_k, P[0]); v3sub(bb, P[2], P[1]); v3cross(c, a, bb); res[3] = v3dot(c, c); }
                 ins = 0; for (int i = 1; i < 4; i++) if (res[i] > res[ins]) ins = i;     /* btVector4::closestAxis4 */
                 o->man[f].imp[ins] = 0;
             }
@@ -1073,7 +1077,7 @@ API int oracle_set_hyp(Oracle *o, int key, double v) {
     case 23: w->pyramid_friction = (int)v; break; case 24: w->base_gyro_off = (int)v; break;
     case 25: w->torsional_points = (int)v; break;
     case 42: w->tors_freeze = (int)v; break;
-    case 43: w->fric_order = (int)v; break; case 44: w->lever_on_plane = (int)v; break;
+    case 43: w->fric_order = (int)v; break; case 44: w->lever_on_plane = (int)v; break; case 45: w->man_key_ground = (int)v; break;
     case 30: w->man_cand = (int)v; break; case 31: w->man_drift = (real)v; break; case 32: w->man_add_all = (int)v; break;
     case 37: w->sole_grow = (real)v; break; case 38: w->sole_dz = (real)v; break;
     case 39: w->man_p1 = (int)v; break; case 40: w->man_p1x = (real)v; break; case 41: w->man_p1y = (real)v; break;

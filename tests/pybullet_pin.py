@@ -23,7 +23,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 # oracle_set_hyp keys (oracle/plen_oracle.c)
 HYP = dict(erp=0, erp2=1, friction_erp=2, cfm=3, slop=4, resid=5, rest_thr=6, maxvel=7, mu=8, box_mu=9, spin=10, roll=11, rest=12,
            lin_damp=13, ang_damp=14, kp=15, kd=16, max_force=17, iters=18, body_contacts=19, dt=20, manifold=21, warm=22, pyramid=23,
-           gyro_off=24, tors_pts=25, rhs_clamp=26, joint_damping=27, nc_order=28, no_flip=29, man_cand=30, man_drift=31, man_add_all=32, man_fresh=33, man_order=34, man_cache=35, man_range=36, sole_grow=37, sole_dz=38, man_p1=39, man_p1x=40, man_p1y=41, tors_freeze=42, fric_order=43, lever_on_plane=44)
+           gyro_off=24, tors_pts=25, rhs_clamp=26, joint_damping=27, nc_order=28, no_flip=29, man_cand=30, man_drift=31, man_add_all=32, man_fresh=33, man_order=34, man_cache=35, man_range=36, sole_grow=37, sole_dz=38, man_p1=39, man_p1x=40, man_p1y=41, tors_freeze=42, fric_order=43, lever_on_plane=44, man_key_ground=45)
 
 
 def load():
