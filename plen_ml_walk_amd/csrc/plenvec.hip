@@ -361,6 +361,21 @@ __device__ __forceinline__ void for_foot_points(unsigned act, F &&row) {
     });
 }
 
+// The same rows for a contact section compiled for KNOWN point counts of the two feet (NR right, NL left; a foot's occupied slots are a prefix): no point test at all.
+// The solver picks the copy once per iteration from the substep's two counts (PLENVEC_COUNT_SPECIALISED, round 4): in the benchmark's rollouts the nested tests above were
+// 8-16 scalar branches per iteration on the wave's dependent chain (a taken one ~35-50 cycles of a latency-bound f64 wave).
+template <int NR, int NL, typename F>
+__device__ __forceinline__ void for_point_counts(F &&row) {
+    static_for<NR>([&](auto kc) { row(std::integral_constant<int, 0>{}, kc); });
+    static_for<NL>([&](auto kc) { row(std::integral_constant<int, 1>{}, kc); });
+}
+#ifndef PLENVEC_THREE_AS_FOUR
+#define PLENVEC_THREE_AS_FOUR 0          /* 1: no copies for three-point feet, they run the four-point copies (16 instead of 25 loops) */
+#endif
+#ifndef PLENVEC_COUNT_SPECIALISED
+#define PLENVEC_COUNT_SPECIALISED 2      /* 0: run-time point tests (rounds 1-3); 1: contact section per point counts, chosen every iteration; 2: the whole iteration loop per point counts, chosen once per substep */
+#endif
+
 static constexpr int NC_ORDER[ND] = {NC_ORDER_LIST};
 #include "plen_motor_pass_gen.h"
 __host__ __device__ constexpr int port_normal(int c) { return 18 + 15 * (c / 4) + 3 + 3 * (c % 4); }
@@ -1554,7 +1569,16 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     const bool has_spin = P.mu_spin > 0, has_roll = P.mu_roll > 0;
     STAMP();
     int it = 0;
+    const int npts = __builtin_amdgcn_readfirstlane(5 * __builtin_popcount(act & 0xfu) + __builtin_popcount((act >> 4) & 0xfu));      // 5 NR + NL: a foot's occupied slots are a prefix
     PLEN_ASSERT_FULL_EXEC();
+    // LSPEC >= 0: this copy of the WHOLE iteration loop is compiled for these point counts (5 NR + NL; 0 = airborne: motor rows only), so that the choice is made
+    // once per substep; LOOP_GENERIC: one loop, the contact section chosen inside every iteration (PLENVEC_COUNT_SPECIALISED 0 / 1)
+    constexpr int LOOP_GENERIC = -1000;
+    auto solve_loop = [&](auto loop_spec_c) {
+    constexpr int LSPEC = decltype(loop_spec_c)::value;
+    // the joint-limit rows (rare: a limit is violated) exist in the generic loop and in the (4, 4) copy only: a substep that needs them runs the (4, 4) copy whatever
+    // its contact set -- the rows of a slot without a point are exact no-ops (bounds (0, 0), mu lambda_n = 0) -- so the other copies carry neither the test nor the code
+    constexpr bool LIM_ROWS = LSPEC == LOOP_GENERIC || LSPEC == 24;
     for (it = 0; it < n_iter; it++) {
         res_i = 0;
         PLEN_ASSERT_FULL_EXEC();
@@ -1567,14 +1591,14 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         if (it & 1) {
             pgs_motor_pass<FAST, false>(e, blo, bhi, dvec, Ar, lane);
             blo -= dvec; bhi -= dvec; exceed |= OVER(dvec); dvec = 0;
-            if (__builtin_expect(lim_mask != 0, 0)) {      // rare: kept out of the hot loop's instruction stream
+            if (LIM_ROWS && __builtin_expect(lim_mask != 0, 0)) {      // rare: kept out of the hot loop's instruction stream
                 static_for<ND>([&](auto ic) {
                     constexpr int PP = NC_ORDER[decltype(ic)::value];
                     if (lim_mask & (1u << PP)) pgs_row_signed<PP>(s.lim, e, diag, Ar[PP], lane, res_i);
                 });
             }
         } else {
-            if (__builtin_expect(lim_mask != 0, 0)) {      // rare: kept out of the hot loop's instruction stream
+            if (LIM_ROWS && __builtin_expect(lim_mask != 0, 0)) {      // rare: kept out of the hot loop's instruction stream
                 static_for<ND>([&](auto ic) {
                     constexpr int PP = NC_ORDER[ND - 1 - decltype(ic)::value];
                     if (lim_mask & (1u << PP)) pgs_row_signed<PP>(s.lim, e, diag, Ar[PP], lane, res_i);
@@ -1584,16 +1608,22 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             blo -= dvec; bhi -= dvec; exceed |= OVER(dvec); dvec = 0;
         }
         ISTAMP(1);
-        if (act) {     // airborne: one branch skips every contact row
+        if (LSPEC == LOOP_GENERIC ? act != 0u : LSPEC > 0) {     // airborne: one branch skips every contact row
             // One copy of the contact section per set of touching feet (right, left, both), chosen here once per iteration: inside a copy
             // no pass has to find out again that a foot is in the air (that was a taken branch per airborne foot in each of the four passes).
-            auto contact_passes = [&](auto feet_c) {
-                constexpr int FEET = decltype(feet_c)::value;
+            // SPEC < 0: run-time point tests inside the copy for the touching feet -SPEC (1 right, 2 left, 3 both); SPEC >= 0: point counts known, SPEC = 5 NR + NL
+            auto contact_passes = [&](auto spec_c) {
+                constexpr int SPEC = decltype(spec_c)::value;
+                constexpr int FEET = SPEC < 0 ? -SPEC : 0, NR = SPEC >= 0 ? SPEC / 5 : 0, NL = SPEC >= 0 ? SPEC % 5 : 0;
+                auto each_point = [&](auto &&row) {
+                    if constexpr (SPEC >= 0) for_point_counts<NR, NL>(row);
+                    else for_foot_points<FEET>(act, row);
+                };
             // Bullet's order is type-major: all normals, all spinning, all rolling, all lateral pairs.  Taken
             // scalar branches cost ~30 cycles each, so inactive points are skipped a whole foot at a time.
             // -- normal rows (manifold order: right foot points, then left foot points) --
             // (points out of range carry blo = bhi = 0 and mu*lambda_n = 0: their rows would be exact no-ops)
-            for_foot_points<FEET>(act, [&](auto fc_, auto kc) {
+            each_point([&](auto fc_, auto kc) {
                 constexpr int PP = port_normal(4 * decltype(fc_)::value + decltype(kc)::value);
                 pgs_row2d<FAST, PP>(e, blo, bhi, dvec, Ar[PP], lane);
             });
@@ -1605,7 +1635,10 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             // three lanes at the same time: lim = fck * (-u_n), nt1 = -(lim + uk), t2 = lim - uk.  Valid
             // because u_n only changes in the normal pass and uk only at its own row.  Bullet skips the row
             // while the normal impulse is not positive: bounds (0, 0) leave e and uk untouched.
-            if (has_spin || has_roll) {
+            // Count-specialised copies run the torsional rows unconditionally: with a zero coefficient their bounds are (+-0, +-0), the row's delta is 0 and e, u are
+            // left untouched -- exactly the rows Bullet does not create (m_combinedSpinningFriction / RollingFriction > 0) -- so the three wave-uniform tests
+            // per iteration are only kept where the rows are skipped for real (the run-time-tested copies).
+            if (SPEC >= 0 || has_spin || has_roll) {
                 // f64: the bounds of a foot's third and fourth point only when some foot has a third point (a foot's points are a prefix; in use a touching foot
                 // has one or two, scripts/gpu_slot_distribution_actor.py): +0.65 % (f32: -0.3 ... -0.7 %, the branch costs more than two gathers: eager there)
                 real nt10, nt11, nt12 = 0, nt13 = 0, t20, t21, t22 = 0, t23 = 0;
@@ -1620,7 +1653,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                     nt10 = fma_(u0, m0, lim0); nt11 = fma_(u1, m1, lim1);
                     t20 = fma_(-u0, m0, lim0); t21 = fma_(-u1, m1, lim1);
                 }
-                if (sizeof(real) == 4 || (act & 0xccu)) {
+                if ((SPEC >= 0 && (NR > 2 || NL > 2)) || (SPEC < 0 && (sizeof(real) == 4 || (act & 0xccu)))) {
                     const real nbv2 = gather_addr(blo, tors_addr + 32), nbv3 = gather_addr(blo, tors_addr + 48);
                     const real lim2 = mul_rn_(fc2, nbv2), lim3 = mul_rn_(fc3, nbv3);
                     const real m2 = nbv2 < 0 ? (real)1 : (real)0, m3 = nbv3 < 0 ? (real)1 : (real)0;
@@ -1629,16 +1662,16 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                 }
                 real dv0 = 0, dv1 = 0, dv2 = 0, dv3 = 0;
                 ISTAMP(3);
-                if (has_spin) {
-                    for_foot_points<FEET>(act, [&](auto fc_, auto kc) {
+                if (SPEC >= 0 || has_spin) {
+                    each_point([&](auto fc_, auto kc) {
                         constexpr int k = decltype(kc)::value, PP = 18 + 15 * decltype(fc_)::value;
                         pgs_rowTd<FAST, PP, k>(e, k == 0 ? nt10 : k == 1 ? nt11 : k == 2 ? nt12 : nt13, k == 0 ? t20 : k == 1 ? t21 : k == 2 ? t22 : t23,
                                             k == 0 ? dv0 : k == 1 ? dv1 : k == 2 ? dv2 : dv3, Ar[PP], lane);
                     });
                 }
                 ISTAMP(4);
-                if (has_roll) {
-                    for_foot_points<FEET>(act, [&](auto fc_, auto kc) {
+                if (SPEC >= 0 || has_roll) {
+                    each_point([&](auto fc_, auto kc) {
                         constexpr int k = decltype(kc)::value, PP = 18 + 15 * decltype(fc_)::value;
                         pgs_rowTd<FAST, PP + 1, k>(e, k == 0 ? nt10 : k == 1 ? nt11 : k == 2 ? nt12 : nt13, k == 0 ? t20 : k == 1 ? t21 : k == 2 ? t22 : t23,
                                                 k == 0 ? dv0 : k == 1 ? dv1 : k == 2 ? dv2 : dv3, Ar[PP + 1], lane);
@@ -1654,7 +1687,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             {
                 // mu * lambda_n of each point: from its normal lane (lane 0 of the point's quad) to the whole quad
                 const real lmv = quad_bcast0(mul_rn_(nfcn, blo));
-                for_foot_points<FEET>(act, [&](auto fc_, auto kc) {
+                each_point([&](auto fc_, auto kc) {
                     constexpr int PN = port_normal(4 * decltype(fc_)::value + decltype(kc)::value);
                     pgs_cone<FAST, PN>(e, u0, dvec, lmv, jdi, Ar[PN + 1], Ar[PN + 2], lane);
                 });
@@ -1664,10 +1697,23 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             exceed |= OVER((dvec + shift_down1(dvec)) * selA);
             u0 += dvec; dvec = 0;
                     };
+#if PLENVEC_COUNT_SPECIALISED
+            // one copy per (points of the right foot, points of the left foot), chosen by a binary search on the scalar unit (<= 5 compares) instead of
+            // 8-16 point tests spread over the four passes
+            if constexpr (LSPEC > 0) contact_passes(std::integral_constant<int, (LSPEC > 0 ? LSPEC : 1)>{});
+            else switch (npts) {
+#define PLEN_CASE(V_) case V_: contact_passes(std::integral_constant<int, V_>{}); break;
+                PLEN_CASE(1) PLEN_CASE(2) PLEN_CASE(3) PLEN_CASE(4) PLEN_CASE(5) PLEN_CASE(6) PLEN_CASE(7) PLEN_CASE(8) PLEN_CASE(9) PLEN_CASE(10) PLEN_CASE(11) PLEN_CASE(12)
+                PLEN_CASE(13) PLEN_CASE(14) PLEN_CASE(15) PLEN_CASE(16) PLEN_CASE(17) PLEN_CASE(18) PLEN_CASE(19) PLEN_CASE(20) PLEN_CASE(21) PLEN_CASE(22) PLEN_CASE(23) PLEN_CASE(24)
+#undef PLEN_CASE
+                default: break;
+            }
+#else
             const unsigned a_ = act;
-            if ((a_ & 0xfu) && (a_ & 0xf0u)) contact_passes(std::integral_constant<int, 3>{});
-            else if (a_ & 0xfu) contact_passes(std::integral_constant<int, 1>{});
-            else contact_passes(std::integral_constant<int, 2>{});
+            if ((a_ & 0xfu) && (a_ & 0xf0u)) contact_passes(std::integral_constant<int, -3>{});
+            else if (a_ & 0xfu) contact_passes(std::integral_constant<int, -1>{});
+            else contact_passes(std::integral_constant<int, -2>{});
+#endif
         }
         ISTAMP(6);
         ISTAMP(7);
@@ -1675,6 +1721,31 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         if ((res_i <= thr_i && exceed == 0) || it >= n_iter - 1) { it++; break; }
 #undef OVER
     }
+    };
+#if PLENVEC_COUNT_SPECIALISED == 2
+    // One copy of the whole loop per (NR, NL) with NR, NL in {0, 1, 2, 4}, chosen ONCE per substep (binary search on the scalar unit).  A foot with three points runs
+    // the four-point copy (its fourth slot's rows are exact no-ops; three-point feet are rare), a substep with a violated joint limit the (4, 4) copy (see LIM_ROWS).
+    // (Sending those to a generic copy with run-time tests instead made the register allocator spill 1 KB per lane to scratch.)
+    {
+        int nr_ = npts / 5, nl_ = npts - 5 * nr_;
+#if PLENVEC_THREE_AS_FOUR
+        nr_ = nr_ == 3 ? 4 : nr_; nl_ = nl_ == 3 ? 4 : nl_;
+#endif
+        const int sel = __builtin_expect(lim_mask != 0, 0) ? 24 : 5 * nr_ + nl_;
+        switch (sel) {
+#define PLEN_CASE(V_) case V_: solve_loop(std::integral_constant<int, V_>{}); break;
+            PLEN_CASE(0) PLEN_CASE(1) PLEN_CASE(2) PLEN_CASE(4) PLEN_CASE(5) PLEN_CASE(6) PLEN_CASE(7) PLEN_CASE(9) PLEN_CASE(10) PLEN_CASE(11) PLEN_CASE(12) PLEN_CASE(14)
+            PLEN_CASE(20) PLEN_CASE(21) PLEN_CASE(22) PLEN_CASE(24)
+#if !PLENVEC_THREE_AS_FOUR
+            PLEN_CASE(3) PLEN_CASE(8) PLEN_CASE(13) PLEN_CASE(15) PLEN_CASE(16) PLEN_CASE(17) PLEN_CASE(18) PLEN_CASE(19) PLEN_CASE(23)
+#endif
+#undef PLEN_CASE
+            default: break;
+        }
+    }
+#else
+    solve_loop(std::integral_constant<int, LOOP_GENERIC>{});
+#endif
     iters = it;
     // issue-slot estimate of this substep (setup + iterations x (motor pass + rows of the active contact points)), for the placement
     // of the env in the NEXT launch (plen_balance_kernel)

@@ -594,3 +594,56 @@ def test_finetuned_walking_policy_still_walks(golden_dir):
     r, l = np.array(res["returns"]), np.array(res["lengths"])
     r0 = np.array(ref["returns"])
     assert r.mean() >= 150 and r.mean() >= r0.mean() + 100 and l.mean() >= 250 and (l >= 500).mean() >= 0.2
+
+
+@pytest.mark.parametrize("nit", [3, 50])
+def test_joint_limit_rows_vs_oracle_f64(nit):
+    """States with joints beyond the +-1.7 rad limits (plen.urdf:1310), moving further out, in every contact situation the collected states offer: the limit
+    rows (btMultiBodyJointLimitConstraint, only while violated) against the oracle after one substep.  Round 4: the solver loop exists once per pair of
+    foot point counts and a substep with a violated limit runs the (4, 4) copy whatever its contact set (rows of empty slots are exact no-ops) -- this is
+    the test of that routing."""
+    n = 48
+    S, T = collect_states(n, seed=9, with_targets=True)
+    rng = np.random.default_rng(2)
+    for i in range(n):
+        for j in rng.choice(18, size=1 + i % 3, replace=False):
+            sgn = rng.choice([-1.0, 1.0])
+            S[i, 13 + j] = sgn * (1.7 + rng.uniform(0.002, 0.03))          # beyond the limit (inside the -0.04 split-impulse threshold)
+            S[i, 31 + j] = sgn * rng.uniform(0.0, 2.0)                       # and still moving outwards
+    env = _env(n, torch.float64, cfg_overrides={"num_iterations": nit, "rolling_friction": 0.0})
+    env.set_state(torch.tensor(S))
+    env.debug_substeps(torch.tensor(T), nsub=1)
+    out = env.get_state().cpu().numpy()
+    worst = 0.0
+    for i in range(n):
+        o = OracleEnv(); o.set_world(num_iterations=nit); o.set_friction(rolling=0.0); o.set_state(S[i]); o.set_targets(T[i]); o.substep()
+        worst = max(worst, np.abs(out[i] - o.get_state()).max())
+    assert worst <= (1e-9 if nit == 3 else 1e-7), worst
+    env.close()
+
+
+def test_every_pair_of_foot_point_counts_vs_oracle_f64():
+    """One substep from states whose feet hold 0..4 contact points each (a flat foot: 4, on an edge: 2, on a corner: 1, three: a slightly tilted flat foot), f64 kernel
+    against the oracle with 3 solver iterations: every specialised copy of the solver loop, including the four-point copy that serves three-point feet."""
+    from oracle.oracle import OracleEnv as OE
+    seen = {}
+    rng = np.random.default_rng(4)
+    S, T = collect_states(600, seed=21, with_targets=True)
+    # classify by the oracle's own collision pass
+    keep_S, keep_T = [], []
+    for i in range(len(S)):
+        o = OE(); o.set_state(S[i]); box, _ = o.contact_slots(run_collide=True)
+        nr, nl = int((box[:4] != -2).sum()), int((box[4:] != -2).sum())
+        if seen.get((nr, nl), 0) < 6:
+            seen[(nr, nl)] = seen.get((nr, nl), 0) + 1; keep_S.append(S[i]); keep_T.append(T[i])
+    assert len(seen) >= 9, sorted(seen)                       # random rollouts visit most pairs; (3, x) included when they occur
+    S, T = np.array(keep_S), np.array(keep_T)
+    n = len(S)
+    env = _env(n, torch.float64, cfg_overrides={"num_iterations": 3})
+    env.set_state(torch.tensor(S))
+    env.debug_substeps(torch.tensor(T), nsub=1)
+    out = env.get_state().cpu().numpy()
+    for i in range(n):
+        o = OE(); o.set_world(num_iterations=3); o.set_state(S[i]); o.set_targets(T[i]); o.substep()
+        assert np.abs(out[i] - o.get_state()).max() <= 1e-9, (i, np.abs(out[i] - o.get_state()).max())
+    env.close()
