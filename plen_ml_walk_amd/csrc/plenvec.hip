@@ -75,6 +75,7 @@ struct DevParams {
     real mu_box;                     // combined lateral friction of a box contact (URDF default 0.5 x plane 0.8)
     int body_contacts;
     int num_iterations, max_episode_steps, joint_act, reward_head;
+    int cost_setup, cost_it0, cost_act, cost_pt;      // issue-slot / latency estimate of a substep for the placement kernel: setup + iterations x (it0 + [any contact] act + points x pt)
 };
 
 __device__ __constant__ int c_parent[NB] = {-1, 0, 1, 2, 3, 4, 5, 0, 7, 8, 9, 10, 11, 0, 13, 14, 0, 16, 17};
@@ -1576,9 +1577,14 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     constexpr int LOOP_GENERIC = -1000;
     auto solve_loop = [&](auto loop_spec_c) {
     constexpr int LSPEC = decltype(loop_spec_c)::value;
-    // the joint-limit rows (rare: a limit is violated) exist in the generic loop and in the (4, 4) copy only: a substep that needs them runs the (4, 4) copy whatever
-    // its contact set -- the rows of a slot without a point are exact no-ops (bounds (0, 0), mu lambda_n = 0) -- so the other copies carry neither the test nor the code
-    constexpr bool LIM_ROWS = LSPEC == LOOP_GENERIC || LSPEC == 24;
+    // The joint-limit rows (rare: a limit is violated) exist in EVERY copy, behind one wave-uniform test per iteration.  Tried and measured (PLENVEC_LIM_ROWS_EVERYWHERE=0):
+    // only in the (4, 4) copy, which then serves every substep with a violated limit whatever its contact set (rows of a slot without a point are exact no-ops) -- 60 % less
+    // code and +1.4 % on random actions, where limits are never violated; but under the walking policy 0.6 % of the env-steps have a violated limit, those waves ran eight
+    // points' rows for their one or two, and a launch lasts as long as its slowest wave: policy leg 9.5 M instead of 11.2 M env-steps/s, f64 walking launch 0.92 instead of 0.82 ms.
+#ifndef PLENVEC_LIM_ROWS_EVERYWHERE
+#define PLENVEC_LIM_ROWS_EVERYWHERE 1
+#endif
+    constexpr bool LIM_ROWS = PLENVEC_LIM_ROWS_EVERYWHERE || LSPEC == LOOP_GENERIC || (PLENVEC_COUNT_SPECIALISED == 2 && LSPEC == 24);
     for (it = 0; it < n_iter; it++) {
         res_i = 0;
         PLEN_ASSERT_FULL_EXEC();
@@ -1731,7 +1737,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
 #if PLENVEC_THREE_AS_FOUR
         nr_ = nr_ == 3 ? 4 : nr_; nl_ = nl_ == 3 ? 4 : nl_;
 #endif
-        const int sel = __builtin_expect(lim_mask != 0, 0) ? 24 : 5 * nr_ + nl_;
+        const int sel = (!PLENVEC_LIM_ROWS_EVERYWHERE && __builtin_expect(lim_mask != 0, 0)) ? 24 : 5 * nr_ + nl_;
         switch (sel) {
 #define PLEN_CASE(V_) case V_: solve_loop(std::integral_constant<int, V_>{}); break;
             PLEN_CASE(0) PLEN_CASE(1) PLEN_CASE(2) PLEN_CASE(4) PLEN_CASE(5) PLEN_CASE(6) PLEN_CASE(7) PLEN_CASE(9) PLEN_CASE(10) PLEN_CASE(11) PLEN_CASE(12) PLEN_CASE(14)
@@ -1743,13 +1749,25 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             default: break;
         }
     }
+#elif PLENVEC_COUNT_SPECIALISED == 3
+    // Hybrid: the whole loop once for each of the few point-count pairs that dominate (airborne, one foot with one or two points); every other substep -- and any with a
+    // violated joint limit -- runs the loop that picks its contact section inside the iteration.  Mode 2's 25 loop copies each carry their own motor passes: with the
+    // contact sets of WALKING robots (bench.py's policy / td3 legs) more copies are in flight than the 64 KB instruction cache of a CU pair holds beside phases A-F
+    // (f32 policy leg: 10.0 M run-time tests, 10.6 M mode 1, 9.5 M mode 2); here the motor passes exist six times, not 25.
+    if (__builtin_expect(lim_mask != 0, 0)) solve_loop(std::integral_constant<int, LOOP_GENERIC>{});
+    else switch (npts) {
+#define PLEN_CASE(V_) case V_: solve_loop(std::integral_constant<int, V_>{}); break;
+        PLEN_CASE(0) PLEN_CASE(1) PLEN_CASE(2) PLEN_CASE(5) PLEN_CASE(10)
+#undef PLEN_CASE
+        default: solve_loop(std::integral_constant<int, LOOP_GENERIC>{}); break;
+    }
 #else
     solve_loop(std::integral_constant<int, LOOP_GENERIC>{});
 #endif
     iters = it;
     // issue-slot estimate of this substep (setup + iterations x (motor pass + rows of the active contact points)), for the placement
     // of the env in the NEXT launch (plen_balance_kernel)
-    load += 4100 + it * (78 + 37 * __builtin_popcount(act) + (act ? 50 : 0));
+    load += P.cost_setup + it * (P.cost_it0 + P.cost_pt * __builtin_popcount(act) + (act ? P.cost_act : 0));
     // back to impulses: joint lanes u = -(mh + blo) (+ the limit row), normal lanes u = -blo, the rest explicit
     real lam_sum;
     if (is_joint) lam_sum = (-(P.max_imp * diag) - blo + s.lim[2][p] * s.lim[3][p]) * jdi;
@@ -2300,6 +2318,12 @@ static void fill_params(const PlenCfg &c, const PlenModel &m, DevParams<real> &p
     }
     p.mu_box = (real)c.box_lateral_friction; p.body_contacts = c.body_contacts;
     p.num_iterations = c.num_iterations; p.max_episode_steps = c.max_episode_steps; p.joint_act = c.joint_act; p.reward_head = c.reward_head;
+    // Cost model of a substep for plen_balance_kernel, in units of ~1/78 of an airborne solver iteration (fitted in round 1).  Round 4 re-measured it per contact
+    // configuration for the count-specialised loops (scripts/gpu_walk_stamps.py: airborne f64 iteration 1335 cycles, first contact point + 1150, further points + ~450
+    // each, 82 k cycles per substep outside the solver) and swept the weights on random and walking workloads (scripts/gpu_ab_cost.py, gpu_ab_walk.py): every setting
+    // within +-0.3 %, so the weights stay.  (What DID cost a walking launch 7 % was not the placement: see LIM_ROWS in the solver.)  PLENVEC_COST="setup,it0,act,pt" overrides.
+    p.cost_setup = 4100; p.cost_it0 = 78; p.cost_act = 50; p.cost_pt = 37;
+    if (const char *e = getenv("PLENVEC_COST")) { int a, b, cc, d; if (sscanf(e, "%d,%d,%d,%d", &a, &b, &cc, &d) == 4) { p.cost_setup = a; p.cost_it0 = b; p.cost_act = cc; p.cost_pt = d; } }
 }
 
 template <typename real>
