@@ -6,7 +6,7 @@ compared block by block with tests/golden/ref_training_log_summary.npz (the refe
 
 n envs step together and n updates follow (same update-to-data ratio, same batch; the reference interleaves them one by one).
 usage: python scripts/gpu_reference_recipe.py [max_env_steps] [wall_budget_s] [n_envs] [f32|f64] [seed]
-writes gpurun_out/r03_reference_recipe_curve[_seed<k>_n<envs>].json"""
+writes gpurun_out/r04_reference_recipe_curve[_seed<k>_n<envs>].json"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -31,7 +31,7 @@ returns, lengths, at_step = [], [], []
 evals = []
 t0 = time.time()
 next_eval = 0
-out_path = os.path.join(ROOT, "gpurun_out", "r03_reference_recipe_curve.json" if (seed == 0 and n == 16) else "r03_reference_recipe_curve_seed%d_n%d.json" % (seed, n))
+out_path = os.path.join(ROOT, "gpurun_out", "r04_reference_recipe_curve.json" if (seed == 0 and n == 16) else "r04_reference_recipe_curve_seed%d_n%d.json" % (seed, n))
 os.makedirs(os.path.dirname(out_path), exist_ok=True)
 ref = np.load(os.path.join(ROOT, "tests", "golden", "ref_training_log_summary.npz"))
 
