@@ -496,7 +496,10 @@ __device__ __forceinline__ void pgs_row2d(real &e, const real blo, const real bh
 template <bool FAST, bool REV, typename real>
 __device__ __forceinline__ void pgs_motor_pass(real &e, const real blo, const real bhi, real &dvec, const real (&Ar)[NPORT], const int lane) {
     static_assert(PLEN_MOTOR_PASS_ORDER_CHECK(NC_ORDER), "plen_motor_pass_gen.h is stale: run tools/gen_motor_pass.py");
-    if constexpr (FAST && sizeof(real) == 4) {
+#ifndef PLENVEC_F32_MOTOR_EXEC
+#define PLENVEC_F32_MOTOR_EXEC 0       /* experiment: 1 = the f32 motor rows in the EXEC-masked form of the contact rows (3 vector + 2 scalar instructions per row) instead of the pipelined v_writelane block (4 vector) */
+#endif
+    if constexpr (FAST && sizeof(real) == 4 && !PLENVEC_F32_MOTOR_EXEC) {
         float d;
         int sA, sB;
         if constexpr (!REV) asm volatile(PLEN_MOTOR_F32_FWD : [d] "=&v"(d), [sA] "=&s"(sA), [sB] "=&s"(sB), [dv] "+v"(dvec), [e] "+v"(e) : [blo] "v"(blo), [bhi] "v"(bhi), PLEN_MOTOR_A_OPERANDS(Ar));
@@ -1584,7 +1587,10 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
 #ifndef PLENVEC_LIM_ROWS_EVERYWHERE
 #define PLENVEC_LIM_ROWS_EVERYWHERE 1
 #endif
-    constexpr bool LIM_ROWS = PLENVEC_LIM_ROWS_EVERYWHERE || LSPEC == LOOP_GENERIC || (PLENVEC_COUNT_SPECIALISED == 2 && LSPEC == 24);
+#ifndef PLENVEC_LIM_FLAVOURS
+#define PLENVEC_LIM_FLAVOURS 0          /* experiment: 1 = every hoisted copy exists with and without the joint-limit rows (50 loops), chosen once per substep */
+#endif
+    constexpr bool LIM_ROWS = PLENVEC_LIM_FLAVOURS ? (LSPEC == LOOP_GENERIC || LSPEC >= 100) : (PLENVEC_LIM_ROWS_EVERYWHERE || LSPEC == LOOP_GENERIC || (PLENVEC_COUNT_SPECIALISED == 2 && LSPEC == 24));
     for (it = 0; it < n_iter; it++) {
         res_i = 0;
         PLEN_ASSERT_FULL_EXEC();
@@ -1614,7 +1620,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             blo -= dvec; bhi -= dvec; exceed |= OVER(dvec); dvec = 0;
         }
         ISTAMP(1);
-        if (LSPEC == LOOP_GENERIC ? act != 0u : LSPEC > 0) {     // airborne: one branch skips every contact row
+        if (LSPEC == LOOP_GENERIC ? act != 0u : (LSPEC % 100) > 0) {     // airborne: one branch skips every contact row
             // One copy of the contact section per set of touching feet (right, left, both), chosen here once per iteration: inside a copy
             // no pass has to find out again that a foot is in the air (that was a taken branch per airborne foot in each of the four passes).
             // SPEC < 0: run-time point tests inside the copy for the touching feet -SPEC (1 right, 2 left, 3 both); SPEC >= 0: point counts known, SPEC = 5 NR + NL
@@ -1706,7 +1712,8 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
 #if PLENVEC_COUNT_SPECIALISED
             // one copy per (points of the right foot, points of the left foot), chosen by a binary search on the scalar unit (<= 5 compares) instead of
             // 8-16 point tests spread over the four passes
-            if constexpr (LSPEC > 0) contact_passes(std::integral_constant<int, (LSPEC > 0 ? LSPEC : 1)>{});
+            if constexpr (LSPEC > 0 && (LSPEC % 100) > 0) contact_passes(std::integral_constant<int, ((LSPEC % 100) > 0 ? LSPEC % 100 : 1)>{});
+            else if constexpr (LSPEC > 0) { }
             else switch (npts) {
 #define PLEN_CASE(V_) case V_: contact_passes(std::integral_constant<int, V_>{}); break;
                 PLEN_CASE(1) PLEN_CASE(2) PLEN_CASE(3) PLEN_CASE(4) PLEN_CASE(5) PLEN_CASE(6) PLEN_CASE(7) PLEN_CASE(8) PLEN_CASE(9) PLEN_CASE(10) PLEN_CASE(11) PLEN_CASE(12)
@@ -1737,9 +1744,17 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
 #if PLENVEC_THREE_AS_FOUR
         nr_ = nr_ == 3 ? 4 : nr_; nl_ = nl_ == 3 ? 4 : nl_;
 #endif
+#if PLENVEC_LIM_FLAVOURS
+        const int sel = 5 * nr_ + nl_ + (__builtin_expect(lim_mask != 0, 0) ? 100 : 0);
+#else
         const int sel = (!PLENVEC_LIM_ROWS_EVERYWHERE && __builtin_expect(lim_mask != 0, 0)) ? 24 : 5 * nr_ + nl_;
+#endif
         switch (sel) {
+#if PLENVEC_LIM_FLAVOURS
+#define PLEN_CASE(V_) case V_: solve_loop(std::integral_constant<int, V_>{}); break; case 100 + V_: solve_loop(std::integral_constant<int, 100 + V_>{}); break;
+#else
 #define PLEN_CASE(V_) case V_: solve_loop(std::integral_constant<int, V_>{}); break;
+#endif
             PLEN_CASE(0) PLEN_CASE(1) PLEN_CASE(2) PLEN_CASE(4) PLEN_CASE(5) PLEN_CASE(6) PLEN_CASE(7) PLEN_CASE(9) PLEN_CASE(10) PLEN_CASE(11) PLEN_CASE(12) PLEN_CASE(14)
             PLEN_CASE(20) PLEN_CASE(21) PLEN_CASE(22) PLEN_CASE(24)
 #if !PLENVEC_THREE_AS_FOUR

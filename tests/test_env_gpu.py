@@ -336,6 +336,33 @@ def test_asm_path_bitwise_equals_compiler_path(tmp_path, dt):
     assert np.array_equal(outs[0], outs[1], equal_nan=True)
 
 
+@pytest.mark.parametrize("dt", ["float32", "float64"])
+def test_count_specialised_solver_loops_bitwise_equal_the_run_time_tested_loop(tmp_path, dt):
+    """Round 4: the solver's iteration loop is compiled once per pair of foot point counts and chosen once per substep.  That changes which code runs, not one
+    operation or its order: against a build with rounds 1-3's run-time point tests (-DPLENVEC_COUNT_SPECIALISED=0, csrc/variants/nospec.so, built by
+    __graft_entry__.build()) 40 steps x 512 envs -- random actions with amplitude 1.7 in joint_act mode for half of them, so that joint limits are violated
+    and every contact configuration from airborne to both feet planted occurs -- agree bit for bit, including states and auto-resets."""
+    from plen_ml_walk_amd.build import build_variant
+    lib0 = build_variant("nospec", ["-DPLENVEC_COUNT_SPECIALISED=0"])
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+            "from plen_ml_walk_amd.vec_env import PlenVecEnv\n"
+            "out, st = [], []\n"
+            "for ja, amp in ((False, 1.0), (True, 1.7)):\n"
+            "    g = torch.Generator().manual_seed(5); acts = ((torch.rand(40, 512, 18, generator=g) * 2 - 1) * amp).float().cuda()\n"
+            "    env = PlenVecEnv(512, dtype=torch.%s, joint_act=ja); env.reset()\n"
+            "    for t in range(40):\n"
+            "        o, r, d, _ = env.step(acts[t]); out.append(torch.cat([o, r[:, None], d.to(o.dtype)[:, None]], 1).cpu().numpy().copy())\n"
+            "    st.append(env.get_state().cpu().numpy()); env.close()\n"
+            "np.save(sys.argv[1], np.array(out)); np.save(sys.argv[1] + '.state.npy', np.array(st))\n" % (ROOT, dt))
+    outs = []
+    for tag, extra in (("spec", {}), ("nospec", {"PLENVEC_LIB": lib0})):
+        p = str(tmp_path / (tag + ".npy"))
+        subprocess.run([sys.executable, "-c", code, p], check=True, timeout=600, env=dict(os.environ, **extra))
+        outs.append((np.load(p), np.load(p + ".state.npy")))
+    assert outs[0][0].shape == outs[1][0].shape and np.array_equal(outs[0][0], outs[1][0], equal_nan=True) and np.array_equal(outs[0][1], outs[1][1], equal_nan=True)
+    assert (outs[0][0][:40, :, 27] != 0).sum() > 100                 # episodes ended and restarted inside the window
+
+
 @pytest.mark.parametrize("nenv", [2048, 1500, 3000])       # full slots, ragged odd last slot, ragged even last slot
 def test_simd_load_balancing_does_not_change_results(tmp_path, nenv):
     """plen_balance_kernel only decides WHICH block (hence SIMD) runs an env; 2048 envs x 25 steps must be bit-identical with
