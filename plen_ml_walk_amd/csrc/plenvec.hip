@@ -1580,7 +1580,8 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     constexpr int LOOP_GENERIC = -1000;
     auto solve_loop = [&](auto loop_spec_c) {
     constexpr int LSPEC = decltype(loop_spec_c)::value;
-    // The joint-limit rows (rare: a limit is violated) exist in EVERY copy, behind one wave-uniform test per iteration.  Tried and measured (PLENVEC_LIM_ROWS_EVERYWHERE=0):
+    // The joint-limit rows (rare: a limit is violated) exist in a second flavour of EVERY copy (LSPEC + 100), chosen with the copy once per substep (PLENVEC_LIM_FLAVOURS;
+    // with 0 they sit in every copy behind one wave-uniform test per iteration).  Tried and measured before that (PLENVEC_LIM_ROWS_EVERYWHERE=0):
     // only in the (4, 4) copy, which then serves every substep with a violated limit whatever its contact set (rows of a slot without a point are exact no-ops) -- 60 % less
     // code and +1.4 % on random actions, where limits are never violated; but under the walking policy 0.6 % of the env-steps have a violated limit, those waves ran eight
     // points' rows for their one or two, and a launch lasts as long as its slowest wave: policy leg 9.5 M instead of 11.2 M env-steps/s, f64 walking launch 0.92 instead of 0.82 ms.
@@ -1588,7 +1589,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
 #define PLENVEC_LIM_ROWS_EVERYWHERE 1
 #endif
 #ifndef PLENVEC_LIM_FLAVOURS
-#define PLENVEC_LIM_FLAVOURS 0          /* experiment: 1 = every hoisted copy exists with and without the joint-limit rows (50 loops), chosen once per substep */
+#define PLENVEC_LIM_FLAVOURS 1          /* 1 (shipped): every hoisted copy exists with and without the joint-limit rows (50 loops), chosen once per substep: no limit test inside an iteration (f64 +1.3 %, f32 +2.5 %, policy leg +2.2 % over 0 = the rows in every copy behind a per-iteration test) */
 #endif
     constexpr bool LIM_ROWS = PLENVEC_LIM_FLAVOURS ? (LSPEC == LOOP_GENERIC || LSPEC >= 100) : (PLENVEC_LIM_ROWS_EVERYWHERE || LSPEC == LOOP_GENERIC || (PLENVEC_COUNT_SPECIALISED == 2 && LSPEC == 24));
     for (it = 0; it < n_iter; it++) {
