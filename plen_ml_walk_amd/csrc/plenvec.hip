@@ -1592,7 +1592,12 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
 #define PLENVEC_LIM_FLAVOURS 1          /* 1 (shipped): every hoisted copy exists with and without the joint-limit rows (50 loops), chosen once per substep: no limit test inside an iteration (f64 +1.3 %, f32 +2.5 %, policy leg +2.2 % over 0 = the rows in every copy behind a per-iteration test) */
 #endif
     constexpr bool LIM_ROWS = PLENVEC_LIM_FLAVOURS ? (LSPEC == LOOP_GENERIC || LSPEC >= 100) : (PLENVEC_LIM_ROWS_EVERYWHERE || LSPEC == LOOP_GENERIC || (PLENVEC_COUNT_SPECIALISED == 2 && LSPEC == 24));
-    for (it = 0; it < n_iter; it++) {
+#ifndef PLENVEC_UNROLL_PARITY
+#define PLENVEC_UNROLL_PARITY 0          /* measured and left off: 1 = the loop body once per iteration parity (even: reversed non-contact rows, odd: sorted order), no parity test: +0.8 % (f64 and f32) for +400 KB of code */
+#endif
+    // one solver iteration; ODD: compile-time parity (PLENVEC_UNROLL_PARITY) or -1 = tested at run time.  Returns Bullet's exit condition; advances `it`.
+    auto iteration = [&](auto odd_c) -> bool {
+        constexpr int ODD = decltype(odd_c)::value;
         res_i = 0;
         PLEN_ASSERT_FULL_EXEC();
         ISTAMP(0);
@@ -1601,7 +1606,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         unsigned long long exceed = 0;
 #define OVER(x_) __ballot((float)abs_(x_) > thr_f)
         // -- non-contact rows: sorted order (motors, then limits) on odd iterations, reversed on even ones --
-        if (it & 1) {
+        if (ODD < 0 ? (it & 1) != 0 : ODD == 1) {
             pgs_motor_pass<FAST, false>(e, blo, bhi, dvec, Ar, lane);
             blo -= dvec; bhi -= dvec; exceed |= OVER(dvec); dvec = 0;
             if (LIM_ROWS && __builtin_expect(lim_mask != 0, 0)) {      // rare: kept out of the hot loop's instruction stream
@@ -1732,9 +1737,16 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         ISTAMP(6);
         ISTAMP(7);
         // (the rare scalar rows, joint limits, keep their max in res_i)
-        if ((res_i <= thr_i && exceed == 0) || it >= n_iter - 1) { it++; break; }
+        const bool stop = (res_i <= thr_i && exceed == 0) || it >= n_iter - 1;
+        it++;
+        return stop;
 #undef OVER
-    }
+    };
+#if PLENVEC_UNROLL_PARITY
+    for (it = 0;;) { if (iteration(std::integral_constant<int, 0>{})) break; if (iteration(std::integral_constant<int, 1>{})) break; }
+#else
+    for (it = 0;;) { if (iteration(std::integral_constant<int, -1>{})) break; }
+#endif
     };
 #if PLENVEC_COUNT_SPECIALISED == 2
     // One copy of the whole loop per (NR, NL) with NR, NL in {0, 1, 2, 4}, chosen ONCE per substep (binary search on the scalar unit).  A foot with three points runs
