@@ -1049,6 +1049,11 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
 #else
 #define ISTAMP(k_) do { } while (0)
 #endif
+#ifdef PGS_STAMPS      // profiling build only: finer stamps inside phases E and F (scripts/gpu_phase_e_stamps.py)
+#define ESTAMP(k_) do { if (dump) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); if (lane == 0) dump[3850 + (k_)] = (real)(double)(t_ - stamp_t0); } } while (0)
+#else
+#define ESTAMP(k_) do { } while (0)
+#endif
 #define STAMP() do { if (dump) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); if (stamp_i == 0) stamp_t0 = t_; if (lane == 0) dump[3800 + stamp_i] = (real)(double)(t_ - stamp_t0); stamp_i++; } } while (0)
     STAMP();
     // ---------------- A. kinematics, inertias, bias ----------------
@@ -1190,6 +1195,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
 
     STAMP();
     FRESH_LANE();
+    ESTAMP(0);
     // ---------------- E. collision (feet vs ground) and port Jacobians ----------------
     // port p: 0..17 joint d | 18+15f+{0,1,2} foot f torsional (n, dir1, dir2) | 18+15f+3+3k+{0,1,2} point k linear; lanes: lane_of_port()
     // (not const: re-derived from the fresh lane id after phase F, so that none of them lives through it)
@@ -1260,6 +1266,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         wpack0 = wp[0]; wpack1 = wp[1];
     }
     LANE_ROLES();
+    ESTAMP(1);          // foot manifolds selected
     const int fb = pf == 0 ? GEN_RFOOT_BODY : GEN_LFOOT_BODY;
     real dist = 0;
     real Pw[3] = {0, 0, 0};
@@ -1295,6 +1302,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         }
     }
     // act: occupied-slot mask in manifold order (right foot points 0..3, left foot 4..7), so far the foot points
+    ESTAMP(2);          // foot port Jacobians written
     rc = (act & 0x0fu) != 0; lc = (act & 0xf0u) != 0;        // getContactPoints(robot, plane, link 11 | 19): foot points only
     // per-lane contact parameters of this lane's slot (foot point: the reference's foot values; a lent slot gets its box's below)
     real rest_l = P.restitution, mu_l = mu_lat;
@@ -1327,6 +1335,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             act |= released;
         }
     }
+    ESTAMP(3);          // box near test (+ rare path)
     lent_out = lent | (act << 8);          // bits 0-7: slots lent to box corners, bits 8-15: slots holding a contact point
     WSYNC();
     // own Jacobian row into registers, b = J v*, then Y = L^-T J^T by back substitution (A = J M^-1 J^T = Y^T Y)
@@ -1341,10 +1350,12 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
 #pragma unroll
         for (int j = 0; j < NV; j++) Jr[j] = is_joint ? (j == 6 + p ? (real)1 : (real)0) : s.YT[j][p];
     }
+    ESTAMP(4);          // Jacobian rows into registers
     real bvel = 0;
 #pragma unroll
     for (int j = 0; j < NV; j++) bvel += Jr[j] * s.v[j];
     // (the inverse diagonal of L is in s.col since phase C)
+    ESTAMP(5);          // port velocities
     // L^T y = J^T, descending; only the supported entries of L.
     if constexpr (sizeof(real) == 8) {
         // f64: the coefficients (row I of L^T, wave-uniform LDS reads) do not depend on the chain through Jr: row I - 1's are requested in the source
@@ -1386,6 +1397,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
 #pragma unroll
         for (int j = 0; j < NV; j++) s.YT[j][p] = Jr[j];
     }
+    ESTAMP(6);          // back substitution + Y stored
     s.park[0][lane] = bvel; s.park[1][lane] = dist;      // needed again in phase G; phase F needs every register
     s.park[2][lane] = rest_l; s.park[3][lane] = mu_l;
     WSYNC();
@@ -1862,6 +1874,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     WSYNC();    STAMP();
 #undef STAMP
 #undef ISTAMP
+#undef ESTAMP
 #undef FRESH_LANE
 }
 
