@@ -1270,9 +1270,15 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     const int fb = pf == 0 ? GEN_RFOOT_BODY : GEN_LFOOT_BODY;
     real dist = 0;
     real Pw[3] = {0, 0, 0};
-    if (is_tors || is_lin) {
+    // every port's Jacobian column is WRITTEN here -- a joint port's is the unit vector e_(6 + p) -- so that all lanes can load their row below with 24 plain LDS reads:
+    // round 3 selected `is_joint ? constant : load`, and the compiler sank each load into its branch of the select: 24 exec-masked loads, each waiting for its own
+    // latency (2.1 k of phase E's 17.5 k cycles in f64, scripts/gpu_phase_e_stamps.py)
+    if (valid_port) {
 #pragma unroll
         for (int j = 0; j < NV; j++) s.YT[j][p] = 0;
+    }
+    if (is_joint) s.YT[6 + p][p] = 1;
+    if (is_tors || is_lin) {
         real ax[3] = {pax == 2 ? (real)1 : (real)0, pax == 1 ? (real)-1 : (real)0, pax == 0 ? (real)1 : (real)0};
         if (is_lin) {
             const unsigned wv = ((pf ? wpack1 : wpack0) >> (8 * pk)) & 31u;          // the sole vertex this slot's foot point sits on
@@ -1340,16 +1346,8 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     WSYNC();
     // own Jacobian row into registers, b = J v*, then Y = L^-T J^T by back substitution (A = J M^-1 J^T = Y^T Y)
     real Jr[NV];
-    if constexpr (sizeof(real) == 8) {
 #pragma unroll
-        for (int j = 0; j < NV; j++) {
-            const real y = s.YT[j][p];     // meant to be read by every lane (a joint lane's p < 18 is a valid column); the compiler sinks the load back into a branch of
-            Jr[j] = is_joint ? (j == 6 + p ? (real)1 : (real)0) : y;      // the select, and pinning it (pin_order) serialises the 24 loads through one register pair: -0.2 %
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < NV; j++) Jr[j] = is_joint ? (j == 6 + p ? (real)1 : (real)0) : s.YT[j][p];
-    }
+    for (int j = 0; j < NV; j++) Jr[j] = s.YT[j][p];       // (lanes that host no port read column 0: their results are never stored)
     ESTAMP(4);          // Jacobian rows into registers
     real bvel = 0;
 #pragma unroll
