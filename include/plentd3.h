@@ -106,6 +106,20 @@ typedef struct PlenTd3PolicyRows {
 } PlenTd3PolicyRows;
 int plentd3_policy_rows(const PlenTd3PolicyRows *args, void *stream);
 
+/* The same two passes for SMALL batches (the reference's recipe: batch 100, one update per env-step -- plen_td3.py:28, :119-120 -- where the latency
+ * of one update is what counts): 16 batch rows per 512-thread workgroup whose 8 waves split every layer's output columns (csrc/td3_team.hip).
+ * Arguments, outputs and arithmetic as plentd3_critic_rows / plentd3_policy_rows (the critics' scalar heads sum in a different order), except that
+ * loss[0] is STORED (per-workgroup partials summed in order by the last workgroup to finish), not added to: no zeroing, same bits every run. */
+int plentd3_critic_team(const PlenTd3CriticRows *args, void *stream);
+int plentd3_policy_team(const PlenTd3PolicyRows *args, void *stream);
+
+/* Up to PLENTD3_WGRAD_JOBS weight gradients (each as plentd3_wgrad: dW[n][k] += sum_b dH[b][n] X[b][k], db[n] += sum_b dH[b][n] when db != NULL) over the
+ * same B batch rows in one launch, the whole batch as a single reduction chunk (small batches).  tile0 is filled in by the call. */
+#define PLENTD3_WGRAD_JOBS 6
+typedef struct PlenTd3WgradJob { const float *dH; const float *X; float *dW; float *db; int ds, xs, dws, N, K, tile0; } PlenTd3WgradJob;
+typedef struct PlenTd3WgradGroup { PlenTd3WgradJob job[PLENTD3_WGRAD_JOBS]; int n_jobs, B; } PlenTd3WgradGroup;
+int plentd3_wgrad_group(const PlenTd3WgradGroup *group, void *stream);
+
 /* plen_td3.py:101-104 for a whole vector step as one launch: action [B][18] = clamp(actor(state [B][26]) + N(0, sigma), +-max_a), the noise drawn as
  * plentd3_explore draws it (rng, bumped by the plentd3_store that follows); p1, p2 [B][256] are scratch. */
 typedef struct PlenTd3ActorRows {

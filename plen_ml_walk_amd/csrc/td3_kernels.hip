@@ -9,6 +9,7 @@
 // Layout conventions: activations are row-major [B][n]; a "strided" operand has an explicit row stride (it is a column slice of a wider
 // row-major matrix, e.g. the action columns 26..43 of a [B][44] state-action matrix, or one column of the packed replay rows).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdlib>
 #include <stdint.h>
 #include "../../include/plentd3.h"
@@ -223,18 +224,16 @@ __global__ void k_polyak(float *__restrict__ t, const float *__restrict__ p, flo
 //      the caller) with float atomics.  Waves of the first column tile also sum their dH operand: the bias gradient comes for free.
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_wgrad(const float *__restrict__ dH, int ds, const float *__restrict__ X, int xs, float *__restrict__ dW, int dws,
-                                               float *__restrict__ db, int B, int N, int K, int rows_per_chunk) {
+static __device__ __forceinline__ void wgrad_tile(const float *__restrict__ dH, int ds, const float *__restrict__ X, int xs, float *__restrict__ dW, int dws,
+                                                  float *__restrict__ db, int N, int K, int tile, int b0, int b1) {
     // workgroup = one (32 x 32 output tile, batch chunk).  NW = 4: its waves take every 4th pair of batch rows and are summed through LDS, so that a
     // tile costs one set of 1024 atomics per chunk instead of four.  NW = 1: one wave, no LDS -- a workgroup that starts in any single free wave
     // slot (the update beside resident env launches, td3_rows.hip), at the price of shorter chunks' worth of atomics.
     __shared__ float red[NW > 1 ? NW - 1 : 1][NW > 1 ? 64 : 1][NW > 1 ? 17 : 1];
     __shared__ float bred[NW > 1 ? NW - 1 : 1][NW > 1 ? 32 : 1];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int nt = (N + 31) / 32, kt = (K + 31) / 32;
-    const int tile = blockIdx.x % (nt * kt), chunk = blockIdx.x / (nt * kt);
+    const int kt = (K + 31) / 32;
     const int n0 = (tile / kt) * 32, k0 = (tile % kt) * 32;
-    const int b0 = chunk * rows_per_chunk, b1 = min(B, b0 + rows_per_chunk);
     const int col = lane & 31, half = lane >> 5;
     const bool na = n0 + col < N, ka = k0 + col < K;
     floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -286,6 +285,27 @@ __global__ __launch_bounds__(64 * NW) void k_wgrad(const float *__restrict__ dH,
         }
         if (db && k0 == 0 && half == 0 && na) atomicAdd(db + n0 + col, bsum);
     }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_wgrad(const float *__restrict__ dH, int ds, const float *__restrict__ X, int xs, float *__restrict__ dW, int dws,
+                                               float *__restrict__ db, int B, int N, int K, int rows_per_chunk) {
+    const int tiles = ((N + 31) / 32) * ((K + 31) / 32);
+    const int tile = blockIdx.x % tiles, chunk = blockIdx.x / tiles;
+    const int b0 = chunk * rows_per_chunk;
+    wgrad_tile<NW>(dH, ds, X, xs, dW, dws, db, N, K, tile, b0, min(B, b0 + rows_per_chunk));
+}
+
+// ---- K15b: every weight gradient of one backward pass in ONE launch (small batches: the reduction over the batch is a single chunk, so each output
+//      tile is written by exactly one workgroup -- the atomics into the zeroed bucket are plain stores in effect, and the result is deterministic).
+//      At batch 100 the five launches of a critic update (two head rows, two second layers, the stacked first layers) are 5 x 5 us of launch latency
+//      for < 1 us of work each; grouped they are one.  job[j] owns workgroups [tile0[j], tile0[j + 1]).
+__global__ __launch_bounds__(256) void k_wgrad_group(PlenTd3WgradGroup G) {
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < PLENTD3_WGRAD_JOBS; k++) j += (k < G.n_jobs && (int)blockIdx.x >= G.job[k].tile0) ? 1 : 0;
+    const PlenTd3WgradJob &J = G.job[j];
+    wgrad_tile<4>(J.dH, J.ds, J.X, J.xs, J.dW, J.dws, J.db, J.N, J.K, (int)blockIdx.x - J.tile0, 0, G.B);
 }
 
 // ---- K12: replay sampling without a host round trip (td3.py:175 np.random.randint(0, len, B)): u uniform in [0, 1) -> a row of the ring that
@@ -357,30 +377,46 @@ __global__ void k_store(float *__restrict__ data, const int64_t *__restrict__ to
 //      the target network (td3.py:348-356) and a copy of the new parameters (the pipelined trainer's behaviour actor).  torch's fused Adam is two
 //      multi-tensor launches of 41 + 5 us for these 12 tensors; this is one pass of single-wave workgroups.
 //      step = float32 device scalar (torch's capturable `step`): read by every workgroup, advanced by the last one to finish.
-__global__ __launch_bounds__(64) void k_adam(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, float *step, int *done_count, int n,
-                                             double lr, double b1d, double b2d, float eps, int zero_grad, float *__restrict__ target, float tau, float *__restrict__ copy_out) {
+__global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, float *step, int *done_count, int n,
+                                              double lr, double b1d, double b2d, float eps, int zero_grad, float *__restrict__ target, float tau, float *__restrict__ copy_out) {
     // the hyper-parameters arrive as the doubles torch holds them in and are rounded where torch's kernel rounds them: 1 - beta2 = 0.001 computed
     // in float would be off by 5e-5 relative, and so would the second moment
+    // (at most 256 workgroups of 256 lanes, 4 consecutive floats per lane and trip: the done_count atomics of 600 single-wave workgroups, all on one
+    // address, were most of this kernel's 20 us on the critic's 154 k parameters)
     const float t = step[0] + 1.f;
     const double bc1 = 1.0 - pow(b1d, (double)t), bc2 = 1.0 - pow(b2d, (double)t);
     const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
     const float b2 = (float)b2d, w1 = (float)(1.0 - b1d), w2 = (float)(1.0 - b2d);
-    const int i0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    auto one = [&](float gi, float &mi, float &vi, float &pi) {
+        mi = mi + (gi - mi) * w1;
+        vi = vi * b2 + w2 * gi * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi = pi - step_size * mi / denom;
+    };
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    for (int i0 = (blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += gridDim.x * 1024) {
+        if (i0 + 3 < n) {                       // four consecutive floats as one 16-byte access per array (the flat buffers are 16-byte aligned)
+            const f4 g4 = *reinterpret_cast<const f4 *>(g + i0);
+            f4 m4 = *reinterpret_cast<const f4 *>(m + i0), v4 = *reinterpret_cast<const f4 *>(v + i0), p4 = *reinterpret_cast<const f4 *>(p + i0), t4 = {0, 0, 0, 0};
+            if (target) t4 = *reinterpret_cast<const f4 *>(target + i0);
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int i = i0 + j;
-        if (i < n) {
-            const float gi = g[i];
-            const float mi = m[i] + (gi - m[i]) * w1;
-            const float vi = v[i] * b2 + w2 * gi * gi;
-            const float denom = sqrtf(vi) / bc2_sqrt + eps;
-            const float pi = p[i] - step_size * mi / denom;
-            m[i] = mi; v[i] = vi; p[i] = pi;
-            if (zero_grad) g[i] = 0.f;
-            if (target) target[i] = tau * pi + (1.f - tau) * target[i];
-            if (copy_out) copy_out[i] = pi;
+            for (int j = 0; j < 4; j++) { float mi = m4[j], vi = v4[j], pi = p4[j]; one(g4[j], mi, vi, pi); m4[j] = mi; v4[j] = vi; p4[j] = pi; t4[j] = tau * pi + (1.f - tau) * t4[j]; }
+            *reinterpret_cast<f4 *>(m + i0) = m4; *reinterpret_cast<f4 *>(v + i0) = v4; *reinterpret_cast<f4 *>(p + i0) = p4;
+            if (zero_grad) *reinterpret_cast<f4 *>(g + i0) = f4{0, 0, 0, 0};
+            if (target) *reinterpret_cast<f4 *>(target + i0) = t4;
+            if (copy_out) *reinterpret_cast<f4 *>(copy_out + i0) = p4;
+        } else {
+            for (int i = i0; i < n; i++) {
+                float mi = m[i], vi = v[i], pi = p[i];
+                one(g[i], mi, vi, pi);
+                m[i] = mi; v[i] = vi; p[i] = pi;
+                if (zero_grad) g[i] = 0.f;
+                if (target) target[i] = tau * pi + (1.f - tau) * target[i];
+                if (copy_out) copy_out[i] = pi;
+            }
         }
     }
+    __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
         if (atomicAdd(done_count, 1) == (int)gridDim.x - 1) { done_count[0] = 0; step[0] = t; }
@@ -388,6 +424,7 @@ __global__ __launch_bounds__(64) void k_adam(float *__restrict__ p, float *__res
 }
 
 #include "td3_rows.hip"
+#include "td3_team.hip"
 
 // ---- K16: timeline probe: slot[0] = the GPU's constant-rate clock (100 MHz) when this one-lane kernel runs.  A node in a captured graph like any
 //      other, so the pipelined trainer's schedule can be read without a profiler serialising it.
@@ -471,7 +508,7 @@ int plentd3_polyak(float *target, const float *param, float tau, int n, void *st
 }
 int plentd3_adam(float *p, float *g, float *m, float *v, float *step, int *done_count, int n, double lr, double beta1, double beta2, float eps, int zero_grad,
                  float *target, float tau, float *copy_out, void *stream) {
-    hipLaunchKernelGGL(k_adam, dim3((n + 255) / 256), dim3(64), 0, (hipStream_t)stream, p, g, m, v, step, done_count, n, lr, beta1, beta2, eps, zero_grad, target, tau, copy_out); CHECK();
+    hipLaunchKernelGGL(k_adam, dim3(std::min((n + 1023) / 1024, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, step, done_count, n, lr, beta1, beta2, eps, zero_grad, target, tau, copy_out); CHECK();
 }
 int plentd3_critic_rows(const PlenTd3CriticRows *args, void *stream) {
     if (!args || args->B <= 0) return -(int)hipErrorInvalidValue;
@@ -480,6 +517,25 @@ int plentd3_critic_rows(const PlenTd3CriticRows *args, void *stream) {
 int plentd3_policy_rows(const PlenTd3PolicyRows *args, void *stream) {
     if (!args || args->B <= 0) return -(int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_policy_rows, dim3((args->B + RB - 1) / RB), dim3(64), 0, (hipStream_t)stream, *args); CHECK();
+}
+int plentd3_critic_team(const PlenTd3CriticRows *args, void *stream) {
+    if (!args || args->B <= 0) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_critic_team, dim3((args->B + RB - 1) / RB), dim3(64 * TEAM_NW), 0, (hipStream_t)stream, *args); CHECK();
+}
+int plentd3_policy_team(const PlenTd3PolicyRows *args, void *stream) {
+    if (!args || args->B <= 0) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_policy_team, dim3((args->B + RB - 1) / RB), dim3(64 * TEAM_NW), 0, (hipStream_t)stream, *args); CHECK();
+}
+int plentd3_wgrad_group(const PlenTd3WgradGroup *group, void *stream) {
+    if (!group || group->n_jobs < 1 || group->n_jobs > PLENTD3_WGRAD_JOBS || group->B <= 0) return -(int)hipErrorInvalidValue;
+    PlenTd3WgradGroup G = *group;
+    int tiles = 0;
+    for (int j = 0; j < G.n_jobs; j++) {
+        if (!G.job[j].dH || !G.job[j].X || !G.job[j].dW || G.job[j].N < 1 || G.job[j].K < 1) return -(int)hipErrorInvalidValue;
+        G.job[j].tile0 = tiles;
+        tiles += ((G.job[j].N + 31) / 32) * ((G.job[j].K + 31) / 32);
+    }
+    hipLaunchKernelGGL(k_wgrad_group, dim3(tiles), dim3(256), 0, (hipStream_t)stream, G); CHECK();
 }
 int plentd3_actor_rows(const PlenTd3ActorRows *args, void *stream) {
     if (!args || args->B <= 0) return -(int)hipErrorInvalidValue;

@@ -16,7 +16,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libplentd3.so")
 EXPORTS = ["plentd3_gather", "plentd3_sample_gather", "plentd3_explore", "plentd3_uniform_actions", "plentd3_store", "plentd3_target_action", "plentd3_q_heads", "plentd3_dh2", "plentd3_relu_mask", "plentd3_colsum", "plentd3_wgrad",
-           "plentd3_tanh_out", "plentd3_dtanh", "plentd3_bias_relu", "plentd3_polyak", "plentd3_adam", "plentd3_critic_rows", "plentd3_policy_rows", "plentd3_actor_rows", "plentd3_stamp", "plentd3_version"]
+           "plentd3_tanh_out", "plentd3_dtanh", "plentd3_bias_relu", "plentd3_polyak", "plentd3_adam", "plentd3_critic_rows", "plentd3_policy_rows", "plentd3_actor_rows", "plentd3_critic_team", "plentd3_policy_team",
+           "plentd3_wgrad_group", "plentd3_stamp", "plentd3_version"]
 ROW, S, A, SA, H = 72, 26, 18, 44, 256
 _lib = None
 
@@ -48,6 +49,22 @@ class ActorRowsArgs(C.Structure):
                 + [("sigma", C.c_float), ("max_a", C.c_float), ("B", C.c_int)])
 
 
+class WgradJob(C.Structure):
+    """Mirror of PlenTd3WgradJob (include/plentd3.h)."""
+    _fields_ = [("dH", C.c_void_p), ("X", C.c_void_p), ("dW", C.c_void_p), ("db", C.c_void_p)] + [(n, C.c_int) for n in ("ds", "xs", "dws", "N", "K", "tile0")]
+
+
+WGRAD_JOBS = 6
+
+
+class WgradGroup(C.Structure):
+    """Mirror of PlenTd3WgradGroup (include/plentd3.h)."""
+    _fields_ = [("job", WgradJob * WGRAD_JOBS), ("n_jobs", C.c_int), ("B", C.c_int)]
+
+
+TEAM_MAX_BATCH = 512          # FusedTD3(team=None): batches up to this size take the small-batch kernels (csrc/td3_team.hip)
+
+
 def load():
     global _lib
     if _lib is None:
@@ -77,6 +94,9 @@ def load():
         lib.plentd3_critic_rows.argtypes = [C.POINTER(CriticRowsArgs), vp]
         lib.plentd3_policy_rows.argtypes = [C.POINTER(PolicyRowsArgs), vp]
         lib.plentd3_actor_rows.argtypes = [C.POINTER(ActorRowsArgs), vp]
+        lib.plentd3_critic_team.argtypes = [C.POINTER(CriticRowsArgs), vp]
+        lib.plentd3_policy_team.argtypes = [C.POINTER(PolicyRowsArgs), vp]
+        lib.plentd3_wgrad_group.argtypes = [C.POINTER(WgradGroup), vp]
         lib.plentd3_adam.argtypes = [vp, vp, vp, vp, vp, vp, i, C.c_double, C.c_double, C.c_double, f, i, vp, f, vp, vp]
         _lib = lib
     return _lib
@@ -140,7 +160,7 @@ class FlatAdam(object):
 class FusedTD3(object):
     """update(data, idx, with_policy) == td3.td3_update(agent, (data rows idx split into s, a, s2, r, not_done), with_policy)."""
 
-    def __init__(self, agent, seed=0, rows=None):
+    def __init__(self, agent, seed=0, rows=None, team=None):
         if agent.device.type != "cuda":
             raise PlenTd3Error("FusedTD3 needs the agent on a HIP device")
         self.agent = agent
@@ -153,6 +173,11 @@ class FusedTD3(object):
         # row-block kernels (csrc/td3_rows.hip) + single-wave weight-gradient workgroups: what the update needs when it shares the chip with resident env
         # launches (PipelinedVecTD3Trainer: 0.73 -> 0.66 ms per step); on an otherwise idle GPU the library GEMMs are faster (critic pass 239 vs 315 us)
         self.rows = (os.environ.get("PLEN_TD3_ROWS", "0") == "1") if rows is None else bool(rows)
+        # small batches (the reference's batch 100 with one update per env-step: a chain of dependent updates, so latency is what counts): the same
+        # row-local passes with a TEAM of 8 waves per 16 batch rows (csrc/td3_team.hip) and all weight gradients of a pass in one launch
+        # (plentd3_wgrad_group): 2 + 1 (Adam) launches per critic update instead of ~35.  None: chosen per call, batch <= TEAM_MAX_BATCH.
+        self.team = (None if "PLEN_TD3_TEAM" not in os.environ else os.environ["PLEN_TD3_TEAM"] == "1") if team is None else bool(team)
+        self._team_pass = False      # did the last critic pass take the team kernels (policy_backward follows it)
         self._done_count = None
         self._alloc = None           # test hook: allocator of the per-iteration scratch matrices (tests put canary rows behind them)
         self._critic_adam = self._actor_adam = None
@@ -171,6 +196,24 @@ class FusedTD3(object):
         K = x.shape[1]
         assert dh.stride(1) == 1 and x.stride(1) == 1 and gw.is_contiguous() and gw.shape == (N, K)
         _chk(self.lib.plentd3_wgrad(_p(dh), dh.stride(0), _p(x), x.stride(0), _p(gw), K, _p(gb), B, N, K, int(self.rows), self._stream()))
+
+    def _use_team(self, B):
+        """Small-batch kernels for this batch size?  An explicit team= wins; otherwise batches <= TEAM_MAX_BATCH take them unless the caller asked for the
+        single-wave row kernels (rows=True: the pipelined trainer's update beside resident env launches, where a 512-thread workgroup would wait for
+        eight free wave slots on one compute unit)."""
+        return (not self.rows and B <= TEAM_MAX_BATCH) if self.team is None else self.team
+
+    def _wgrad_group(self, B, jobs):
+        """Every (dh, x, gw, gb) of `jobs` as _wgrad, in one launch (plentd3_wgrad_group: the batch is one reduction chunk)."""
+        G = WgradGroup()
+        assert 1 <= len(jobs) <= WGRAD_JOBS
+        for j, (dh, x, gw, gb) in zip(G.job, jobs):
+            N, K = gw.shape
+            assert dh.shape[0] == B and x.shape[0] == B and dh.stride(1) == 1 and x.stride(1) == 1 and gw.is_contiguous() and x.shape[1] == K and dh.shape[1] == N
+            j.dH, j.X, j.dW, j.db = dh.data_ptr(), x.data_ptr(), gw.data_ptr(), (gb.data_ptr() if gb is not None else None)
+            j.ds, j.xs, j.dws, j.N, j.K = dh.stride(0), x.stride(0), K, N, K
+        G.n_jobs, G.B = len(jobs), int(B)
+        _chk(self.lib.plentd3_wgrad_group(C.byref(G), self._stream()))
 
     @staticmethod
     def new_rng(device, seed):
@@ -298,8 +341,9 @@ class FusedTD3(object):
         """Sample, targets, critic forward / loss / backward: gradients land in the critic's flat bucket.  Returns the loss (device scalar).
         idx: LongTensor [B] of replay rows, or an int B with `total` (device int64 scalar: transitions written so far) to draw them here
         (then, with self.rows, everything up to the weight gradients runs as one row-block kernel: critic_backward_rows)."""
-        if self.rows and isinstance(idx, int) and noise is None:
-            return self.critic_backward_rows(data, idx, total, guard)
+        self._team_pass = False
+        if isinstance(idx, int) and noise is None and (self.rows or self._use_team(idx)):
+            return self.critic_backward_rows(data, idx, total, guard, team=self._use_team(idx))
         ag, lib, st = self.agent, self.lib, self._stream()
         dev = self.dev
         assert data.dtype == torch.float32 and data.is_contiguous() and data.shape[1] == ROW
@@ -366,7 +410,7 @@ class FusedTD3(object):
         self._probe(4)
         return loss[0]
 
-    def critic_backward_rows(self, data, B, total, guard=0):
+    def critic_backward_rows(self, data, B, total, guard=0, team=False):
         """critic_backward() with everything between the sampling and the weight gradients in ONE launch of single-wave workgroups
         (plentd3_critic_rows, csrc/td3_rows.hip): 8 kernels per critic update instead of ~35, and none of them needs more than one free wave slot
         per workgroup to start, which is what the update lacks beside two resident env launches.  Draws its random numbers in-kernel
@@ -380,7 +424,7 @@ class FusedTD3(object):
             tv, cv, gv = ag._critic_target_flat.views, ag._critic_flat.views, ag._critic_grads.views
             batch, sa_pi, sa2, dq = new(B, ROW), new(B, SA), new(B, SA), new(B, 2)
             t0, t1, c1, c2, dh2, dh1 = (new(B, 2 * H) for _ in range(6))
-            loss = torch.zeros(2, device=dev, dtype=torch.float32)
+            loss = new(2) if team else torch.zeros(2, device=dev, dtype=torch.float32)         # (the team kernel stores its loss, the row kernel adds to it)
             self._zero_grads("critic")
             if self._done_count is None:
                 self._done_count = torch.zeros(1, device=dev, dtype=torch.int32)
@@ -398,6 +442,16 @@ class FusedTD3(object):
             a.sigma, a.clip, a.max_a, a.gamma, a.B = float(ag.policy_noise), float(ag.noise_clip), float(ag.max_action), float(ag.discount), int(B)
             self._probe(1)
             self._probe(2)
+            if team:        # small batch: a team of 8 waves per row block, then every weight gradient in one launch (head rows as 1 x 256 products)
+                _chk(lib.plentd3_critic_team(C.byref(a), st))
+                self._probe(3)
+                self._wgrad_group(B, [(dq[:, 0:1], c2[:, :H], cr.fc3.weight.grad, None), (dq[:, 1:2], c2[:, H:], cr.fc6.weight.grad, None),
+                                      (dh2[:, :H], c1[:, :H], cr.fc2.weight.grad, cr.fc2.bias.grad), (dh2[:, H:], c1[:, H:], cr.fc5.weight.grad, cr.fc5.bias.grad),
+                                      (dh1, batch[:, :SA], gv["W14"], gv["b14"])])
+                self._saved = (batch[:, :S], sa_pi, B)
+                self._team_pass = True
+                self._probe(4)
+                return loss[0]
             _chk(lib.plentd3_critic_rows(C.byref(a), st))
             self._probe(3)
             # weight gradients (reductions over the batch): last layers, second layers, stacked first layers
@@ -417,7 +471,7 @@ class FusedTD3(object):
         s, sa_pi, B = self._saved
         new = self._alloc or (lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32))
         cr = ag.critic
-        if self.rows:
+        if self.rows or self._team_pass:
             with torch.no_grad():
                 ac = ag.actor
                 self._zero_grads("actor")
@@ -428,6 +482,11 @@ class FusedTD3(object):
                 a.c_w1, a.c_b1, a.c_w2, a.c_b2, a.c_w3 = (t.data_ptr() for t in (cr.fc1.weight, cr.fc1.bias, cr.fc2.weight, cr.fc2.bias, cr.fc3.weight))
                 a.sa_pi, a.a_pi, a.p1, a.p2, a.g1, a.dg2, a.dg1, a.dz, a.dp2, a.dp1 = (t.data_ptr() for t in (sa_pi, a_pi, p1, p2, g1, dg2, dg1, dz, dp2, dp1))
                 a.max_a, a.B = float(ag.max_action), int(B)
+                if self._team_pass:
+                    _chk(lib.plentd3_policy_team(C.byref(a), st))
+                    self._wgrad_group(B, [(dz, p2, ac.fc3.weight.grad, ac.fc3.bias.grad), (dp2, p1, ac.fc2.weight.grad, ac.fc2.bias.grad),
+                                          (dp1, s, ac.fc1.weight.grad, ac.fc1.bias.grad)])
+                    return
                 _chk(lib.plentd3_policy_rows(C.byref(a), st))
                 self._wgrad(dz, p2, ac.fc3.weight.grad, ac.fc3.bias.grad)
                 self._wgrad(dp2, p1, ac.fc2.weight.grad, ac.fc2.bias.grad)

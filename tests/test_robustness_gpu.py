@@ -285,7 +285,7 @@ def test_critic_rows_kernel_equals_the_layer_by_layer_update(B, total):
     data[:, 71] = (torch.rand(1000, device="cuda") > 0.1).float()         # not_done
     tot = torch.tensor(total, dtype=torch.long, device="cuda")
     rng0 = fz.rng.clone()
-    fz.rows = False                                                        # layer by layer
+    fz.rows, fz.team = False, False                                        # layer by layer
     loss_a = fz.critic_backward(data, B, total=tot, guard=64).clone()
     grads_a = ag._critic_grads.flat.clone()
     saved_a = [t.clone() for t in fz._saved[:2]]
@@ -320,7 +320,7 @@ def test_policy_rows_kernel_equals_the_layer_by_layer_policy_gradient(B):
     for net in (ag.actor, ag.critic):
         for p_ in net.parameters():
             p_.data.add_(0.05 * torch.randn_like(p_))
-    fz = FusedTD3(ag, seed=3)
+    fz = FusedTD3(ag, seed=3, team=False)
     data = torch.randn(500, 72, device="cuda")
     idx = torch.randint(0, 500, (B,), device="cuda")
     out = {}
@@ -337,6 +337,105 @@ def test_policy_rows_kernel_equals_the_layer_by_layer_policy_gradient(B):
         ga, gb = out[False][off:off + n], out[True][off:off + n]
         assert float(ga.abs().max()) > 0 and float((ga - gb).abs().max()) <= 1e-4 * float(ga.abs().max()), tuple(p_.shape)
         off += n
+
+
+@pytest.mark.parametrize("B,total", [(100, 700), (512, 50000), (16, 40), (37, 900), (3, 5)])
+def test_small_batch_team_kernels_equal_the_layer_by_layer_update(B, total):
+    """The small-batch shape of the update (csrc/td3_team.hip: a team of 8 waves per 16 batch rows; every weight gradient of a pass in one
+    plentd3_wgrad_group launch) against the layer-by-layer path (library GEMMs + one kernel per step) from the same random state: the reference's
+    batch 100 (plen_td3.py:28), the largest batch that takes this path by default, one row block exactly, a ragged last block, fewer rows than a
+    group of four.  Same sampled rows, same smoothing noise; loss, every critic gradient and every actor gradient agree to f32 summation order;
+    the call counter advances once; and two runs of the team path give bitwise equal weight gradients (one workgroup per output tile)."""
+    from plen_ml_walk_amd import td3 as T
+    from plen_ml_walk_amd.td3_fused import FusedTD3
+    torch.manual_seed(21)
+    ag = T.TD3Agent(26, 18, 1.0, data_parallel=False)
+    for net in (ag.actor, ag.actor_target, ag.critic_target, ag.critic):
+        for p_ in net.parameters():
+            p_.data.add_(0.05 * torch.randn_like(p_))
+    fz = FusedTD3(ag, seed=9)
+    data = torch.randn(1000, 72, device="cuda")
+    data[:, 70] = torch.rand(1000, device="cuda")
+    data[:, 71] = (torch.rand(1000, device="cuda") > 0.1).float()
+    tot = torch.tensor(total, dtype=torch.long, device="cuda")
+    rng0 = fz.rng.clone()
+    res = {}
+    for name, team in (("layers", False), ("team", True), ("team again", True)):
+        fz.rng.copy_(rng0)
+        fz.team = team
+        ag._critic_grads.zero(); ag._actor_grads.zero(); fz._zeroed = {}
+        loss = fz.critic_backward(data, B, total=tot, guard=64).clone()
+        assert fz._team_pass == team
+        fz.policy_backward()
+        torch.cuda.synchronize()
+        assert int(fz.rng[1]) == int(rng0[1]) + 1
+        res[name] = (loss, ag._critic_grads.flat.clone(), ag._actor_grads.flat.clone(), fz._saved[0].clone(), fz._saved[1].clone())
+    assert int(fz._done_count) == 0
+    la, ca, aa, sa_, pa = res["layers"]
+    lb, cb, ab, sb, pb = res["team"]
+    assert torch.equal(sa_, sb) and torch.equal(pa[:, :26], pb[:, :26])                         # the same replay rows were drawn
+    assert float((pa[:, 26:] - pb[:, 26:]).abs().max()) <= 2e-5                                  # actor(s): the policy pass's actions
+    assert torch.isfinite(lb) and abs(float(la) - float(lb)) <= 2e-5 * max(1.0, abs(float(la)))
+    for net, ga_all, gb_all in ((ag.critic, ca, cb), (ag.actor, aa, ab)):
+        assert float(ga_all.abs().max()) > 0 and float((ga_all - gb_all).abs().max()) <= 2e-5 * float(ga_all.abs().max())
+        off = 0
+        for p_ in T._flat_order(net):                   # per layer, so that a wrong small block cannot hide behind a large one
+            n = p_.numel()
+            ga, gb = ga_all[off:off + n], gb_all[off:off + n]
+            assert float((ga - gb).abs().max()) <= 1e-4 * max(float(ga.abs().max()), 1e-6), tuple(p_.shape)
+            off += n
+    lc, cc, ac, sc, pc = res["team again"]
+    assert torch.equal(ab, ac) and torch.equal(sb, sc) and torch.equal(pb, pc)               # (the loss and the two head biases' gradients are sums of
+    assert float((cb - cc).abs().max()) <= 1e-6 * float(cb.abs().max())                        # per-workgroup atomics: order-dependent in the last bit)
+
+
+def test_small_batch_update_keeps_its_scratch_rows_inside_the_batch():
+    """Canary rows behind every per-iteration scratch matrix of a team-path update at B = 100 (16-row blocks: the last one is ragged) stay untouched."""
+    from plen_ml_walk_amd import td3 as T
+    from plen_ml_walk_amd.td3_fused import FusedTD3
+    torch.manual_seed(5)
+    ag = T.TD3Agent(26, 18, 1.0, data_parallel=False)
+    fz = FusedTD3(ag, seed=1, team=True)
+    made = []
+
+    def alloc(*shape):
+        full = torch.full((shape[0] + 16,) + tuple(shape[1:]), 777.0, device="cuda")
+        made.append((full, shape[0]))
+        return full[:shape[0]]
+    fz._alloc = alloc
+    data = torch.randn(400, 72, device="cuda")
+    fz.critic_backward(data, 100, total=torch.tensor(400, dtype=torch.long, device="cuda"))
+    fz.policy_backward()
+    torch.cuda.synchronize()
+    assert len(made) >= 10
+    for full, n in made:
+        assert bool((full[n:] == 777.0).all()), tuple(full.shape)
+
+
+def test_flat_adam_kernel_equals_torch_adam_over_ragged_sizes():
+    """plentd3_adam (<= 128 workgroups of 256 lanes, 4 floats per lane and trip) against torch.optim.Adam for sizes that are not multiples of 4 or of a
+    workgroup's span, three steps, with the zeroed gradient, Polyak target and parameter copy of the same pass."""
+    from plen_ml_walk_amd import td3_fused as F
+    lib = F.load()
+    for n in (1, 3, 1023, 1025, 154114, 300001):
+        torch.manual_seed(n)
+        p = torch.randn(n, device="cuda"); ref = p.clone().requires_grad_(True)
+        opt = torch.optim.Adam([ref], lr=3e-4)
+        m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        step, done = torch.zeros((), device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+        target, copy = torch.randn(n, device="cuda"), torch.empty(n, device="cuda")
+        t_ref = target.clone()
+        st = F.C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for k in range(3):
+            g = torch.randn(n, device="cuda") * (10.0 ** (k - 1))
+            ref.grad = g.clone()
+            opt.step()
+            F._chk(lib.plentd3_adam(F._p(p), F._p(g), F._p(m), F._p(v), F._p(step), F._p(done), n, 3e-4, 0.9, 0.999, 1e-8, 1, F._p(target), 0.005, F._p(copy), st))
+            t_ref = 0.005 * ref.detach() + 0.995 * t_ref
+            torch.cuda.synchronize()
+            assert float(step) == k + 1 and int(done) == 0 and float(g.abs().max()) == 0.0
+            assert float((p - ref.detach()).abs().max()) <= 1e-6, (n, k)
+            assert torch.equal(copy, p) and float((target - t_ref).abs().max()) <= 1e-6
 
 
 @pytest.mark.parametrize("n", [2048, 37])
