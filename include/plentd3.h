@@ -120,6 +120,18 @@ typedef struct PlenTd3WgradJob { const float *dH; const float *X; float *dW; flo
 typedef struct PlenTd3WgradGroup { PlenTd3WgradJob job[PLENTD3_WGRAD_JOBS]; int n_jobs, B; } PlenTd3WgradGroup;
 int plentd3_wgrad_group(const PlenTd3WgradGroup *group, void *stream);
 
+/* plentd3_wgrad_group with the optimiser step of plentd3_adam applied where each gradient element is produced (the batch is one reduction chunk, so
+ * every element is owned by one workgroup): dW / db of the jobs must point INTO the flat gradient buffer g [n] (dws == K); the element's offset
+ * there addresses p, m, v and target (NULL: no Polyak update).  The gradients themselves are not stored: g stays zero.  extra_off: offsets of
+ * elements whose gradient is already in g (the critics' head biases): stepped and zeroed here.  step / done_count as plentd3_adam. */
+#define PLENTD3_ADAM_EXTRAS 4
+typedef struct PlenTd3AdamFused {
+    float *p, *g, *m, *v, *step, *target; int *done_count;
+    double lr, beta1, beta2; float eps, tau;
+    int n, n_extra, extra_off[PLENTD3_ADAM_EXTRAS];
+} PlenTd3AdamFused;
+int plentd3_wgrad_adam_group(const PlenTd3WgradGroup *group, const PlenTd3AdamFused *adam, void *stream);
+
 /* plen_td3.py:101-104 for a whole vector step as one launch: action [B][18] = clamp(actor(state [B][26]) + N(0, sigma), +-max_a), the noise drawn as
  * plentd3_explore draws it (rng, bumped by the plentd3_store that follows); p1, p2 [B][256] are scratch. */
 typedef struct PlenTd3ActorRows {

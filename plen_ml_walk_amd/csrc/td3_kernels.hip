@@ -223,9 +223,16 @@ __global__ void k_polyak(float *__restrict__ t, const float *__restrict__ p, flo
 //      two coalesced 128-byte row segments per operand and step, no transpose, no LDS -- and the partial tiles are added into dW (zeroed by
 //      the caller) with float atomics.  Waves of the first column tile also sum their dH operand: the bias gradient comes for free.
 typedef float floatx16 __attribute__((ext_vector_type(16)));
-template <int NW>
+struct WgradAtomicAdd {        // the plain epilogue: partial tiles are added into the (zeroed) gradient bucket
+    __device__ __forceinline__ void tile(float *const (&dst)[16], const float (&v)[16]) const {
+#pragma unroll
+        for (int k = 0; k < 16; k++) if (dst[k]) atomicAdd(dst[k], v[k]);
+    }
+    __device__ __forceinline__ void one(float *dst, float v) const { atomicAdd(dst, v); }
+};
+template <int NW, class Epilogue = WgradAtomicAdd>
 static __device__ __forceinline__ void wgrad_tile(const float *__restrict__ dH, int ds, const float *__restrict__ X, int xs, float *__restrict__ dW, int dws,
-                                                  float *__restrict__ db, int N, int K, int tile, int b0, int b1) {
+                                                  float *__restrict__ db, int N, int K, int tile, int b0, int b1, const Epilogue &emit = Epilogue()) {
     // workgroup = one (32 x 32 output tile, batch chunk).  NW = 4: its waves take every 4th pair of batch rows and are summed through LDS, so that a
     // tile costs one set of 1024 atomics per chunk instead of four.  NW = 1: one wave, no LDS -- a workgroup that starts in any single free wave
     // slot (the update beside resident env launches, td3_rows.hip), at the price of shorter chunks' worth of atomics.
@@ -276,14 +283,16 @@ static __device__ __forceinline__ void wgrad_tile(const float *__restrict__ dH, 
     }
     if (w == 0) {
         // result layout of the 32x32 MFMA: lane l holds column j = l % 32 and rows i = 8 * (v / 4) + 4 * (l / 32) + v % 4, v = 0..15
-        if (ka) {
+        float *dst[16];
+        float val[16];
 #pragma unroll
-            for (int v = 0; v < 16; v++) {
-                const int i = 8 * (v / 4) + 4 * half + (v % 4);
-                if (n0 + i < N) atomicAdd(dW + (size_t)(n0 + i) * dws + k0 + col, acc[v]);
-            }
+        for (int v = 0; v < 16; v++) {
+            const int i = 8 * (v / 4) + 4 * half + (v % 4);
+            dst[v] = (ka && n0 + i < N) ? dW + (size_t)(n0 + i) * dws + k0 + col : nullptr;
+            val[v] = acc[v];
         }
-        if (db && k0 == 0 && half == 0 && na) atomicAdd(db + n0 + col, bsum);
+        emit.tile(dst, val);
+        if (db && k0 == 0 && half == 0 && na) emit.one(db + n0 + col, bsum);
     }
 }
 
@@ -372,6 +381,23 @@ __global__ void k_store(float *__restrict__ data, const int64_t *__restrict__ to
     data[(size_t)row * TD3_ROW + c] = v;
 }
 
+// One Adam step of one element, and the Polyak update that may follow it: shared by k_adam and k_wgrad_adam_group, with the multiply-adds spelled out so that
+// the two kernels round alike whatever the compiler would have contracted in each context.
+// the hyper-parameters arrive as the doubles torch holds them in and are rounded where torch's kernel rounds them: 1 - beta2 = 0.001 computed
+// in float would be off by 5e-5 relative, and so would the second moment
+struct AdamCoef { float step_size, bc2_sqrt, b2, w1, w2, eps, tau; };
+static __device__ __forceinline__ AdamCoef adam_coef(float t, double lr, double b1d, double b2d, float eps, float tau) {
+    const double bc1 = 1.0 - pow(b1d, (double)t), bc2 = 1.0 - pow(b2d, (double)t);
+    return AdamCoef{(float)(lr / bc1), (float)sqrt(bc2), (float)b2d, (float)(1.0 - b1d), (float)(1.0 - b2d), eps, tau};
+}
+static __device__ __forceinline__ void adam_one(float gi, float &mi, float &vi, float &pi, const AdamCoef &c) {
+    mi = __fmaf_rn(gi - mi, c.w1, mi);
+    vi = __fmaf_rn(__fmul_rn(c.w2, gi), gi, __fmul_rn(vi, c.b2));
+    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), c.bc2_sqrt), c.eps);
+    pi = __fsub_rn(pi, __fdiv_rn(__fmul_rn(c.step_size, mi), denom));
+}
+static __device__ __forceinline__ float adam_polyak(float pi, float ti, float tau) { return __fmaf_rn(tau, pi, __fmul_rn(1.f - tau, ti)); }
+
 // ---- K17: one Adam step over a network's flat parameter / gradient buffers (torch.optim.Adam as td3.py:236-247 configures it: no weight decay, no
 //      amsgrad), optionally with what follows it in the iteration: the gradient bucket zeroed for the next backward pass, the Polyak update of
 //      the target network (td3.py:348-356) and a copy of the new parameters (the pipelined trainer's behaviour actor).  torch's fused Adam is two
@@ -379,20 +405,11 @@ __global__ void k_store(float *__restrict__ data, const int64_t *__restrict__ to
 //      step = float32 device scalar (torch's capturable `step`): read by every workgroup, advanced by the last one to finish.
 __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, float *step, int *done_count, int n,
                                               double lr, double b1d, double b2d, float eps, int zero_grad, float *__restrict__ target, float tau, float *__restrict__ copy_out) {
-    // the hyper-parameters arrive as the doubles torch holds them in and are rounded where torch's kernel rounds them: 1 - beta2 = 0.001 computed
-    // in float would be off by 5e-5 relative, and so would the second moment
     // (at most 256 workgroups of 256 lanes, 4 consecutive floats per lane and trip: the done_count atomics of 600 single-wave workgroups, all on one
     // address, were most of this kernel's 20 us on the critic's 154 k parameters)
     const float t = step[0] + 1.f;
-    const double bc1 = 1.0 - pow(b1d, (double)t), bc2 = 1.0 - pow(b2d, (double)t);
-    const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
-    const float b2 = (float)b2d, w1 = (float)(1.0 - b1d), w2 = (float)(1.0 - b2d);
-    auto one = [&](float gi, float &mi, float &vi, float &pi) {
-        mi = mi + (gi - mi) * w1;
-        vi = vi * b2 + w2 * gi * gi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        pi = pi - step_size * mi / denom;
-    };
+    const AdamCoef c = adam_coef(t, lr, b1d, b2d, eps, tau);
+    auto one = [&](float gi, float &mi, float &vi, float &pi) { adam_one(gi, mi, vi, pi, c); };
     typedef float f4 __attribute__((ext_vector_type(4)));
     for (int i0 = (blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += gridDim.x * 1024) {
         if (i0 + 3 < n) {                       // four consecutive floats as one 16-byte access per array (the flat buffers are 16-byte aligned)
@@ -400,7 +417,7 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, float *__re
             f4 m4 = *reinterpret_cast<const f4 *>(m + i0), v4 = *reinterpret_cast<const f4 *>(v + i0), p4 = *reinterpret_cast<const f4 *>(p + i0), t4 = {0, 0, 0, 0};
             if (target) t4 = *reinterpret_cast<const f4 *>(target + i0);
 #pragma unroll
-            for (int j = 0; j < 4; j++) { float mi = m4[j], vi = v4[j], pi = p4[j]; one(g4[j], mi, vi, pi); m4[j] = mi; v4[j] = vi; p4[j] = pi; t4[j] = tau * pi + (1.f - tau) * t4[j]; }
+            for (int j = 0; j < 4; j++) { float mi = m4[j], vi = v4[j], pi = p4[j]; one(g4[j], mi, vi, pi); m4[j] = mi; v4[j] = vi; p4[j] = pi; t4[j] = adam_polyak(pi, t4[j], tau); }
             *reinterpret_cast<f4 *>(m + i0) = m4; *reinterpret_cast<f4 *>(v + i0) = v4; *reinterpret_cast<f4 *>(p + i0) = p4;
             if (zero_grad) *reinterpret_cast<f4 *>(g + i0) = f4{0, 0, 0, 0};
             if (target) *reinterpret_cast<f4 *>(target + i0) = t4;
@@ -411,7 +428,7 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, float *__re
                 one(g[i], mi, vi, pi);
                 m[i] = mi; v[i] = vi; p[i] = pi;
                 if (zero_grad) g[i] = 0.f;
-                if (target) target[i] = tau * pi + (1.f - tau) * target[i];
+                if (target) target[i] = adam_polyak(pi, target[i], tau);
                 if (copy_out) copy_out[i] = pi;
             }
         }
@@ -420,6 +437,63 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, float *__re
     if (threadIdx.x == 0) {
         __threadfence();
         if (atomicAdd(done_count, 1) == (int)gridDim.x - 1) { done_count[0] = 0; step[0] = t; }
+    }
+}
+
+// ---- K15c + K17 in one: the grouped weight gradients of a SMALL batch with the Adam step applied where each gradient element is produced.
+//      With the whole batch as one reduction chunk every element of every gradient is owned by exactly one workgroup (its 32 x 32 tile; the bias
+//      gradients by the tiles of the first column block), so that workgroup can take the Adam step for it at once: the gradient never travels
+//      through the bucket (which therefore stays zero for the next pass), and the iteration loses a launch and two dependent trips to memory.
+//      dW / db of the jobs point INTO the flat gradient buffer Ad.g: an element's offset there is its offset in p, m, v and target.
+//      Elements whose gradient is already in the bucket (the critics' head biases, summed by k_critic_team) are listed in extra_off: workgroup 0
+//      steps them and zeroes them.  Same arithmetic per element as k_adam, same step counter protocol.
+struct WgradAdamStep {
+    const PlenTd3AdamFused &Ad; const AdamCoef &c;
+    // all of a lane's 16 elements: every load first (one trip to memory for the tile, not one per element), then the arithmetic, then the stores
+    __device__ __forceinline__ void tile(float *const (&dst)[16], const float (&gv)[16]) const {
+        float m[16], v[16], p[16], tg[16];
+        size_t o[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            o[k] = dst[k] ? (size_t)(dst[k] - Ad.g) : 0;
+            m[k] = Ad.m[o[k]]; v[k] = Ad.v[o[k]]; p[k] = Ad.p[o[k]]; tg[k] = Ad.target ? Ad.target[o[k]] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) adam_one(gv[k], m[k], v[k], p[k], c);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (dst[k]) {
+                Ad.m[o[k]] = m[k]; Ad.v[o[k]] = v[k]; Ad.p[o[k]] = p[k];
+                if (Ad.target) Ad.target[o[k]] = adam_polyak(p[k], tg[k], c.tau);
+            }
+        }
+    }
+    __device__ __forceinline__ void one(float *dst, float gi) const {
+        const size_t o = (size_t)(dst - Ad.g);
+        float m = Ad.m[o], v = Ad.v[o], p = Ad.p[o];
+        adam_one(gi, m, v, p, c);
+        Ad.m[o] = m; Ad.v[o] = v; Ad.p[o] = p;
+        if (Ad.target) Ad.target[o] = adam_polyak(p, Ad.target[o], c.tau);
+    }
+};
+__global__ __launch_bounds__(256) void k_wgrad_adam_group(PlenTd3WgradGroup G, PlenTd3AdamFused Ad) {
+    const float t = Ad.step[0] + 1.f;
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < PLENTD3_WGRAD_JOBS; k++) j += (k < G.n_jobs && (int)blockIdx.x >= G.job[k].tile0) ? 1 : 0;
+    const PlenTd3WgradJob &J = G.job[j];
+    const AdamCoef c = adam_coef(t, Ad.lr, Ad.beta1, Ad.beta2, Ad.eps, Ad.tau);
+    const WgradAdamStep emit{Ad, c};
+    wgrad_tile<4, WgradAdamStep>(J.dH, J.ds, J.X, J.xs, J.dW, J.dws, J.db, J.N, J.K, (int)blockIdx.x - J.tile0, 0, G.B, emit);
+    if (blockIdx.x == 0 && (int)threadIdx.x < Ad.n_extra) {
+        float *ge = Ad.g + Ad.extra_off[threadIdx.x];
+        emit.one(ge, *ge);
+        *ge = 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(Ad.done_count, 1) == (int)gridDim.x - 1) { Ad.done_count[0] = 0; Ad.step[0] = t; }
     }
 }
 
@@ -536,6 +610,24 @@ int plentd3_wgrad_group(const PlenTd3WgradGroup *group, void *stream) {
         tiles += ((G.job[j].N + 31) / 32) * ((G.job[j].K + 31) / 32);
     }
     hipLaunchKernelGGL(k_wgrad_group, dim3(tiles), dim3(256), 0, (hipStream_t)stream, G); CHECK();
+}
+int plentd3_wgrad_adam_group(const PlenTd3WgradGroup *group, const PlenTd3AdamFused *adam, void *stream) {
+    if (!group || !adam || group->n_jobs < 1 || group->n_jobs > PLENTD3_WGRAD_JOBS || group->B <= 0) return -(int)hipErrorInvalidValue;
+    if (!adam->p || !adam->g || !adam->m || !adam->v || !adam->step || !adam->done_count || adam->n < 1 || adam->n_extra < 0 || adam->n_extra > PLENTD3_ADAM_EXTRAS)
+        return -(int)hipErrorInvalidValue;
+    PlenTd3WgradGroup G = *group;
+    int tiles = 0;
+    for (int j = 0; j < G.n_jobs; j++) {
+        const PlenTd3WgradJob &J = G.job[j];
+        if (!J.dH || !J.X || !J.dW || J.N < 1 || J.K < 1 || J.dws != J.K) return -(int)hipErrorInvalidValue;
+        // every output element must lie inside the flat gradient buffer the Adam buffers mirror
+        if (J.dW < adam->g || J.dW + (size_t)J.N * J.K > adam->g + adam->n || (J.db && (J.db < adam->g || J.db + J.N > adam->g + adam->n))) return -(int)hipErrorInvalidValue;
+        G.job[j].tile0 = tiles;
+        tiles += ((J.N + 31) / 32) * ((J.K + 31) / 32);
+    }
+    for (int e = 0; e < adam->n_extra; e++)
+        if (adam->extra_off[e] < 0 || adam->extra_off[e] >= adam->n) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_wgrad_adam_group, dim3(tiles), dim3(256), 0, (hipStream_t)stream, G, *adam); CHECK();
 }
 int plentd3_actor_rows(const PlenTd3ActorRows *args, void *stream) {
     if (!args || args->B <= 0) return -(int)hipErrorInvalidValue;

@@ -92,6 +92,59 @@ static __device__ __forceinline__ void mm_nt_c(rsrc_t rx, int ldx, int xcol0, rs
     }
 }
 
+// acc[t] += G[16 rows][gcol0 + (0..Kc)] * W[(0..Kc)][j0 + 16 t + (0..15)] (input gradient of a dense layer: W is the layer's [out = Kc][in] weight).
+// The B operand of td3_rows.hip's mm_nn is coalesced as it stands (16 lanes read 64 contiguous bytes of one row of W), its A operand is not: here A
+// goes through LDS as in mm_nt_c, B stays a direct load.  (B through LDS as well -- whole row segments per load, parked row-major -- was measured
+// and lost: 32 scalar LDS reads per stage cost more than the look-ups they save.)
+template <int NT, bool KGUARD>
+static __device__ __forceinline__ void mm_nn_a(rsrc_t rg, int ldg, int gcol0, rsrc_t rw, int ldw, int j0, int Kc, floatx4 (&acc)[NT], const RowBlock &rb, float *lds) {
+    const int lane = rb.lane, r = rb.r, g = rb.g, rho = lane >> 3, c8 = lane & 7;
+    const int k_lo = c8 ^ team_sigma(rho), k_hi = c8 ^ team_sigma(rho + 8);
+    const uint32_t xo0 = (uint32_t)(min(rb.b0 + rho, rb.B - 1) * ldg + gcol0 + 4 * k_lo) * 4u, xo1 = (uint32_t)(min(rb.b0 + rho + 8, rb.B - 1) * ldg + gcol0 + 4 * k_hi) * 4u;
+    const int rd0 = 4 * (8 * r + (g ^ team_sigma(r))), rd1 = 4 * (8 * r + ((4 + g) ^ team_sigma(r)));
+    const uint32_t woff = (uint32_t)(4 * g * ldw + j0 + r) * 4u;
+    struct Stage { floatx4 a[2], b[2][NT]; };
+    auto load = [&](int k0, Stage &S) {
+        S.a[0] = bload4(rg, xo0, 4u * (uint32_t)k0); S.a[1] = bload4(rg, xo1, 4u * (uint32_t)k0);
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) S.b[s][t][j] = bload1(rw, woff, 4u * (uint32_t)((k0 + 16 * s + j) * ldw + 16 * t));
+    };
+    auto compute = [&](int k0, const Stage &S) {
+        *reinterpret_cast<floatx4 *>(lds + 4 * lane) = S.a[0]; *reinterpret_cast<floatx4 *>(lds + 256 + 4 * lane) = S.a[1];
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            floatx4 fa = *reinterpret_cast<const floatx4 *>(lds + (s ? rd1 : rd0));
+            if constexpr (KGUARD) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) fa[j] = k0 + 16 * s + 4 * g + j < Kc ? fa[j] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], S.b[s][t][j], acc[t], 0, 0, 0);
+        }
+    };
+    Stage S0, S1;
+    load(0, S0);
+#pragma unroll 1
+    for (int k0 = 0; k0 < Kc; k0 += 64) {
+        load(k0 + 32, S1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(k0, S0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k0 + 32 < Kc) {
+            load(k0 + 64, S0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(k0 + 32, S1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // Y[b0 + row][n0 + (0..16 NT)] = relu(X[:, xcol0 ...] W^T + bias) (dense_relu with the coalesced product; the bias is requested before the product)
 template <int NT, bool KGUARD>
 static __device__ __forceinline__ void dense_relu_c(rsrc_t rx, int ldx, int xcol0, int K, rsrc_t rw, int ldw, const float *bias, int n0, rsrc_t ry, int ldy, const RowBlock &rb, float *lds) {
@@ -278,9 +331,10 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
             lsum = ea * ea * inv + eb * eb * inv;
         }
         lsum = wave_sum(lsum); ga = wave_sum(ga); gb = wave_sum(gb);
-        // the loss: one partial per workgroup, parked in an unused column of the workgroup's own scratch row and summed in order by the last workgroup
-        // to finish (below) -- a plain store into loss[0], so nobody has to zero it first and the sum does not depend on the finishing order
-        if (lane == 0) { A.t1[(size_t)b0 * 2 * TD3_H + TD3_H] = lsum; atomicAdd(A.db3a, ga); atomicAdd(A.db3b, gb); }
+        // the loss and the two head biases' gradients: one partial per workgroup, parked in unused columns of the workgroup's own scratch row and summed
+        // in order by the last workgroup to finish (below): the sums do not depend on the finishing order (same bits every run), and loss[0] is a
+        // plain store that nobody has to zero first
+        if (lane == 0) { float *park = A.t1 + (size_t)b0 * 2 * TD3_H + TD3_H; park[0] = lsum; park[1] = ga; park[2] = gb; }
     }
     TEAM_SYNC();
     // ---- dh2 = dq (x) w3 where the hidden unit was active: two rows per wave, 4 columns per lane and critic ----
@@ -314,7 +368,7 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
         floatx4 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; t++) acc[t] = floatx4{0, 0, 0, 0};
-        mm_nn<4, false>(r_dh2, rb.aoff(2 * TD3_H, half * TD3_H), rw, TD3_H, j0, TD3_H, acc, r, g);
+        mm_nn_a<4, false>(r_dh2, 2 * TD3_H, half * TD3_H, rw, TD3_H, j0, TD3_H, acc, rb, lds);
 #pragma unroll
         for (int t = 0; t < 4; t++)
 #pragma unroll
@@ -329,9 +383,14 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
         __threadfence();
         if (atomicAdd(A.done_count, 1) == (int)gridDim.x - 1) {
             __threadfence();
-            float l = 0.f;
-            for (int k = 0; k < (int)gridDim.x; k++) l += __hip_atomic_load(A.t1 + (size_t)k * RB * 2 * TD3_H + TD3_H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            A.loss[0] = l;
+            float l = 0.f, ga = 0.f, gb = 0.f;
+            for (int k = 0; k < (int)gridDim.x; k++) {
+                const float *park = A.t1 + (size_t)k * RB * 2 * TD3_H + TD3_H;
+                l += __hip_atomic_load(park, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ga += __hip_atomic_load(park + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gb += __hip_atomic_load(park + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            A.loss[0] = l; A.db3a[0] += ga; A.db3b[0] += gb;
             A.done_count[0] = 0;
             if (A.rng_bump) A.rng_bump[1] += 1;
         }
@@ -352,7 +411,7 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
     const rsrc_t r_dg2 = mkrs(A.dg2, Bz * TD3_H * 4), r_dg1 = mkrs(A.dg1, Bz * TD3_H * 4), r_dp2 = mkrs(A.dp2, Bz * TD3_H * 4), r_dp1 = mkrs(A.dp1, Bz * TD3_H * 4);
     const rsrc_t r_dz = mkrs(A.dz, Bz * TD3_A * 4);
     const int n0 = 32 * w;
-    __shared__ float team_lds[TEAM_NW][3 * TEAM_TILE];
+    __shared__ float team_lds[TEAM_NW][3 * TEAM_TILE];          // A + two column tiles of W
     float *lds = team_lds[w];
     // an 18-wide result of a 256-long product, split over the team along k and summed through LDS in wave order: z[i] valid in waves 0, 1 (tile t = w)
     auto team_reduce = [&](const floatx4 (&acc)[2], int lane, floatx4 &z) {
@@ -425,7 +484,7 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
         PHASE();
         const uint32_t hoff = rb.soff(TD3_H);
         floatx4 acc[2] = {floatx4{0, 0, 0, 0}, floatx4{0, 0, 0, 0}};
-        mm_nn<2, false>(r_dg2, rb.aoff(TD3_H), mkrs(A.c_w2, (size_t)TD3_H * TD3_H * 4), TD3_H, n0, TD3_H, acc, r, g);
+        mm_nn_a<2, false>(r_dg2, TD3_H, 0, mkrs(A.c_w2, (size_t)TD3_H * TD3_H * 4), TD3_H, n0, TD3_H, acc, rb, lds);
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
@@ -436,7 +495,7 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
     {
         PHASE();
         floatx4 acc[2] = {floatx4{0, 0, 0, 0}, floatx4{0, 0, 0, 0}}, z;
-        mm_nn<2, false>(r_dg1, rb.aoff(TD3_H, n0), mkrs(A.c_w1 + (size_t)n0 * TD3_SA, ((size_t)TD3_H - n0) * TD3_SA * 4), TD3_SA, TD3_S, 32, acc, r, g);
+        mm_nn_a<2, false>(r_dg1, TD3_H, n0, mkrs(A.c_w1 + (size_t)n0 * TD3_SA, ((size_t)TD3_H - n0) * TD3_SA * 4), TD3_SA, TD3_S, 32, acc, rb, lds);
         team_reduce(acc, lane, z);
         const int j = 16 * w + r;
         if (w < 2 && j < TD3_A) {
@@ -456,7 +515,7 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
         PHASE();
         const uint32_t hoff = rb.soff(TD3_H);
         floatx4 acc[2] = {floatx4{0, 0, 0, 0}, floatx4{0, 0, 0, 0}};
-        mm_nn<2, true>(r_dz, rb.aoff(TD3_A), mkrs(A.a_w3, (size_t)TD3_A * TD3_H * 4), TD3_H, n0, TD3_A, acc, r, g);
+        mm_nn_a<2, true>(r_dz, TD3_A, 0, mkrs(A.a_w3, (size_t)TD3_A * TD3_H * 4), TD3_H, n0, TD3_A, acc, rb, lds);
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
@@ -467,7 +526,7 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
         PHASE();
         const uint32_t hoff = rb.soff(TD3_H);
         floatx4 acc[2] = {floatx4{0, 0, 0, 0}, floatx4{0, 0, 0, 0}};
-        mm_nn<2, false>(r_dp2, rb.aoff(TD3_H), mkrs(A.a_w2, (size_t)TD3_H * TD3_H * 4), TD3_H, n0, TD3_H, acc, r, g);
+        mm_nn_a<2, false>(r_dp2, TD3_H, 0, mkrs(A.a_w2, (size_t)TD3_H * TD3_H * 4), TD3_H, n0, TD3_H, acc, rb, lds);
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libplentd3.so")
 EXPORTS = ["plentd3_gather", "plentd3_sample_gather", "plentd3_explore", "plentd3_uniform_actions", "plentd3_store", "plentd3_target_action", "plentd3_q_heads", "plentd3_dh2", "plentd3_relu_mask", "plentd3_colsum", "plentd3_wgrad",
            "plentd3_tanh_out", "plentd3_dtanh", "plentd3_bias_relu", "plentd3_polyak", "plentd3_adam", "plentd3_critic_rows", "plentd3_policy_rows", "plentd3_actor_rows", "plentd3_critic_team", "plentd3_policy_team",
-           "plentd3_wgrad_group", "plentd3_stamp", "plentd3_version"]
+           "plentd3_wgrad_group", "plentd3_wgrad_adam_group", "plentd3_stamp", "plentd3_version"]
 ROW, S, A, SA, H = 72, 26, 18, 44, 256
 _lib = None
 
@@ -62,6 +62,15 @@ class WgradGroup(C.Structure):
     _fields_ = [("job", WgradJob * WGRAD_JOBS), ("n_jobs", C.c_int), ("B", C.c_int)]
 
 
+ADAM_EXTRAS = 4
+
+
+class AdamFusedArgs(C.Structure):
+    """Mirror of PlenTd3AdamFused (include/plentd3.h)."""
+    _fields_ = ([(n, C.c_void_p) for n in ("p", "g", "m", "v", "step", "target", "done_count")] + [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
+                ("eps", C.c_float), ("tau", C.c_float), ("n", C.c_int), ("n_extra", C.c_int), ("extra_off", C.c_int * ADAM_EXTRAS)])
+
+
 TEAM_MAX_BATCH = 512          # FusedTD3(team=None): batches up to this size take the small-batch kernels (csrc/td3_team.hip)
 
 
@@ -97,6 +106,7 @@ def load():
         lib.plentd3_critic_team.argtypes = [C.POINTER(CriticRowsArgs), vp]
         lib.plentd3_policy_team.argtypes = [C.POINTER(PolicyRowsArgs), vp]
         lib.plentd3_wgrad_group.argtypes = [C.POINTER(WgradGroup), vp]
+        lib.plentd3_wgrad_adam_group.argtypes = [C.POINTER(WgradGroup), C.POINTER(AdamFusedArgs), vp]
         lib.plentd3_adam.argtypes = [vp, vp, vp, vp, vp, vp, i, C.c_double, C.c_double, C.c_double, f, i, vp, f, vp, vp]
         _lib = lib
     return _lib
@@ -146,6 +156,21 @@ class FlatAdam(object):
         if steps:
             self.step_t.fill_(steps.pop())
 
+    def fused_args(self, target=None, tau=0.0, extras=()):
+        """PlenTd3AdamFused for plentd3_wgrad_adam_group: this optimiser's step taken inside the weight-gradient kernel (hyper-parameters as they are now)."""
+        st0 = self.opt.state.get(self.params[0])
+        if (not st0 or st0["exp_avg"].data_ptr() != self.m.data_ptr()) and not torch.cuda.is_current_stream_capturing():
+            self.bind()
+        g = self.opt.param_groups[0]
+        a = AdamFusedArgs()
+        a.p, a.g, a.m, a.v, a.step, a.done_count = (t.data_ptr() for t in (self.p, self.g, self.m, self.v, self.step_t, self.done))
+        a.target = target.data_ptr() if target is not None else None
+        a.lr, a.beta1, a.beta2, a.eps, a.tau = float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(tau)
+        a.n, a.n_extra = self.p.numel(), len(extras)
+        for k, e in enumerate(extras):
+            a.extra_off[k] = int(e)
+        return a
+
     def step(self, zero_grad=False, target=None, tau=0.0, copy_out=None):
         st0 = self.opt.state.get(self.params[0])
         if (not st0 or st0["exp_avg"].data_ptr() != self.m.data_ptr()) and not torch.cuda.is_current_stream_capturing():
@@ -178,6 +203,10 @@ class FusedTD3(object):
         # (plentd3_wgrad_group): 2 + 1 (Adam) launches per critic update instead of ~35.  None: chosen per call, batch <= TEAM_MAX_BATCH.
         self.team = (None if "PLEN_TD3_TEAM" not in os.environ else os.environ["PLEN_TD3_TEAM"] == "1") if team is None else bool(team)
         self._team_pass = False      # did the last critic pass take the team kernels (policy_backward follows it)
+        # one rank, small batch, flat Adam: the optimiser step is taken inside the grouped weight-gradient kernel (plentd3_wgrad_adam_group).
+        # update() sets _fuse = {"critic": target-or-None, "actor": target} for the passes it is about to run and reads _fused_done back.
+        self.fuse_adam = os.environ.get("PLEN_TD3_FUSE_ADAM", "1") == "1"
+        self._fuse, self._fused_done = None, set()
         self._done_count = None
         self._alloc = None           # test hook: allocator of the per-iteration scratch matrices (tests put canary rows behind them)
         self._critic_adam = self._actor_adam = None
@@ -203,8 +232,9 @@ class FusedTD3(object):
         eight free wave slots on one compute unit)."""
         return (not self.rows and B <= TEAM_MAX_BATCH) if self.team is None else self.team
 
-    def _wgrad_group(self, B, jobs):
-        """Every (dh, x, gw, gb) of `jobs` as _wgrad, in one launch (plentd3_wgrad_group: the batch is one reduction chunk)."""
+    def _wgrad_group(self, B, jobs, which=None, extras=()):
+        """Every (dh, x, gw, gb) of `jobs` as _wgrad, in one launch (plentd3_wgrad_group: the batch is one reduction chunk).  With update()'s consent
+        (self._fuse holds `which`) the network's Adam step (+ Polyak update) is taken in the same launch and the gradients are not stored."""
         G = WgradGroup()
         assert 1 <= len(jobs) <= WGRAD_JOBS
         for j, (dh, x, gw, gb) in zip(G.job, jobs):
@@ -213,6 +243,13 @@ class FusedTD3(object):
             j.dH, j.X, j.dW, j.db = dh.data_ptr(), x.data_ptr(), gw.data_ptr(), (gb.data_ptr() if gb is not None else None)
             j.ds, j.xs, j.dws, j.N, j.K = dh.stride(0), x.stride(0), K, N, K
         G.n_jobs, G.B = len(jobs), int(B)
+        if which is not None and self._fuse is not None and which in self._fuse:
+            adam = self._critic_adam if which == "critic" else self._actor_adam
+            base = adam.g.data_ptr()
+            a = adam.fused_args(target=self._fuse[which], tau=self.agent.tau, extras=[(t.data_ptr() - base) // 4 for t in extras])
+            _chk(self.lib.plentd3_wgrad_adam_group(C.byref(G), C.byref(a), self._stream()))
+            self._fused_done.add(which)
+            return
         _chk(self.lib.plentd3_wgrad_group(C.byref(G), self._stream()))
 
     @staticmethod
@@ -267,22 +304,32 @@ class FusedTD3(object):
     def update(self, data, idx, with_policy, noise=None, all_reduce=True, total=None, guard=0):
         """The whole iteration; with torch.distributed initialised the two gradient buckets are averaged over ranks before their Adam steps."""
         ag = self.agent
+        flat = self._critic_adam is not None
+        fuse = flat and self.fuse_adam and not all_reduce         # (with ranks to average over, the gradients have to exist in the bucket)
+        self._fused_done = set()
+        self._fuse = {"critic": ag._critic_target_flat.flat if with_policy else None} if fuse else None
         loss = self.critic_backward(data, idx, noise, total, guard)
+        self._fuse = None
         if all_reduce:
             ag._critic_grads.all_reduce_mean()
-        flat = self._critic_adam is not None
-        if flat:       # Adam + zeroed bucket (+ the critic's Polyak update, which nothing reads before the iteration's end: td3.py:348-352) in one pass
+        if "critic" in self._fused_done:
+            self._zeroed["critic"] = True      # nothing was written into the bucket (the head biases' sums were consumed and zeroed)
+        elif flat:     # Adam + zeroed bucket (+ the critic's Polyak update, which nothing reads before the iteration's end: td3.py:348-352) in one pass
             self._critic_adam.step(zero_grad=True, target=ag._critic_target_flat.flat if with_policy else None, tau=ag.tau)
             self._zeroed["critic"] = True
         else:
             ag.critic_optimizer.step()
         ag.last_critic_loss = loss
         if with_policy:
+            self._fuse = {"actor": ag._actor_target_flat.flat} if fuse else None
             self.policy_backward()
+            self._fuse = None
             if all_reduce:
                 ag._actor_grads.all_reduce_mean()
             ag.last_actor_loss = None          # (-mean Q1 itself is not needed for the update; the autograd path reports it)
-            if flat:
+            if "actor" in self._fused_done:
+                self._zeroed["actor"] = True
+            elif flat:
                 self._actor_adam.step(zero_grad=True, target=ag._actor_target_flat.flat, tau=ag.tau)
                 self._zeroed["actor"] = True
             else:
@@ -447,7 +494,7 @@ class FusedTD3(object):
                 self._probe(3)
                 self._wgrad_group(B, [(dq[:, 0:1], c2[:, :H], cr.fc3.weight.grad, None), (dq[:, 1:2], c2[:, H:], cr.fc6.weight.grad, None),
                                       (dh2[:, :H], c1[:, :H], cr.fc2.weight.grad, cr.fc2.bias.grad), (dh2[:, H:], c1[:, H:], cr.fc5.weight.grad, cr.fc5.bias.grad),
-                                      (dh1, batch[:, :SA], gv["W14"], gv["b14"])])
+                                      (dh1, batch[:, :SA], gv["W14"], gv["b14"])], which="critic", extras=(cr.fc3.bias.grad, cr.fc6.bias.grad))
                 self._saved = (batch[:, :S], sa_pi, B)
                 self._team_pass = True
                 self._probe(4)
@@ -485,7 +532,7 @@ class FusedTD3(object):
                 if self._team_pass:
                     _chk(lib.plentd3_policy_team(C.byref(a), st))
                     self._wgrad_group(B, [(dz, p2, ac.fc3.weight.grad, ac.fc3.bias.grad), (dp2, p1, ac.fc2.weight.grad, ac.fc2.bias.grad),
-                                          (dp1, s, ac.fc1.weight.grad, ac.fc1.bias.grad)])
+                                          (dp1, s, ac.fc1.weight.grad, ac.fc1.bias.grad)], which="actor")
                     return
                 _chk(lib.plentd3_policy_rows(C.byref(a), st))
                 self._wgrad(dz, p2, ac.fc3.weight.grad, ac.fc3.bias.grad)

@@ -345,7 +345,7 @@ def test_small_batch_team_kernels_equal_the_layer_by_layer_update(B, total):
     plentd3_wgrad_group launch) against the layer-by-layer path (library GEMMs + one kernel per step) from the same random state: the reference's
     batch 100 (plen_td3.py:28), the largest batch that takes this path by default, one row block exactly, a ragged last block, fewer rows than a
     group of four.  Same sampled rows, same smoothing noise; loss, every critic gradient and every actor gradient agree to f32 summation order;
-    the call counter advances once; and two runs of the team path give bitwise equal weight gradients (one workgroup per output tile)."""
+    the call counter advances once; and two runs of the team path are bitwise equal (no sum depends on the order workgroups finish in)."""
     from plen_ml_walk_amd import td3 as T
     from plen_ml_walk_amd.td3_fused import FusedTD3
     torch.manual_seed(21)
@@ -384,9 +384,36 @@ def test_small_batch_team_kernels_equal_the_layer_by_layer_update(B, total):
             ga, gb = ga_all[off:off + n], gb_all[off:off + n]
             assert float((ga - gb).abs().max()) <= 1e-4 * max(float(ga.abs().max()), 1e-6), tuple(p_.shape)
             off += n
-    lc, cc, ac, sc, pc = res["team again"]
-    assert torch.equal(ab, ac) and torch.equal(sb, sc) and torch.equal(pb, pc)               # (the loss and the two head biases' gradients are sums of
-    assert float((cb - cc).abs().max()) <= 1e-6 * float(cb.abs().max())                        # per-workgroup atomics: order-dependent in the last bit)
+    for x, y in zip(res["team"], res["team again"]):          # same bits every run: one workgroup per output tile, per-workgroup partial sums added in order
+        assert torch.equal(x, y)
+
+
+def test_adam_step_inside_the_weight_gradient_kernel_equals_the_separate_step():
+    """plentd3_wgrad_adam_group (small batch, one rank: each gradient element is stepped by the workgroup that produced it, the bucket stays zero) against
+    plentd3_wgrad_group + plentd3_adam: six updates of batch 100 from the same state leave bitwise equal parameters, targets, moments and step counts."""
+    from plen_ml_walk_amd import td3 as T
+    from plen_ml_walk_amd.td3_fused import FusedTD3
+    data = torch.randn(5000, 72, device="cuda")
+    data[:, 70] = torch.rand(5000, device="cuda"); data[:, 71] = (torch.rand(5000, device="cuda") > 0.1).float()
+    tot = torch.tensor(5000, dtype=torch.long, device="cuda")
+    out = {}
+    for fuse in (False, True):
+        torch.manual_seed(31)
+        ag = T.TD3Agent(26, 18, 1.0, data_parallel=False)
+        fz = FusedTD3(ag, seed=4, team=True)
+        fz.enable_flat_adam()
+        fz.fuse_adam = fuse
+        for k in range(6):
+            loss = fz.update(data, 100, with_policy=(k % 2 == 1), all_reduce=False, total=tot)
+            assert ("critic" in fz._fused_done) == fuse and ("actor" in fz._fused_done) == (fuse and k % 2 == 1)
+        torch.cuda.synchronize()
+        assert float(ag._critic_grads.flat.abs().max()) == 0.0 and float(ag._actor_grads.flat.abs().max()) == 0.0
+        out[fuse] = [loss.clone(), ag._critic_flat.flat.clone(), ag._actor_flat.flat.clone(), ag._critic_target_flat.flat.clone(), ag._actor_target_flat.flat.clone(),
+                     fz._critic_adam.m.clone(), fz._critic_adam.v.clone(), fz._actor_adam.m.clone(), fz._actor_adam.v.clone(),
+                     fz._critic_adam.step_t.clone(), fz._actor_adam.step_t.clone()]
+        assert float(out[fuse][-2]) == 6.0 and float(out[fuse][-1]) == 3.0
+    for a_, b_ in zip(out[False], out[True]):
+        assert torch.equal(a_, b_)
 
 
 def test_small_batch_update_keeps_its_scratch_rows_inside_the_batch():
