@@ -369,7 +369,7 @@ def td3_leg(a, dev, rank, world, dist, steps, warmup):
     return out
 
 
-def td3_reference_leg(a, dev, rank, world, dist, n=64, steps=60):
+def td3_reference_leg(a, dev, rank, world, dist, n=64, steps=320):
     """The REFERENCE'S update-to-data recipe as a driver-run leg: batch 100 and ONE TD3 update per env-step (plen_td3.py:119-120,
     td3.py:259-356), start_timesteps 1e4 of uniform random actions, exploration N(0, 0.1), replay 1e6 -- n envs step together, then n updates follow
     (same ratio; the reference interleaves them one by one).  Update-bound by construction: reports updates/s and env-steps/s (equal per rank)."""
@@ -400,6 +400,8 @@ def td3_reference_leg(a, dev, rank, world, dist, n=64, steps=60):
     out = {"value": world * (tr.env_steps - e0) / dt, "unit": "env-steps/s", "grad_steps_per_s": (tr.grad_steps - g0) / dt, "updates_in_window": tr.grad_steps - g0,
            "env_steps_in_window": tr.env_steps - e0, "seconds": dt, "envs": n, "batch": 100, "updates_per_env_step": (tr.grad_steps - g0) / max(1, tr.env_steps - e0),
            "critic_loss": float(agent.last_critic_loss) if agent.last_critic_loss is not None else None,
+           "update_path": "small-batch kernels (csrc/td3_team.hip: a team of 8 waves per 16 batch rows, all weight gradients + Adam + Polyak of a pass in one launch): "
+                          "3 launches per critic update, 2 more per policy update; same bits every run",
            "workload": "the reference's recipe (plen_td3.py:21-30, 83-157): %d envs, one update of batch 100 per env-step, policy_freq 2, hipGraph-captured fused update" % n}
     env.close()
     return out

@@ -289,12 +289,13 @@ class GraphedVecTD3Trainer(object):
 
         fz = self.fused
 
-        def update(with_policy):                       # one rank, or collectives captured: the whole iteration in one graph
+        def update(with_policy, publish=True):         # one rank, or collectives captured: the whole iteration in one graph
             if fz is not None:
                 loss = fz.update(replay.data, batch_size, with_policy, all_reduce=self.collectives, total=self.total_t)
             else:
                 loss = T.td3_update(agent, sample(), with_policy, all_reduce=self.collectives)
-            self._critic_loss.copy_(loss)
+            if publish:                                # (a 5 us device copy: a block of updates publishes its last loss only)
+                self._critic_loss.copy_(loss)
 
         # --- segments for eager collectives between graph replays (world > 1) ---
         def seg_critic_backward():
@@ -374,6 +375,11 @@ class GraphedVecTD3Trainer(object):
         self._graphs[key] = g
         g.replay()                                   # the capture itself does not execute
 
+    def _update_block(self, n):
+        """n consecutive iterations starting at a multiple of policy_freq (td3.py:334: every policy_freq-th one carries the delayed policy update)."""
+        for k in range(n):
+            self._update_fn((k + 1) % self.agent.policy_freq == 0, publish=(k == n - 1))
+
     def _update(self, with_policy):
         if not self.collectives or self.allreduce_mode == "captured":
             self._run(("update", with_policy), self._update_fn, with_policy)
@@ -392,11 +398,20 @@ class GraphedVecTD3Trainer(object):
         self.host_total += self.n
         self.env_steps += self.n
         if self.host_total >= self.start_timesteps:
-            for _ in range(self.updates_per_step):
-                with_policy = (self.grad_steps + 1) % self.agent.policy_freq == 0
-                self._update(with_policy)
-                self.grad_steps += 1
+            n_up, pf = self.updates_per_step, self.agent.policy_freq
+            if n_up > 1 and n_up % pf == 0 and self.grad_steps % pf == 0 and (not self.collectives or self.allreduce_mode == "captured"):
+                # a whole vector step's updates as ONE graph (the reference's recipe: as many updates as env-steps, plen_td3.py:119-120): the pattern
+                # of delayed policy updates repeats every policy_freq iterations, so the block is the same every step, and a chain of ~100 us
+                # updates is not paced by one graph launch each
+                self._run(("updates", n_up), self._update_block, n_up)
+                self.grad_steps += n_up
                 self.agent.total_it = self.grad_steps
+            else:
+                for _ in range(n_up):
+                    with_policy = (self.grad_steps + 1) % pf == 0
+                    self._update(with_policy)
+                    self.grad_steps += 1
+                    self.agent.total_it = self.grad_steps
         self.replay.size = min(self.host_total, self.replay.max_size)
         self.replay.ptr = self.host_total % self.replay.max_size if self.host_total >= self.replay.max_size else 0
         self.agent.last_critic_loss = self._critic_loss
