@@ -594,11 +594,11 @@ int plentd3_policy_rows(const PlenTd3PolicyRows *args, void *stream) {
 }
 int plentd3_critic_team(const PlenTd3CriticRows *args, void *stream) {
     if (!args || args->B <= 0) return -(int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_critic_team, dim3((args->B + RB - 1) / RB), dim3(64 * TEAM_NW), 0, (hipStream_t)stream, *args); CHECK();
+    hipLaunchKernelGGL(k_critic_team, dim3((args->B + QB - 1) / QB), dim3(64 * TEAM_NW), 0, (hipStream_t)stream, *args); CHECK();
 }
 int plentd3_policy_team(const PlenTd3PolicyRows *args, void *stream) {
     if (!args || args->B <= 0) return -(int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_policy_team, dim3((args->B + RB - 1) / RB), dim3(64 * TEAM_NW), 0, (hipStream_t)stream, *args); CHECK();
+    hipLaunchKernelGGL(k_policy_team, dim3((args->B + QB - 1) / QB), dim3(64 * TEAM_NW), 0, (hipStream_t)stream, *args); CHECK();
 }
 int plentd3_wgrad_group(const PlenTd3WgradGroup *group, void *stream) {
     if (!group || group->n_jobs < 1 || group->n_jobs > PLENTD3_WGRAD_JOBS || group->B <= 0) return -(int)hipErrorInvalidValue;

@@ -21,7 +21,7 @@ def alloc(*shape):
 fz._alloc = alloc
 data = torch.randn(100000, 72, device="cuda")
 tot = torch.tensor(100000, dtype=torch.long, device="cuda")
-names = ["gather", "at1 + c14", "at2", "at3 partial", "at3 reduce + action", "ct14", "ct2/5 + c2/5 heads", "y, loss, dq", "dh2", "dh1"]
+names = ["gather", "at1 + c14", "at2", "at3 + action (wave 0)", "ct14", "ct2/5 + c2/5 heads", "y, loss, dq", "dh2", "dh1"]
 rows = []
 for k in range(40):
     del made[:]
@@ -31,7 +31,7 @@ for k in range(40):
     st = t1[0, 256 + 8:256 + 8 + 2 * 12].cpu().numpy().view(np.uint64).astype(np.int64)
     if k >= 8:
         rows.append(np.diff(st[:len(names) + 1]))
-d = np.median(np.array(rows), 0) / 100.0
+d = np.median(np.array(rows), 0) / 100.0          # s_memtime ticks at 100 MHz
 for n, v in zip(names, d):
     print("%-24s %6.2f us" % (n, v))
 print("%-24s %6.2f us" % ("total (to last barrier)", d.sum()))
