@@ -369,7 +369,7 @@ def td3_leg(a, dev, rank, world, dist, steps, warmup):
     return out
 
 
-def td3_reference_leg(a, dev, rank, world, dist, n=64, steps=320):
+def td3_reference_leg(a, dev, rank, world, dist, n=64, steps=400):
     """The REFERENCE'S update-to-data recipe as a driver-run leg: batch 100 and ONE TD3 update per env-step (plen_td3.py:119-120,
     td3.py:259-356), start_timesteps 1e4 of uniform random actions, exploration N(0, 0.1), replay 1e6 -- n envs step together, then n updates follow
     (same ratio; the reference interleaves them one by one).  Update-bound by construction: reports updates/s and env-steps/s (equal per rank)."""

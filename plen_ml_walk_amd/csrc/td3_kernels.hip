@@ -259,10 +259,17 @@ static __device__ __forceinline__ void wgrad_tile(const float *__restrict__ dH, 
 #pragma unroll
         for (int u = 0; u < 8; u++) { acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0); bsum += av[u]; }
     }
-    for (; b < b1; b += 2 * NW) {                     // ragged tail (also an odd last row)
-        const bool ra = b + half < b1;
-        const float a = (na && ra) ? dH[(size_t)(b + half) * ds + n0 + col] : 0.f, x = (ka && ra) ? X[(size_t)(b + half) * xs + k0 + col] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x, acc, 0, 0, 0); bsum += a;
+    if (b < b1) {                                     // ragged tail (also an odd last row): one more group of 8 pairs, rows past the end read as zero --
+        float av[8], bv[8];                           // its loads all in flight together (a batch of 100 is 36 tail rows: row by row, each one's trip
+#pragma unroll                                        // to memory was exposed and the tail took longer than everything else in the kernel)
+        for (int u = 0; u < 8; u++) {
+            const int row = b + 2 * NW * u + half;
+            const bool ra = row < b1;
+            av[u] = (na && ra) ? dH[(size_t)row * ds + n0 + col] : 0.f;
+            bv[u] = (ka && ra) ? X[(size_t)row * xs + k0 + col] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0); bsum += av[u]; }
     }
     bsum += __shfl_xor(bsum, 32);
     if constexpr (NW > 1) {
