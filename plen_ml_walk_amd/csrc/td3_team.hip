@@ -8,9 +8,10 @@
 //   * td3_rows.hip's one-wave-per-16-rows kernels put the whole chain of 13 dense layers on ONE wave per row block: 7 waves on a 256-CU chip.
 // Here a block of FOUR batch rows belongs to a TEAM of 8 waves (one 512-thread workgroup, 2 waves per SIMD): 25 workgroups at batch 100.  Every dense
 // layer's output columns are split over the team -- a wave owns 32 (or 2 x 32) columns --, the twin critics run side by side on the two halves of
-// the team, and layers are separated by workgroup barriers instead of launches.  Activations go through global memory between layers (the
-// weight-gradient kernel wants them there anyway; the team's waves share one compute unit's vector cache, so a workgroup-scope barrier makes them
-// visible).
+// the team, and layers are separated by workgroup barriers instead of launches.  The block's activations live in LDS (4 rows x ~2400 floats) from
+// the gathered replay rows to the last gradient: a layer reads its input there and writes its output there, so a barrier between layers has to
+// wait for LDS only (fence on the local address space + s_barrier: no drain of the stores to global memory, no trip to L2 for the next layer's
+// input).  What the weight-gradient launch needs is ALSO stored to global memory, asynchronously.
 //
 // The matrix-core shape is v_mfma_f32_4x4x1_16b_f32: sixteen independent 4 x 4 outer products per instruction.  Lane l feeds block l / 4 with
 // A[i = l % 4] and B[j = l % 4] and receives D[i = 0..3][j = l % 4].  The blocks are used as 8 column groups x 2 halves of the reduction index:
@@ -26,7 +27,7 @@
 // conflicts) and read back as the 16 bytes per lane the MFMAs consume.  The four activation rows need no staging: the MFMA's block broadcast
 // (CBSZ / ABID) hands one block's A values to all blocks of a half, so a single coalesced 16-byte load per lane feeds a whole stage.
 //
-// Sums: every dot product adds its k values in ascending order within a half, then the two halves; the critics' scalar heads add per-wave partial
+// Sums: every dot product adds its k values in ascending order per (k % 4, half) class, then the four classes, then the two halves; the critics' scalar heads add per-wave partial
 // sums in wave order; loss and head-bias gradients add per-workgroup partials in workgroup order.  Nothing depends on timing: same bits every run.
 
 #define TEAM_NW 8
@@ -34,10 +35,13 @@
 #define TEAM_B_F (32 * 64)                     // floats of a staged W tile: 32 rows x 64 k
 #define TEAM_LDS_PER_WAVE TEAM_B_F
 #ifdef TEAM_STAMPS            // development (scripts/gpu_td3_team_stamps.py): the clock after every barrier, parked in unused columns of workgroup 0's scratch row of t1
-#define TEAM_SYNC() do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) { reinterpret_cast<unsigned long long *>(A.t1 + TD3_H + 8)[team_stamp_k++] = __builtin_readcyclecounter(); } } while (0)
+#define TEAM_SYNC() do { TEAM_LDS_BARRIER(); if (threadIdx.x == 0 && blockIdx.x == 0) { reinterpret_cast<unsigned long long *>(A.t1 + TD3_H + 8)[team_stamp_k++] = __builtin_readcyclecounter(); } } while (0)
 #else
-#define TEAM_SYNC() __syncthreads()
+#define TEAM_SYNC() TEAM_LDS_BARRIER()
 #endif
+// a workgroup barrier that orders LDS accesses only: stores to global memory stay in flight across it (nothing in these kernels reads back from
+// global memory what another wave of the same launch wrote, except where noted)
+#define TEAM_LDS_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
 
 // Geometry of a wave's tile.  Built per phase from an opaque lane id (as td3_rows.hip's fresh_rows: lane-derived offsets are then not common
 // subexpressions of the whole kernel, kept alive -- and spilled -- across all phases).
@@ -52,11 +56,10 @@ static __device__ __forceinline__ Quad fresh_quad(int b0, int B) {
 #define QPHASE() const Quad q = fresh_quad(b0, B); const int lane = q.lane, col = q.col; (void)lane; (void)col
 
 // The A operand needs no staging at all: with CBSZ = 3 an MFMA broadcasts the A values of ONE block (ABID = 0..7) to the 8 blocks of its group -- here
-// the two groups are the two halves of the reduction index.  So lane l loads 16 bytes of row l % 4 (clamped to the batch) at k = 32 (l / 32) + 4 ((l % 32) / 4)
+// the two groups are the two halves of the reduction index.  So lane l reads 16 bytes of row l % 4 at k = 32 (l / 32) + 4 ((l % 32) / 4)
 // of the stage, and MFMA (c, j) of the stage broadcasts element j of the lanes of blocks c and 8 + c: k = 32 half + 4 c + j, the k its B operand holds.
-static __device__ __forceinline__ uint32_t quad_a_voff(const Quad &q, int ld, int col0) {
-    return (uint32_t)(min(q.b0 + q.row4, q.B - 1) * ld + col0 + 32 * q.half + 4 * (q.col >> 2)) * 4u;
-}
+// (the activations are in LDS: xa = the block's row 0 of the layer's input, row stride ld floats; 16-byte aligned)
+static __device__ __forceinline__ const float *quad_a_ptr(const Quad &q, const float *xa, int ld) { return xa + q.row4 * ld + 32 * q.half + 4 * (q.col >> 2); }
 template <bool KGUARD>
 static __device__ __forceinline__ floatx4 quad_a_guard(floatx4 a, int k0, int K, const Quad &q) {
     if constexpr (KGUARD) {
@@ -65,49 +68,55 @@ static __device__ __forceinline__ floatx4 quad_a_guard(floatx4 a, int k0, int K,
     }
     return a;
 }
+// (four accumulators, one per k % 4: back-to-back MFMAs on ONE accumulator wait for each other's result -- 128 of them per 256-long product)
 #define QUAD_MFMA_STAGE(ACC, FA, FB_OF_C_J)                                                            \
     do {                                                                                               \
-        ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[0], FB_OF_C_J(0, 0), ACC, 3, 0, 0); ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[1], FB_OF_C_J(0, 1), ACC, 3, 0, 0); \
-        ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[2], FB_OF_C_J(0, 2), ACC, 3, 0, 0); ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[3], FB_OF_C_J(0, 3), ACC, 3, 0, 0); \
-        ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[0], FB_OF_C_J(1, 0), ACC, 3, 1, 0); ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[1], FB_OF_C_J(1, 1), ACC, 3, 1, 0); \
-        ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[2], FB_OF_C_J(1, 2), ACC, 3, 1, 0); ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[3], FB_OF_C_J(1, 3), ACC, 3, 1, 0); \
-        ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[0], FB_OF_C_J(2, 0), ACC, 3, 2, 0); ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[1], FB_OF_C_J(2, 1), ACC, 3, 2, 0); \
-        ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[2], FB_OF_C_J(2, 2), ACC, 3, 2, 0); ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[3], FB_OF_C_J(2, 3), ACC, 3, 2, 0); \
-        ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[0], FB_OF_C_J(3, 0), ACC, 3, 3, 0); ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[1], FB_OF_C_J(3, 1), ACC, 3, 3, 0); \
-        ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[2], FB_OF_C_J(3, 2), ACC, 3, 3, 0); ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[3], FB_OF_C_J(3, 3), ACC, 3, 3, 0); \
-        ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[0], FB_OF_C_J(4, 0), ACC, 3, 4, 0); ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[1], FB_OF_C_J(4, 1), ACC, 3, 4, 0); \
-        ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[2], FB_OF_C_J(4, 2), ACC, 3, 4, 0); ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[3], FB_OF_C_J(4, 3), ACC, 3, 4, 0); \
-        ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[0], FB_OF_C_J(5, 0), ACC, 3, 5, 0); ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[1], FB_OF_C_J(5, 1), ACC, 3, 5, 0); \
-        ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[2], FB_OF_C_J(5, 2), ACC, 3, 5, 0); ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[3], FB_OF_C_J(5, 3), ACC, 3, 5, 0); \
-        ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[0], FB_OF_C_J(6, 0), ACC, 3, 6, 0); ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[1], FB_OF_C_J(6, 1), ACC, 3, 6, 0); \
-        ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[2], FB_OF_C_J(6, 2), ACC, 3, 6, 0); ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[3], FB_OF_C_J(6, 3), ACC, 3, 6, 0); \
-        ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[0], FB_OF_C_J(7, 0), ACC, 3, 7, 0); ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[1], FB_OF_C_J(7, 1), ACC, 3, 7, 0); \
-        ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[2], FB_OF_C_J(7, 2), ACC, 3, 7, 0); ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[3], FB_OF_C_J(7, 3), ACC, 3, 7, 0); \
+        ACC[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[0], FB_OF_C_J(0, 0), ACC[0], 3, 0, 0); ACC[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[1], FB_OF_C_J(0, 1), ACC[1], 3, 0, 0); ACC[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[2], FB_OF_C_J(0, 2), ACC[2], 3, 0, 0); ACC[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[3], FB_OF_C_J(0, 3), ACC[3], 3, 0, 0); \
+        ACC[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[0], FB_OF_C_J(1, 0), ACC[0], 3, 1, 0); ACC[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[1], FB_OF_C_J(1, 1), ACC[1], 3, 1, 0); ACC[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[2], FB_OF_C_J(1, 2), ACC[2], 3, 1, 0); ACC[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[3], FB_OF_C_J(1, 3), ACC[3], 3, 1, 0); \
+        ACC[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[0], FB_OF_C_J(2, 0), ACC[0], 3, 2, 0); ACC[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[1], FB_OF_C_J(2, 1), ACC[1], 3, 2, 0); ACC[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[2], FB_OF_C_J(2, 2), ACC[2], 3, 2, 0); ACC[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[3], FB_OF_C_J(2, 3), ACC[3], 3, 2, 0); \
+        ACC[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[0], FB_OF_C_J(3, 0), ACC[0], 3, 3, 0); ACC[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[1], FB_OF_C_J(3, 1), ACC[1], 3, 3, 0); ACC[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[2], FB_OF_C_J(3, 2), ACC[2], 3, 3, 0); ACC[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[3], FB_OF_C_J(3, 3), ACC[3], 3, 3, 0); \
+        ACC[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[0], FB_OF_C_J(4, 0), ACC[0], 3, 4, 0); ACC[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[1], FB_OF_C_J(4, 1), ACC[1], 3, 4, 0); ACC[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[2], FB_OF_C_J(4, 2), ACC[2], 3, 4, 0); ACC[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[3], FB_OF_C_J(4, 3), ACC[3], 3, 4, 0); \
+        ACC[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[0], FB_OF_C_J(5, 0), ACC[0], 3, 5, 0); ACC[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[1], FB_OF_C_J(5, 1), ACC[1], 3, 5, 0); ACC[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[2], FB_OF_C_J(5, 2), ACC[2], 3, 5, 0); ACC[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[3], FB_OF_C_J(5, 3), ACC[3], 3, 5, 0); \
+        ACC[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[0], FB_OF_C_J(6, 0), ACC[0], 3, 6, 0); ACC[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[1], FB_OF_C_J(6, 1), ACC[1], 3, 6, 0); ACC[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[2], FB_OF_C_J(6, 2), ACC[2], 3, 6, 0); ACC[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[3], FB_OF_C_J(6, 3), ACC[3], 3, 6, 0); \
+        ACC[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[0], FB_OF_C_J(7, 0), ACC[0], 3, 7, 0); ACC[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[1], FB_OF_C_J(7, 1), ACC[1], 3, 7, 0); ACC[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[2], FB_OF_C_J(7, 2), ACC[2], 3, 7, 0); ACC[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(FA[3], FB_OF_C_J(7, 3), ACC[3], 3, 7, 0); \
     } while (0)
+static __device__ __forceinline__ floatx4 quad_combine(const floatx4 (&a)[4]) {
+    floatx4 r = (a[0] + a[1]) + (a[2] + a[3]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) r[i] += __shfl_xor(r[i], 32);           // the two halves of the reduction index
+    return r;
+}
 
 // acc[i] (rows b0 + i, column n0 + col; valid in every lane) = sum_{k < K} X[b0 + i][xcol0 + k] W[n0 + col][k]      (W: nn.Linear's [out][in], row stride ldw)
 // Rows of W at or beyond the end of rw read as zero (the 18-wide output layers); k beyond K must be harmless: KGUARD zeroes A there (B then holds
 // finite values of the next row, or zeros).
 template <bool KGUARD, int NS>          // NS = stages of 64 k: K <= 64 NS
-static __device__ __forceinline__ floatx4 quad_nt(rsrc_t rx, int ldx, int xcol0, rsrc_t rw, int ldw, int n0, int K, const Quad &q, float *lds) {
+static __device__ __forceinline__ floatx4 quad_nt(const float *xa, int ldx, rsrc_t rw, int ldw, int n0, int K, const Quad &q, float *lds) {
     const int lane = q.lane, brow = lane >> 4, bch = lane & 15;
-    const uint32_t xo = quad_a_voff(q, ldx, xcol0);
-    struct Stage { floatx4 a, b[8]; };
+    const float *xp = quad_a_ptr(q, xa, ldx);
+    struct Stage { floatx4 b[8]; };
     auto load = [&](int k0, Stage &S) {
-        S.a = bload4(rx, xo, 4u * (uint32_t)k0);
 #pragma unroll
         for (int i = 0; i < 8; i++) {                      // rows brow + 4 i of the tile; the chunk this lane fetches is the one whose parking slot is (row, bch)
             const int row = brow + 4 * i, ch = bch ^ (row & 15);
+#ifdef TEAM_EXPERIMENT_NO_LOAD                             /* development: what the phases cost without their trips to memory (results are wrong) */
+            S.b[i] = floatx4{(float)(row + k0), 1.f, 2.f, (float)ch};
+#else
             S.b[i] = bload4(rw, (uint32_t)((n0 + row) * ldw + 4 * ch) * 4u, 4u * (uint32_t)k0);
+#endif
         }
     };
     auto park = [&](const Stage &S) {
+#ifndef TEAM_EXPERIMENT_NO_PARK
 #pragma unroll
         for (int i = 0; i < 8; i++) *reinterpret_cast<floatx4 *>(lds + 4 * (64 * i + lane)) = S.b[i];
+#else
+        if (lane > 64) *reinterpret_cast<floatx4 *>(lds) = S.b[0] + S.b[1] + S.b[2] + S.b[3] + S.b[4] + S.b[5] + S.b[6] + S.b[7];
+#endif
     };
-    floatx4 acc = {0, 0, 0, 0};
-    auto compute = [&](int k0, const Stage &S) {
-        const floatx4 fa = quad_a_guard<KGUARD>(S.a, k0, K, q);
+    floatx4 acc[4] = {floatx4{0, 0, 0, 0}, floatx4{0, 0, 0, 0}, floatx4{0, 0, 0, 0}, floatx4{0, 0, 0, 0}};
+    auto compute = [&](int k0, const Stage &) {
+        const floatx4 fa = quad_a_guard<KGUARD>(*reinterpret_cast<const floatx4 *>(xp + k0), k0, K, q);
         floatx4 fb[8];
 #pragma unroll
         for (int c = 0; c < 8; c++) fb[c] = *reinterpret_cast<const floatx4 *>(lds + 4 * (16 * q.col + ((8 * q.half + c) ^ (q.col & 15))));
@@ -126,27 +135,24 @@ static __device__ __forceinline__ floatx4 quad_nt(rsrc_t rx, int ldx, int xcol0,
         park(S[s]);
         compute(64 * s, S[s]);
     }
-#pragma unroll
-    for (int i = 0; i < 4; i++) acc[i] += __shfl_xor(acc[i], 32);
-    return acc;
+    return quad_combine(acc);
 }
 
 // acc[i] (rows b0 + i, column j0 + col) = sum_{n < Kc} G[b0 + i][gcol0 + n] W[n][j0 + col]    (input gradient of a dense layer: W is the layer's [out = Kc][in])
 // B needs no staging: the 32 lanes of a half read 128 contiguous bytes of one row of W per load.  Rows n >= Kc must lie outside rw (they read as zero);
 // KGUARD also zeroes A there (a G whose rows are shorter than a stage: the next row's values are not wanted).
 template <bool KGUARD, int NS>
-static __device__ __forceinline__ floatx4 quad_nn(rsrc_t rg, int ldg, int gcol0, rsrc_t rw, int ldw, int j0, int Kc, const Quad &q, float * /*lds: nothing is staged*/) {
-    const uint32_t xo = quad_a_voff(q, ldg, gcol0);
+static __device__ __forceinline__ floatx4 quad_nn(const float *ga, int ldg, rsrc_t rw, int ldw, int j0, int Kc, const Quad &q) {
+    const float *gp = quad_a_ptr(q, ga, ldg);
     const uint32_t wo = (uint32_t)(32 * q.half * ldw + j0 + q.col) * 4u;
-    struct Stage { floatx4 a; float b[32]; };
+    struct Stage { float b[32]; };
     auto load = [&](int k0, Stage &S) {
-        S.a = bload4(rg, xo, 4u * (uint32_t)k0);
 #pragma unroll
         for (int m = 0; m < 32; m++) S.b[m] = bload1(rw, wo + 4u * (uint32_t)((k0 + m) * ldw), 0);          // (the row term in voffset: range-checked)
     };
-    floatx4 acc = {0, 0, 0, 0};
+    floatx4 acc[4] = {floatx4{0, 0, 0, 0}, floatx4{0, 0, 0, 0}, floatx4{0, 0, 0, 0}, floatx4{0, 0, 0, 0}};
     auto compute = [&](int k0, const Stage &S) {
-        const floatx4 fa = quad_a_guard<KGUARD>(S.a, k0, Kc, q);
+        const floatx4 fa = quad_a_guard<KGUARD>(*reinterpret_cast<const floatx4 *>(gp + k0), k0, Kc, q);
 #define QUAD_FB(c, j) S.b[4 * (c) + (j)]
         QUAD_MFMA_STAGE(acc, fa, QUAD_FB);
 #undef QUAD_FB
@@ -167,37 +173,54 @@ static __device__ __forceinline__ floatx4 quad_nn(rsrc_t rg, int ldg, int gcol0,
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-#pragma unroll
-    for (int i = 0; i < 4; i++) acc[i] += __shfl_xor(acc[i], 32);
-    return acc;
+    return quad_combine(acc);
 }
 
-// Y[b0 + i][n0 + col] = v[i] for the rows inside the batch: one lane per column (the lower half of the wave), 128 contiguous bytes per row
-static __device__ __forceinline__ void quad_store(float *Y, int ldy, int n0, const floatx4 &v, const Quad &q) {
+// v[i] (rows b0 + i, column n0 + col) into the block's LDS activations (L: row 0 of the destination, row stride ldl; may be null) and / or into
+// global memory (Y: [B][ldy], rows inside the batch only; may be null): one lane per column (the lower half of the wave), 128 contiguous bytes per row
+static __device__ __forceinline__ void quad_store(float *L, int ldl, float *Y, int ldy, int n0, const floatx4 &v, const Quad &q) {
     if (q.lane < 32) {
 #pragma unroll
-        for (int i = 0; i < QB; i++)
-            if (q.b0 + i < q.B) Y[(size_t)(q.b0 + i) * ldy + n0 + q.col] = v[i];
+        for (int i = 0; i < QB; i++) {
+            if (L) L[i * ldl + n0 + q.col] = v[i];
+            if (Y && q.b0 + i < q.B) Y[(size_t)(q.b0 + i) * ldy + n0 + q.col] = v[i];
+        }
     }
 }
 
-// one 32-column tile of a hidden layer: Y = relu(X W^T + bias)   (the bias is requested before the product)
+// one 32-column tile of a hidden layer: relu(X W^T + bias)   (the bias is requested before the product)
 template <bool KGUARD, int NS>
-static __device__ __forceinline__ void quad_dense_relu(rsrc_t rx, int ldx, int xcol0, int K, rsrc_t rw, int ldw, const float *bias, int n0, float *Y, int ldy, const Quad &q, float *lds) {
+static __device__ __forceinline__ void quad_dense_relu(const float *xa, int ldx, int K, rsrc_t rw, int ldw, const float *bias, int n0, float *L, int ldl, float *Y, int ldy, const Quad &q, float *lds) {
     const float bv = bias[n0 + q.col];
-    floatx4 acc = quad_nt<KGUARD, NS>(rx, ldx, xcol0, rw, ldw, n0, K, q, lds);
+    floatx4 acc = quad_nt<KGUARD, NS>(xa, ldx, rw, ldw, n0, K, q, lds);
 #pragma unroll
     for (int i = 0; i < 4; i++) acc[i] = fmaxf(acc[i] + bv, 0.f);
-    quad_store(Y, ldy, n0, acc, q);
+    quad_store(L, ldl, Y, ldy, n0, acc, q);
 }
 
 // sum over the wave's 32 columns (every lane of the lower half holds one; the upper half holds copies)
 static __device__ __forceinline__ float quad_colsum(float v, const Quad &q) { return wave_sum(q.lane < 32 ? v : 0.f); }
 
-// ---- td3.py:277-323 for 4 batch rows per workgroup (arguments and outputs exactly as k_critic_rows / plentd3_critic_rows) ----
+// LDS activations of a critic block, per row: the gathered replay row | [s2 | target action] | t0 (512) | t1 (256) | c1 (512) | c2 (512) | dh2 (512).
+// Row stride = 16 mod 64 dwords: the four rows' 16-byte A reads of one ds_read_b128 lane group fall on 16 different bank quads.
+#define CA_BATCH 0
+#define CA_SA2 (CA_BATCH + TD3_ROW)
+#define CA_T0 (CA_SA2 + TD3_SA)
+#define CA_T1 (CA_T0 + 2 * TD3_H)
+#define CA_C1 (CA_T1 + TD3_H)
+#define CA_C2 (CA_C1 + 2 * TD3_H)
+#define CA_DH2 (CA_C2 + 2 * TD3_H)
+#define CA_LD 2448
+static_assert(CA_DH2 + 2 * TD3_H <= CA_LD && CA_LD % 64 == 16 && TD3_ROW % 4 == 0 && TD3_SA % 4 == 0, "critic block layout");
+
+// ---- td3.py:277-323 for 4 batch rows per workgroup (arguments and outputs as k_critic_rows / plentd3_critic_rows; t0, sa2 and all of t1 but the
+//      workgroup's three parked partial sums are not written: those activations never leave LDS) ----
 __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_critic_team(PlenTd3CriticRows A) {
     __shared__ float qp[4][4][QB];              // [target a, target b, critic a, critic b][wave of the half team][row]: partial heads
+    __shared__ float dql[QB][2];                // the loss gradient at the two heads, per row
+    __shared__ float noise_l[QB][32];           // the target action's clipped smoothing noise, per row (drawn beside the gather by the waves it leaves idle)
     __shared__ float team_lds[TEAM_NW][TEAM_LDS_PER_WAVE];
+    __shared__ __attribute__((aligned(16))) float act[QB * CA_LD];
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), wq = w & 3, half = w >> 2;
     const int B = A.B, b0 = blockIdx.x * QB;
     float *lds = team_lds[w];
@@ -205,10 +228,12 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
     int team_stamp_k = 1;
     if (threadIdx.x == 0 && blockIdx.x == 0) reinterpret_cast<unsigned long long *>(A.t1 + TD3_H + 8)[0] = __builtin_readcyclecounter();
 #endif
-    // ---- sample the block's 4 rows of the replay ring (td3.py:166-193; same draw as k_sample_gather) and gather them: one row per wave 0..3 ----
-    if (w < QB && b0 + w < B) {
+    // ---- sample the block's 4 rows of the replay ring (td3.py:166-193; same draw as k_sample_gather) and gather them: one row per wave 0..3
+    //      (a row past the end of the batch repeats the last one in LDS -- finite inputs for the block's unused rows -- and is not stored) ----
+    if (w < QB) {
         QPHASE();
-        const int b = b0 + w;
+        const int b = min(b0 + w, B - 1);
+        const bool inside = b0 + w < B;
         const int64_t tot = A.total[0];
         int64_t filled, start;
         if (tot + A.guard <= A.capacity) { filled = tot; start = 0; }
@@ -220,48 +245,46 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
         const int64_t id = (start + i) % A.capacity;
         const float *src = A.data + (size_t)id * TD3_ROW;
         const float v0 = src[lane], v1 = lane < TD3_ROW - 64 ? src[64 + lane] : 0.f;
-        float *dst = A.batch + (size_t)b * TD3_ROW;
-        dst[lane] = v0;
-        if (lane < TD3_ROW - 64) dst[64 + lane] = v1;
-        if (lane < TD3_S) A.sa_pi[(size_t)b * TD3_SA + lane] = v0;
-        if (lane >= TD3_SA) A.sa2[(size_t)b * TD3_SA + lane - TD3_SA] = v0;                  // s2 = columns 44..69 of the row: 44..63 here,
-        if (lane < TD3_SA + TD3_S - 64) A.sa2[(size_t)b * TD3_SA + 64 - TD3_SA + lane] = v1;  // 64..69 there
+        float *al = act + w * CA_LD;
+        al[CA_BATCH + lane] = v0;
+        if (lane < TD3_ROW - 64) al[CA_BATCH + 64 + lane] = v1;
+        if (lane >= TD3_SA) al[CA_SA2 + lane - TD3_SA] = v0;                  // s2 = columns 44..69 of the row: 44..63 here,
+        if (lane < TD3_SA + TD3_S - 64) al[CA_SA2 + 64 - TD3_SA + lane] = v1;  // 64..69 there
+        if (inside) {
+            float *dst = A.batch + (size_t)b * TD3_ROW;
+            dst[lane] = v0;
+            if (lane < TD3_ROW - 64) dst[64 + lane] = v1;
+            if (lane < TD3_S) A.sa_pi[(size_t)b * TD3_SA + lane] = v0;
+        }
+    } else {
+        QPHASE();
+        const int i = w - QB;
+        if (lane < TD3_A) noise_l[i][lane] = fminf(fmaxf(rng_normal(A.rng, 1u, (uint32_t)(min(b0 + i, B - 1) * TD3_A + lane)) * A.sigma, -A.clip), A.clip);    // torch.randn_like(action), td3.py:300
     }
     TEAM_SYNC();
-    const size_t Bz = (size_t)B;
-    const rsrc_t r_batch = mkrs(A.batch, Bz * TD3_ROW * 4), r_t0 = mkrs(A.t0, Bz * 2 * TD3_H * 4), r_t1 = mkrs(A.t1, Bz * 2 * TD3_H * 4), r_sa2 = mkrs(A.sa2, Bz * TD3_SA * 4);
-    const rsrc_t r_c1 = mkrs(A.c1, Bz * 2 * TD3_H * 4);
     // gathered rows: s 0..25 | a 26..43 | s2 44..69 | r 70 | not_done 71
     // ---- target actor's first layer on s2 (32 columns per wave) and, independent of it, the critics' stacked first layers on (s, a) (64 per wave) ----
     {
         QPHASE();
-        quad_dense_relu<true, 1>(r_batch, TD3_ROW, TD3_SA, TD3_S, mkrs(A.at_w1, (size_t)TD3_H * TD3_S * 4), TD3_S, A.at_b1, 32 * w, A.t0, 2 * TD3_H, q, lds);
+        quad_dense_relu<true, 1>(act + CA_BATCH + TD3_SA, CA_LD, TD3_S, mkrs(A.at_w1, (size_t)TD3_H * TD3_S * 4), TD3_S, A.at_b1, 32 * w, act + CA_T0, CA_LD, nullptr, 0, q, lds);
         const rsrc_t rw = mkrs(A.c_w14, (size_t)2 * TD3_H * TD3_SA * 4);
 #pragma unroll 1
-        for (int t = 0; t < 2; t++) quad_dense_relu<true, 1>(r_batch, TD3_ROW, 0, TD3_SA, rw, TD3_SA, A.c_b14, 64 * w + 32 * t, A.c1, 2 * TD3_H, q, lds);
+        for (int t = 0; t < 2; t++) quad_dense_relu<true, 1>(act + CA_BATCH, CA_LD, TD3_SA, rw, TD3_SA, A.c_b14, 64 * w + 32 * t, act + CA_C1, CA_LD, A.c1, 2 * TD3_H, q, lds);
     }
     TEAM_SYNC();
     {
         QPHASE();
-        quad_dense_relu<false, 4>(r_t0, 2 * TD3_H, 0, TD3_H, mkrs(A.at_w2, (size_t)TD3_H * TD3_H * 4), TD3_H, A.at_b2, 32 * w, A.t1, 2 * TD3_H, q, lds);
+        quad_dense_relu<false, 4>(act + CA_T0, CA_LD, TD3_H, mkrs(A.at_w2, (size_t)TD3_H * TD3_H * 4), TD3_H, A.at_b2, 32 * w, act + CA_T1, CA_LD, nullptr, 0, q, lds);
     }
     TEAM_SYNC();
     // ---- target action (td3.py:299-304): the 18-wide output layer is one tile: wave 0 ----
     if (w == 0) {
         QPHASE();
-        // the smoothing noise of this lane's four actions and the output bias: drawn / requested before the product
-        float noise[4] = {0.f, 0.f, 0.f, 0.f}, bv3 = 0.f;
-        if (col < TD3_A) {
-            bv3 = A.at_b3[col];
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                noise[i] = fminf(fmaxf(rng_normal(A.rng, 1u, (uint32_t)(min(b0 + i, B - 1) * TD3_A + col)) * A.sigma, -A.clip), A.clip);       // torch.randn_like(action), td3.py:300
-        }
-        const floatx4 z = quad_nt<false, 4>(r_t1, 2 * TD3_H, 0, mkrs(A.at_w3, (size_t)TD3_A * TD3_H * 4), TD3_H, 0, TD3_H, q, lds);
+        const float bv3 = col < TD3_A ? A.at_b3[col] : 0.f;
+        const floatx4 z = quad_nt<false, 4>(act + CA_T1, CA_LD, mkrs(A.at_w3, (size_t)TD3_A * TD3_H * 4), TD3_H, 0, TD3_H, q, lds);
         if (lane < TD3_A) {
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                if (b0 + i < B) A.sa2[(size_t)(b0 + i) * TD3_SA + TD3_S + col] = fminf(fmaxf(A.max_a * tanhf(z[i] + bv3) + noise[i], -A.max_a), A.max_a);
+            for (int i = 0; i < 4; i++) act[i * CA_LD + CA_SA2 + TD3_S + col] = fminf(fmaxf(A.max_a * tanhf(z[i] + bv3) + noise_l[i][col], -A.max_a), A.max_a);
         }
     }
     TEAM_SYNC();
@@ -270,10 +293,10 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
         QPHASE();
         const rsrc_t rw = mkrs(A.ct_w14, (size_t)2 * TD3_H * TD3_SA * 4);
 #pragma unroll 1
-        for (int t = 0; t < 2; t++) quad_dense_relu<true, 1>(r_sa2, TD3_SA, 0, TD3_SA, rw, TD3_SA, A.ct_b14, 64 * w + 32 * t, A.t0, 2 * TD3_H, q, lds);
+        for (int t = 0; t < 2; t++) quad_dense_relu<true, 1>(act + CA_SA2, CA_LD, TD3_SA, rw, TD3_SA, A.ct_b14, 64 * w + 32 * t, act + CA_T0, CA_LD, nullptr, 0, q, lds);
     }
     TEAM_SYNC();
-    // ---- second layers + heads: waves 0..3 = critic a, 4..7 = critic b, 64 columns each; target critics, then the critics themselves (c2 stored) ----
+    // ---- second layers + heads: waves 0..3 = critic a, 4..7 = critic b, 64 columns each; target critics, then the critics themselves (c2 kept) ----
     {
         QPHASE();
 #pragma unroll 1
@@ -286,10 +309,10 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
             for (int t = 0; t < 2; t++) {
                 const int n0 = 64 * wq + 32 * t;
                 const float bv = b2[n0 + col], wv = w3[n0 + col];
-                floatx4 acc = quad_nt<false, 4>(k ? r_c1 : r_t0, 2 * TD3_H, half * TD3_H, rw, TD3_H, n0, TD3_H, q, lds);
+                floatx4 acc = quad_nt<false, 4>(act + (k ? CA_C1 : CA_T0) + half * TD3_H, CA_LD, rw, TD3_H, n0, TD3_H, q, lds);
 #pragma unroll
                 for (int i = 0; i < 4; i++) { acc[i] = fmaxf(acc[i] + bv, 0.f); part[i] += acc[i] * wv; }
-                if (k) quad_store(A.c2, 2 * TD3_H, half * TD3_H + n0, acc, q);
+                if (k) quad_store(act + CA_C2, CA_LD, A.c2, 2 * TD3_H, half * TD3_H + n0, acc, q);
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -306,12 +329,13 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
         const int b = b0 + lane;
         if (lane < QB && b < B) {
             auto head = [&](int k, const float *b3) { return ((qp[k][0][lane] + qp[k][1][lane]) + (qp[k][2][lane] + qp[k][3][lane])) + b3[0]; };
-            const float *row = A.batch + (size_t)b * TD3_ROW;
+            const float *row = act + lane * CA_LD + CA_BATCH;
             const float y = row[TD3_ROW - 2] + row[TD3_ROW - 1] * A.gamma * fminf(head(0, A.ct_b3), head(1, A.ct_b6));
             const float inv = 1.f / (float)B;
             const float ea = head(2, A.c_b3) - y, eb = head(3, A.c_b6) - y;
             ga = 2.f * ea * inv; gb = 2.f * eb * inv;
             A.dq[2 * b] = ga; A.dq[2 * b + 1] = gb;
+            dql[lane][0] = ga; dql[lane][1] = gb;
             lsum = ea * ea * inv + eb * eb * inv;
         }
         lsum = wave_sum(lsum); ga = wave_sum(ga); gb = wave_sum(gb);
@@ -322,31 +346,31 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
     }
     TEAM_SYNC();
     // ---- dh2 = dq (x) w3 where the hidden unit was active: wave = (row, critic), 4 columns per lane ----
-    if (b0 + wq < B) {
+    {
         QPHASE();
-        const int b = b0 + wq, c = half;
+        const int c = half;
         const floatx4 wv = *reinterpret_cast<const floatx4 *>((c ? A.c_w6 : A.c_w3) + 4 * lane);
-        const float d = A.dq[2 * b + c];
-        const size_t o = (size_t)b * 2 * TD3_H + c * TD3_H + 4 * lane;
-        const floatx4 h = *reinterpret_cast<const floatx4 *>(A.c2 + o);
+        const float d = b0 + wq < B ? dql[wq][c] : 0.f;
+        float *al = act + wq * CA_LD;
+        const floatx4 h = *reinterpret_cast<const floatx4 *>(al + CA_C2 + c * TD3_H + 4 * lane);
         floatx4 dv;
 #pragma unroll
         for (int j = 0; j < 4; j++) dv[j] = h[j] > 0.f ? d * wv[j] : 0.f;
-        *reinterpret_cast<floatx4 *>(A.dh2 + o) = dv;
+        *reinterpret_cast<floatx4 *>(al + CA_DH2 + c * TD3_H + 4 * lane) = dv;
+        if (b0 + wq < B) *reinterpret_cast<floatx4 *>(A.dh2 + (size_t)(b0 + wq) * 2 * TD3_H + c * TD3_H + 4 * lane) = dv;
     }
     TEAM_SYNC();
     // ---- dh1_c = (dh2_c W2_c) where c1_c was active: half a team per critic, 64 columns per wave ----
     {
         QPHASE();
-        const rsrc_t r_dh2 = mkrs(A.dh2, Bz * 2 * TD3_H * 4);
         const rsrc_t rw = mkrs(half ? A.c_w5 : A.c_w2, (size_t)TD3_H * TD3_H * 4);
 #pragma unroll 1
         for (int t = 0; t < 2; t++) {
             const int j0 = 64 * wq + 32 * t, oc = half * TD3_H + j0;
-            floatx4 acc = quad_nn<false, 4>(r_dh2, 2 * TD3_H, half * TD3_H, rw, TD3_H, j0, TD3_H, q, lds);
+            floatx4 acc = quad_nn<false, 4>(act + CA_DH2 + half * TD3_H, CA_LD, rw, TD3_H, j0, TD3_H, q);
 #pragma unroll
-            for (int i = 0; i < 4; i++) acc[i] = A.c1[(size_t)min(b0 + i, B - 1) * 2 * TD3_H + oc + col] > 0.f ? acc[i] : 0.f;
-            quad_store(A.dh1, 2 * TD3_H, oc, acc, q);
+            for (int i = 0; i < 4; i++) acc[i] = act[i * CA_LD + CA_C1 + oc + col] > 0.f ? acc[i] : 0.f;
+            quad_store(nullptr, 0, A.dh1, 2 * TD3_H, oc, acc, q);
         }
     }
     // the last workgroup to finish adds up the partial sums and advances the random stream's call counter: every wave has read it by then
@@ -371,45 +395,62 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
 
 #ifdef TEAM_STAMPS            // (stamps exist in the critic kernel only)
 #undef TEAM_SYNC
-#define TEAM_SYNC() __syncthreads()
+#define TEAM_SYNC() TEAM_LDS_BARRIER()
 #endif
-// ---- td3.py:334-341 for 4 batch rows per workgroup (arguments and outputs exactly as k_policy_rows / plentd3_policy_rows): 32 columns per wave ----
+// LDS activations of a policy block, per row: [s | a] | p1 | p2 | g1 | dg2 | dg1 | dz (18 + 2) | dp2
+#define PA_SA 0
+#define PA_P1 (PA_SA + TD3_SA)
+#define PA_P2 (PA_P1 + TD3_H)
+#define PA_G1 (PA_P2 + TD3_H)
+#define PA_DG2 (PA_G1 + TD3_H)
+#define PA_DG1 (PA_DG2 + TD3_H)
+#define PA_DZ (PA_DG1 + TD3_H)
+#define PA_DP2 (PA_DZ + 20)
+#define PA_LD 1616
+static_assert(PA_DP2 + TD3_H <= PA_LD && PA_LD % 64 == 16, "policy block layout");
+
+// ---- td3.py:334-341 for 4 batch rows per workgroup (arguments and outputs as k_policy_rows / plentd3_policy_rows; g1, dg2, dg1 are not written:
+//      they never leave LDS): 32 columns per wave ----
 __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_policy_team(PlenTd3PolicyRows A) {
     __shared__ float team_lds[TEAM_NW][TEAM_LDS_PER_WAVE];
+    __shared__ __attribute__((aligned(16))) float act[QB * PA_LD];
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int B = A.B, b0 = blockIdx.x * QB;
-    const size_t Bz = (size_t)B;
     float *lds = team_lds[w];
-    const rsrc_t r_sa = mkrs(A.sa_pi, Bz * TD3_SA * 4), r_p1 = mkrs(A.p1, Bz * TD3_H * 4), r_p2 = mkrs(A.p2, Bz * TD3_H * 4), r_g1 = mkrs(A.g1, Bz * TD3_H * 4);
-    const rsrc_t r_dg2 = mkrs(A.dg2, Bz * TD3_H * 4), r_dg1 = mkrs(A.dg1, Bz * TD3_H * 4), r_dp2 = mkrs(A.dp2, Bz * TD3_H * 4);
-    const rsrc_t r_dz = mkrs(A.dz, Bz * TD3_A * 4);
     const int n0 = 32 * w;
-    // masked by the forward activation H (> 0) and stored
-    auto store_masked = [&](floatx4 acc, const float *H, float *Y, const Quad &q) {
+    // masked by the forward activation (> 0, at LDS offset hoff of each row) and stored (LDS offset loff, or none: -1) / to global Y
+    auto store_masked = [&](floatx4 acc, int hoff, int loff, float *Y, const Quad &q) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) acc[i] = H[(size_t)min(b0 + i, B - 1) * TD3_H + n0 + q.col] > 0.f ? acc[i] : 0.f;
-        quad_store(Y, TD3_H, n0, acc, q);
+        for (int i = 0; i < 4; i++) acc[i] = act[i * PA_LD + hoff + n0 + q.col] > 0.f ? acc[i] : 0.f;
+        quad_store(loff >= 0 ? act + loff : nullptr, PA_LD, Y, TD3_H, n0, acc, q);
     };
-    // actor forward: s = state columns of sa_pi (left there by the critic pass)
+    // the block's states: the state columns of sa_pi (left there by the critic pass: an earlier launch); rows past the batch repeat the last one
+    if (w < QB) {
+        QPHASE();
+        if (lane < TD3_S) act[w * PA_LD + PA_SA + lane] = A.sa_pi[(size_t)min(b0 + w, B - 1) * TD3_SA + lane];
+    }
+    TEAM_SYNC();
+    // actor forward
     {
         QPHASE();
-        quad_dense_relu<true, 1>(r_sa, TD3_SA, 0, TD3_S, mkrs(A.a_w1, (size_t)TD3_H * TD3_S * 4), TD3_S, A.a_b1, n0, A.p1, TD3_H, q, lds);
+        quad_dense_relu<true, 1>(act + PA_SA, PA_LD, TD3_S, mkrs(A.a_w1, (size_t)TD3_H * TD3_S * 4), TD3_S, A.a_b1, n0, act + PA_P1, PA_LD, A.p1, TD3_H, q, lds);
     }
     TEAM_SYNC();
     {
         QPHASE();
-        quad_dense_relu<false, 4>(r_p1, TD3_H, 0, TD3_H, mkrs(A.a_w2, (size_t)TD3_H * TD3_H * 4), TD3_H, A.a_b2, n0, A.p2, TD3_H, q, lds);
+        quad_dense_relu<false, 4>(act + PA_P1, PA_LD, TD3_H, mkrs(A.a_w2, (size_t)TD3_H * TD3_H * 4), TD3_H, A.a_b2, n0, act + PA_P2, PA_LD, A.p2, TD3_H, q, lds);
     }
     TEAM_SYNC();
     if (w == 0) {
         QPHASE();
         const float bv = col < TD3_A ? A.a_b3[col] : 0.f;
-        const floatx4 z = quad_nt<false, 4>(r_p2, TD3_H, 0, mkrs(A.a_w3, (size_t)TD3_A * TD3_H * 4), TD3_H, 0, TD3_H, q, lds);
+        const floatx4 z = quad_nt<false, 4>(act + PA_P2, PA_LD, mkrs(A.a_w3, (size_t)TD3_A * TD3_H * 4), TD3_H, 0, TD3_H, q, lds);
         if (lane < TD3_A) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
+                const float a = A.max_a * tanhf(z[i] + bv);                                   // td3.py:57
+                act[i * PA_LD + PA_SA + TD3_S + col] = a;
                 if (b0 + i < B) {
-                    const float a = A.max_a * tanhf(z[i] + bv);                                   // td3.py:57
                     A.a_pi[(size_t)(b0 + i) * TD3_A + col] = a;
                     A.sa_pi[(size_t)(b0 + i) * TD3_SA + TD3_S + col] = a;
                 }
@@ -420,35 +461,35 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
     // critic.Q1 forward (fc1 = the first 256 rows of W14) and the gradient of -mean Q1 at its second hidden layer: dg2 = -(1/B) w3 (g2 > 0)
     {
         QPHASE();
-        quad_dense_relu<true, 1>(r_sa, TD3_SA, 0, TD3_SA, mkrs(A.c_w1, (size_t)TD3_H * TD3_SA * 4), TD3_SA, A.c_b1, n0, A.g1, TD3_H, q, lds);
+        quad_dense_relu<true, 1>(act + PA_SA, PA_LD, TD3_SA, mkrs(A.c_w1, (size_t)TD3_H * TD3_SA * 4), TD3_SA, A.c_b1, n0, act + PA_G1, PA_LD, nullptr, 0, q, lds);
     }
     TEAM_SYNC();
     {
         QPHASE();
         const float bv = A.c_b2[n0 + col], wv = (-1.f / (float)B) * A.c_w3[n0 + col];
-        floatx4 acc = quad_nt<false, 4>(r_g1, TD3_H, 0, mkrs(A.c_w2, (size_t)TD3_H * TD3_H * 4), TD3_H, n0, TD3_H, q, lds);
+        floatx4 acc = quad_nt<false, 4>(act + PA_G1, PA_LD, mkrs(A.c_w2, (size_t)TD3_H * TD3_H * 4), TD3_H, n0, TD3_H, q, lds);
 #pragma unroll
         for (int i = 0; i < 4; i++) acc[i] = acc[i] + bv > 0.f ? wv : 0.f;
-        quad_store(A.dg2, TD3_H, n0, acc, q);
+        quad_store(act + PA_DG2, PA_LD, nullptr, 0, n0, acc, q);
     }
     TEAM_SYNC();
     // dg1 = (dg2 W2)(g1 > 0)
     {
         QPHASE();
-        store_masked(quad_nn<false, 4>(r_dg2, TD3_H, 0, mkrs(A.c_w2, (size_t)TD3_H * TD3_H * 4), TD3_H, n0, TD3_H, q, lds), A.g1, A.dg1, q);
+        store_masked(quad_nn<false, 4>(act + PA_DG2, PA_LD, mkrs(A.c_w2, (size_t)TD3_H * TD3_H * 4), TD3_H, n0, TD3_H, q), PA_G1, PA_DG1, nullptr, q);
     }
     TEAM_SYNC();
     // d/d action = (dg1 W1)[:, 26:44], through the tanh: dz = that * (max_a - a^2 / max_a): one tile, wave 0
     if (w == 0) {
         QPHASE();
-        const floatx4 z = quad_nn<false, 4>(r_dg1, TD3_H, 0, mkrs(A.c_w1, (size_t)TD3_H * TD3_SA * 4), TD3_SA, TD3_S, TD3_H, q, lds);
+        const floatx4 z = quad_nn<false, 4>(act + PA_DG1, PA_LD, mkrs(A.c_w1, (size_t)TD3_H * TD3_SA * 4), TD3_SA, TD3_S, TD3_H, q);
         if (lane < TD3_A) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                if (b0 + i < B) {
-                    const float a = A.a_pi[(size_t)(b0 + i) * TD3_A + col];
-                    A.dz[(size_t)(b0 + i) * TD3_A + col] = z[i] * (A.max_a - a * a / A.max_a);
-                }
+                const float a = act[i * PA_LD + PA_SA + TD3_S + col];
+                const float dz = z[i] * (A.max_a - a * a / A.max_a);
+                act[i * PA_LD + PA_DZ + col] = dz;
+                if (b0 + i < B) A.dz[(size_t)(b0 + i) * TD3_A + col] = dz;
             }
         }
     }
@@ -456,11 +497,11 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
     // back through the actor: dp2 = (dz W3)(p2 > 0), dp1 = (dp2 W2)(p1 > 0)
     {
         QPHASE();
-        store_masked(quad_nn<true, 1>(r_dz, TD3_A, 0, mkrs(A.a_w3, (size_t)TD3_A * TD3_H * 4), TD3_H, n0, TD3_A, q, lds), A.p2, A.dp2, q);
+        store_masked(quad_nn<true, 1>(act + PA_DZ, PA_LD, mkrs(A.a_w3, (size_t)TD3_A * TD3_H * 4), TD3_H, n0, TD3_A, q), PA_P2, PA_DP2, A.dp2, q);
     }
     TEAM_SYNC();
     {
         QPHASE();
-        store_masked(quad_nn<false, 4>(r_dp2, TD3_H, 0, mkrs(A.a_w2, (size_t)TD3_H * TD3_H * 4), TD3_H, n0, TD3_H, q, lds), A.p1, A.dp1, q);
+        store_masked(quad_nn<false, 4>(act + PA_DP2, PA_LD, mkrs(A.a_w2, (size_t)TD3_H * TD3_H * 4), TD3_H, n0, TD3_H, q), PA_P1, -1, A.dp1, q);
     }
 }
