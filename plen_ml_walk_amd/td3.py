@@ -152,6 +152,13 @@ class ReplayBuffer(object):
         else:
             self.ptr = (self.ptr + n) % self.max_size
 
+    def size_on_device(self):
+        """Number of valid rows as an int64 device scalar (what the in-kernel sampling of the fused update reads; refreshed when the size changed)."""
+        if getattr(self, "_size_dev", None) is None or self._size_dev_host != self.size:
+            self._size_dev = torch.tensor(self.size, dtype=torch.long, device=self.device)
+            self._size_dev_host = self.size
+        return self._size_dev
+
     # -- reads ----------------------------------------------------------------------------
     def sample(self, batch_size, ind=None):
         """Uniform with replacement (reference: np.random.randint(0, len, size=B), td3.py:175).
@@ -258,6 +265,11 @@ class _FlatGrads(object):
         self.flat.zero_()
         self.dirty = False
 
+    def will_reduce(self):
+        """Does all_reduce_mean() issue a collective in this process (several ranks, or the forced one-rank collective)?"""
+        import torch.distributed as dist
+        return bool(self.data_parallel and dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("PLEN_TD3_FORCE_COLLECTIVES") == "1"))
+
     def all_reduce_mean(self):
         import torch.distributed as dist
         # PLEN_TD3_FORCE_COLLECTIVES=1: issue the collective at world size 1 too (one-GPU boxes: exercises RCCL's init, stream ordering and
@@ -350,6 +362,8 @@ class TD3Agent(object):
         self.noise_clip = noise_clip
         self.policy_freq = policy_freq
         self.total_it = 0
+        self.fused_train = None      # train(): None = fused iteration where possible (PLEN_TD3_FUSED_TRAIN=0 turns it off), False = always the autograd iteration
+        self._fused = None
         self.last_critic_loss = None
         self.last_actor_loss = None
 
@@ -375,10 +389,40 @@ class TD3Agent(object):
 
     # ---- learning -----------------------------------------------------------------------
     def train(self, replay_buffer, batch_size=100):
-        """One TD3 iteration, reference td3.py:259-356 (same order of operations and RNG call)."""
+        """One TD3 iteration, reference td3.py:259-356.
+
+        On a HIP device with this module's device-resident ReplayBuffer the iteration is the hand-fused one (td3_fused.FusedTD3.update: for the
+        reference's batch 100 three launches per critic update and two more per policy update instead of ~170, csrc/td3_team.hip) -- same
+        arithmetic, with the replay indices and the target-smoothing noise drawn inside the kernels from the agent's counter-based stream instead of
+        torch's / NumPy's generators.  The autograd iteration (td3_update: same order of operations and RNG calls as the reference) runs
+        wherever that is not possible or not wanted: on the CPU, with `fused_train = False` or PLEN_TD3_FUSED_TRAIN=0, with PLEN_TD3_NUMPY_RNG=1,
+        or when the buffer's `sample` is not this module's own (a subclass or an instance override: the caller's sampling is honoured)."""
         self.total_it += 1
+        with_policy = self.total_it % self.policy_freq == 0
+        fz = self._fused_for(replay_buffer)
+        if fz is not None:
+            self.last_critic_loss = fz.update(replay_buffer.data, int(batch_size), with_policy, all_reduce=self._critic_grads.will_reduce(),
+                                              total=replay_buffer.size_on_device())
+            return
         batch = replay_buffer.sample(batch_size)
-        td3_update(self, batch, with_policy=self.total_it % self.policy_freq == 0)
+        td3_update(self, batch, with_policy=with_policy)
+
+    def _fused_for(self, replay_buffer):
+        """The FusedTD3 behind train() (created on first use), or None where train() has to take the autograd iteration."""
+        if self.fused_train is False or (self.fused_train is None and os.environ.get("PLEN_TD3_FUSED_TRAIN", "1") != "1"):
+            return None
+        if self.device.type != "cuda" or os.environ.get("PLEN_TD3_NUMPY_RNG") == "1":
+            return None
+        if not (isinstance(replay_buffer, ReplayBuffer) and type(replay_buffer).sample is ReplayBuffer.sample and "sample" not in vars(replay_buffer)):
+            return None
+        data = getattr(replay_buffer, "data", None)
+        if data is None or data.device != self.device or data.dtype != torch.float32 or data.dim() != 2 or data.shape[1] != 72 or replay_buffer.size < 1:
+            return None
+        if self._fused is None:
+            from .td3_fused import FusedTD3
+            self._fused = FusedTD3(self, seed=int(torch.initial_seed()) & 0x7fffffff)
+            self._fused.enable_flat_adam()
+        return self._fused
 
     # ---- checkpoints: the reference's four files per checkpoint (td3.py:358-376) -----------------
     def save(self, filename):

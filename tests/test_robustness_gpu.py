@@ -416,6 +416,59 @@ def test_adam_step_inside_the_weight_gradient_kernel_equals_the_separate_step():
         assert torch.equal(a_, b_)
 
 
+def test_agent_train_takes_the_fused_iteration_on_the_device_and_honours_a_callers_sampling(tmp_path):
+    """TD3Agent.train(replay_buffer, 100) -- the reference's call, plen_td3.py:119-120 -- on a HIP device with the device-resident ReplayBuffer runs the
+    fused small-batch update (td3.py:259-356's arithmetic; indices and smoothing noise from the agent's Philox stream): step counts, Polyak cadence and
+    checkpoints behave as with the autograd iteration; an overridden `sample` (instance or subclass) or fused_train = False takes the autograd path."""
+    from plen_ml_walk_amd import td3 as T
+    torch.manual_seed(3)
+    a = T.TD3Agent(26, 18, 1.0, data_parallel=False)
+    buf = T.ReplayBuffer(5000)
+    buf.add_batch(torch.randn(600, 26), torch.rand(600, 18) * 2 - 1, torch.randn(600, 26), torch.randn(600), (torch.rand(600) < 0.05).float())
+    p0 = a._critic_flat.flat.clone(); q0 = a._actor_flat.flat.clone(); t0 = a._actor_target_flat.flat.clone()
+    a.train(buf, 100)
+    assert a._fused is not None and "critic" in a._fused._fused_done and a._fused._team_pass
+    torch.cuda.synchronize()
+    assert torch.isfinite(a.last_critic_loss) and not torch.equal(p0, a._critic_flat.flat)
+    assert torch.equal(q0, a._actor_flat.flat) and torch.equal(t0, a._actor_target_flat.flat)          # iteration 1: no policy update, no Polyak step
+    a.train(buf, 100)
+    torch.cuda.synchronize()
+    assert not torch.equal(q0, a._actor_flat.flat) and not torch.equal(t0, a._actor_target_flat.flat) and a.total_it == 2
+    for _ in range(4):
+        a.train(buf, 100)
+    sd_c, sd_a = a.critic_optimizer.state_dict(), a.actor_optimizer.state_dict()
+    assert float(next(iter(sd_c["state"].values()))["step"]) == 6.0 and float(next(iter(sd_a["state"].values()))["step"]) == 3.0
+    # checkpoints round-trip (td3.py:358-376's four files) and training continues from them
+    a.save(str(tmp_path / "ck"))
+    b = T.TD3Agent(26, 18, 1.0, data_parallel=False)
+    b.load(str(tmp_path / "ck"))
+    assert torch.equal(a._critic_flat.flat, b._critic_flat.flat) and torch.equal(a._actor_flat.flat, b._actor_flat.flat)
+    b.train(buf, 100)
+    torch.cuda.synchronize()
+    assert float(next(iter(b.critic_optimizer.state_dict()["state"].values()))["step"]) == 7.0
+    # a caller's own sampling is honoured: the autograd iteration runs on the batch it returns
+    seen = []
+    real = buf.sample
+    buf.sample = lambda bs, ind=None: (seen.append(bs), real(bs, ind))[1]
+    n_before = int(a._fused.rng[1])
+    a.train(buf, 100)
+    assert seen == [100] and int(a._fused.rng[1]) == n_before
+    del buf.sample
+
+    class Mine(T.ReplayBuffer):
+        def sample(self, batch_size, ind=None):
+            seen.append(-batch_size)
+            return super().sample(batch_size, ind)
+    mine = Mine(1000)
+    mine.add_batch(torch.randn(300, 26), torch.rand(300, 18) * 2 - 1, torch.randn(300, 26), torch.randn(300), torch.zeros(300))
+    a.train(mine, 64)
+    assert seen[-1] == -64 and int(a._fused.rng[1]) == n_before
+    a.fused_train = False
+    a.train(buf, 100)
+    torch.cuda.synchronize()
+    assert int(a._fused.rng[1]) == n_before and torch.isfinite(a.last_critic_loss)
+
+
 def test_small_batch_update_keeps_its_scratch_rows_inside_the_batch():
     """Canary rows behind every per-iteration scratch matrix of a team-path update at B = 100 (16-row blocks: the last one is ragged) stay untouched."""
     from plen_ml_walk_amd import td3 as T
