@@ -469,6 +469,30 @@ def test_agent_train_takes_the_fused_iteration_on_the_device_and_honours_a_calle
     assert int(a._fused.rng[1]) == n_before and torch.isfinite(a.last_critic_loss)
 
 
+def test_single_transition_add_and_one_kernel_select_action_equal_the_general_paths(golden_dir):
+    """The drop-in loop's per-step calls on a HIP device: ReplayBuffer.add (one packed row, one copy) writes what add_batch writes, ring wrap included;
+    TD3Agent.select_action (one kernel, pinned buffers) returns the torch layers' action on the reference's shipped policy to f32 summation order."""
+    from plen_ml_walk_amd import td3 as T
+    rng = np.random.default_rng(5)
+    a_buf, b_buf = T.ReplayBuffer(7), T.ReplayBuffer(7)
+    for k in range(17):                                   # more than the capacity: the ring wraps twice
+        s_, a_, s2 = rng.normal(size=26), rng.uniform(-1, 1, 18).astype(np.float32), rng.normal(size=26)
+        r, d = np.float64(rng.normal()), float(k % 5 == 0)
+        a_buf.add((s_, a_, s2, r, d))
+        t = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float32)).reshape(1, -1)
+        b_buf.add_batch(t(s_), t(a_), t(s2), t(r), t(d))
+        assert (a_buf.size, a_buf.ptr) == (b_buf.size, b_buf.ptr)
+    assert torch.equal(a_buf.data, b_buf.data) and len(a_buf.storage) == 7
+    ag = T.TD3Agent(26, 18, 1.0, data_parallel=False)
+    ag.load_arrays(np.load(os.path.join(golden_dir, "policy_3229999.npz")))
+    obs = rng.normal(size=(64, 26)) * np.array([1.0] * 18 + [0.1, 0.3, 0.3, 0.3, 0.3, 0.3, 1.0, 1.0])
+    fast = np.stack([ag.select_action(o) for o in obs])
+    assert ag._select_state is not None and fast.dtype == np.float32 and fast.shape == (64, 18)
+    ag.fused_select = False
+    slow = np.stack([ag.select_action(o) for o in obs])
+    assert np.abs(fast - slow).max() <= 1e-4 and np.abs(slow).max() > 0.1          # (the shipped policy's pre-activations are O(10): 3e-5 observed)
+
+
 def test_small_batch_update_keeps_its_scratch_rows_inside_the_batch():
     """Canary rows behind every per-iteration scratch matrix of a team-path update at B = 100 (16-row blocks: the last one is ragged) stay untouched."""
     from plen_ml_walk_amd import td3 as T
