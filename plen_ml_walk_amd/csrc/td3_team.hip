@@ -24,11 +24,11 @@
 // together touch 16 different cache lines and a 1 KB wave load costs 64 tag look-ups instead of 8 -- with 8 waves per compute unit the look-up rate
 // WAS the kernel's speed (stamps: 28 k cycles for a 256 x 256 layer against 8 k of matrix-core time).  So a stage's 32 rows x 64 k of W are loaded as
 // whole 256-byte row segments per 16 lanes, parked in the wave's private LDS (chunks permuted by the row, so that the reads are free of bank
-// conflicts) and read back as the 16 bytes per lane the MFMAs consume.  The four activation rows need no staging: the MFMA's block broadcast
-// (CBSZ / ABID) hands one block's A values to all blocks of a half, so a single coalesced 16-byte load per lane feeds a whole stage.
+// conflicts) and read back as the 16 bytes per lane the MFMAs consume.  The four activation rows need no staging or replication: the MFMA's block
+// broadcast (CBSZ / ABID) hands one block's A values to all blocks of a half, so ONE 16-byte read per lane (from the block's LDS activations) feeds a whole stage.
 //
-// Sums: every dot product adds its k values in ascending order per (k % 4, half) class, then the four classes, then the two halves; the critics' scalar heads add per-wave partial
-// sums in wave order; loss and head-bias gradients add per-workgroup partials in workgroup order.  Nothing depends on timing: same bits every run.
+// Sums: every dot product adds its k values in ascending order per (k % 4, half) class, then the four classes, then the two halves; the critics'
+// scalar heads add per-wave partial sums in wave order; loss and head-bias gradients add per-workgroup partials in workgroup order.  Nothing depends on timing: same bits every run.
 
 #define TEAM_NW 8
 #define QB 4                                   // batch rows per workgroup

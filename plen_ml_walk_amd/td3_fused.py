@@ -308,8 +308,10 @@ class FusedTD3(object):
         fuse = flat and self.fuse_adam and not all_reduce         # (with ranks to average over, the gradients have to exist in the bucket)
         self._fused_done = set()
         self._fuse = {"critic": ag._critic_target_flat.flat if with_policy else None} if fuse else None
-        loss = self.critic_backward(data, idx, noise, total, guard)
-        self._fuse = None
+        try:
+            loss = self.critic_backward(data, idx, noise, total, guard)
+        finally:
+            self._fuse = None            # (consent to the in-kernel Adam step never outlives the pass it was given for)
         if all_reduce:
             ag._critic_grads.all_reduce_mean()
         if "critic" in self._fused_done:
@@ -322,8 +324,10 @@ class FusedTD3(object):
         ag.last_critic_loss = loss
         if with_policy:
             self._fuse = {"actor": ag._actor_target_flat.flat} if fuse else None
-            self.policy_backward()
-            self._fuse = None
+            try:
+                self.policy_backward()
+            finally:
+                self._fuse = None
             if all_reduce:
                 ag._actor_grads.all_reduce_mean()
             ag.last_actor_loss = None          # (-mean Q1 itself is not needed for the update; the autograd path reports it)
