@@ -404,6 +404,23 @@ def td3_reference_leg(a, dev, rank, world, dist, n=64, steps=400):
                           "3 launches per critic update, 2 more per policy update; same bits every run",
            "workload": "the reference's recipe (plen_td3.py:21-30, 83-157): %d envs, one update of batch 100 per env-step, policy_freq 2, hipGraph-captured fused update" % n}
     env.close()
+    # the same iteration as the reference's caller issues it: TD3Agent.train(replay_buffer, 100), eagerly from Python, one call per iteration (plen_td3.py:119-120)
+    try:
+        torch.manual_seed(1)
+        ag2 = TD3Agent(26, 18, 1.0, device=dev, data_parallel=False)
+        buf2 = ReplayBuffer(20000, device=dev)
+        buf2.add_batch(torch.randn(10000, 26), torch.rand(10000, 18) * 2 - 1, torch.randn(10000, 26), torch.randn(10000), (torch.rand(10000) < 0.02).float())
+        for _ in range(30):
+            ag2.train(buf2, 100)
+        torch.cuda.synchronize()
+        t1, calls = time.perf_counter(), 500
+        for _ in range(calls):
+            ag2.train(buf2, 100)
+        torch.cuda.synchronize()
+        out["agent_train_call"] = {"us_per_call": (time.perf_counter() - t1) / calls * 1e6, "calls": calls, "fused": ag2._fused is not None,
+                                   "what": "TD3Agent.train(replay_buffer, 100) called eagerly from Python (no graph): the drop-in surface's own call"}
+    except Exception as ex:
+        out["agent_train_call"] = {"us_per_call": None, "error": repr(ex)}
     return out
 
 

@@ -59,6 +59,7 @@ def test_bench_line_small_run_carries_every_block():
         assert d["legs"][leg].get("value"), (leg, d["legs"][leg])
     ref = d["legs"]["td3_reference"]
     assert ref["batch"] == 100 and abs(ref["updates_per_env_step"] - 1.0) < 1e-9 and ref["grad_steps_per_s"] > 100        # the reference's recipe: one batch-100 update per env-step
+    assert ref["agent_train_call"]["fused"] and 0 < ref["agent_train_call"]["us_per_call"] < 1000                      # TD3Agent.train itself takes the fused iteration
     assert d["roofline_valu"] == d["roofline"]["valu_issue"] and 0 < d["roofline_valu"]["frac_nominal_2cycle"] < 1
     assert d["timed_region"]["seconds_total"] >= 2.0
     cl = d["pybullet_pin"]["closed_loop"]
