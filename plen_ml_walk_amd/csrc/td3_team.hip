@@ -263,13 +263,10 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
     }
     TEAM_SYNC();
     // gathered rows: s 0..25 | a 26..43 | s2 44..69 | r 70 | not_done 71
-    // ---- target actor's first layer on s2 (32 columns per wave) and, independent of it, the critics' stacked first layers on (s, a) (64 per wave) ----
+    // ---- target actor's first layer on s2 (32 columns per wave) ----
     {
         QPHASE();
         quad_dense_relu<true, 1>(act + CA_BATCH + TD3_SA, CA_LD, TD3_S, mkrs(A.at_w1, (size_t)TD3_H * TD3_S * 4), TD3_S, A.at_b1, 32 * w, act + CA_T0, CA_LD, nullptr, 0, q, lds);
-        const rsrc_t rw = mkrs(A.c_w14, (size_t)2 * TD3_H * TD3_SA * 4);
-#pragma unroll 1
-        for (int t = 0; t < 2; t++) quad_dense_relu<true, 1>(act + CA_BATCH, CA_LD, TD3_SA, rw, TD3_SA, A.c_b14, 64 * w + 32 * t, act + CA_C1, CA_LD, A.c1, 2 * TD3_H, q, lds);
     }
     TEAM_SYNC();
     {
@@ -277,8 +274,14 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
         quad_dense_relu<false, 4>(act + CA_T0, CA_LD, TD3_H, mkrs(A.at_w2, (size_t)TD3_H * TD3_H * 4), TD3_H, A.at_b2, 32 * w, act + CA_T1, CA_LD, nullptr, 0, q, lds);
     }
     TEAM_SYNC();
-    // ---- target action (td3.py:299-304): the 18-wide output layer is one tile: wave 0 ----
-    if (w == 0) {
+    // ---- target action (td3.py:299-304): the 18-wide output layer is one tile: wave 0.  Beside it, on the other seven waves, the critics' stacked
+    //      first layers on (s, a) -- 16 tiles that depend on the gathered rows only and are not needed before the critics' second layers ----
+    if (w != 0) {
+        QPHASE();
+        const rsrc_t rw = mkrs(A.c_w14, (size_t)2 * TD3_H * TD3_SA * 4);
+#pragma unroll 1
+        for (int t = w - 1; t < 16; t += TEAM_NW - 1) quad_dense_relu<true, 1>(act + CA_BATCH, CA_LD, TD3_SA, rw, TD3_SA, A.c_b14, 32 * t, act + CA_C1, CA_LD, A.c1, 2 * TD3_H, q, lds);
+    } else {
         QPHASE();
         const float bv3 = col < TD3_A ? A.at_b3[col] : 0.f;
         const floatx4 z = quad_nt<false, 4>(act + CA_T1, CA_LD, mkrs(A.at_w3, (size_t)TD3_A * TD3_H * 4), TD3_H, 0, TD3_H, q, lds);

@@ -21,7 +21,7 @@ def alloc(*shape):
 fz._alloc = alloc
 data = torch.randn(100000, 72, device="cuda")
 tot = torch.tensor(100000, dtype=torch.long, device="cuda")
-names = ["gather", "at1 + c14", "at2", "at3 + action (wave 0)", "ct14", "ct2/5 + c2/5 heads", "y, loss, dq", "dh2", "dh1"]
+names = ["gather", "at1", "at2", "at3 + action (wave 0) | c14 (waves 1-7)", "ct14", "ct2/5 + c2/5 heads", "y, loss, dq", "dh2", "dh1"]
 rows = []
 for k in range(40):
     del made[:]
