@@ -90,6 +90,10 @@ typedef struct PlenTd3CriticRows {
     int *done_count; uint64_t *rng_bump;
     float sigma, clip, max_a, gamma;
     int B;
+    /* plentd3_critic_team only (NULL otherwise; plentd3_critic_rows refuses them): the replay rows to use instead of drawing them (int64 [B]; total is
+     * then not read) and the raw target-smoothing noise z ~ N(0, 1) to use instead of drawing it ([B][18], scaled and clipped as td3.py:300-301) -- what
+     * lets the reference's recorded iterations (indices and noise captured from td3.py) be replayed through these kernels */
+    const int64_t *idx; const float *noise;
 } PlenTd3CriticRows;
 int plentd3_critic_rows(const PlenTd3CriticRows *args, void *stream);
 

@@ -592,7 +592,7 @@ int plentd3_adam(float *p, float *g, float *m, float *v, float *step, int *done_
     hipLaunchKernelGGL(k_adam, dim3(std::min((n + 1023) / 1024, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, step, done_count, n, lr, beta1, beta2, eps, zero_grad, target, tau, copy_out); CHECK();
 }
 int plentd3_critic_rows(const PlenTd3CriticRows *args, void *stream) {
-    if (!args || args->B <= 0) return -(int)hipErrorInvalidValue;
+    if (!args || args->B <= 0 || args->idx || args->noise) return -(int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_critic_rows, dim3((args->B + RB - 1) / RB), dim3(64), 0, (hipStream_t)stream, *args); CHECK();
 }
 int plentd3_policy_rows(const PlenTd3PolicyRows *args, void *stream) {

@@ -234,15 +234,20 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
         QPHASE();
         const int b = min(b0 + w, B - 1);
         const bool inside = b0 + w < B;
-        const int64_t tot = A.total[0];
-        int64_t filled, start;
-        if (tot + A.guard <= A.capacity) { filled = tot; start = 0; }
-        else { filled = A.capacity - A.guard; start = (tot + A.guard) % A.capacity; }
-        const float ub = rng_uniform(A.rng, 0u, (uint32_t)b);
-        int64_t i = (int64_t)((double)ub * (double)filled);
-        i = i < filled - 1 ? i : filled - 1;
-        i = i > 0 ? i : 0;
-        const int64_t id = (start + i) % A.capacity;
+        int64_t id;
+        if (A.idx) {
+            id = A.idx[b];                       // the caller's rows (golden iterations)
+        } else {
+            const int64_t tot = A.total[0];
+            int64_t filled, start;
+            if (tot + A.guard <= A.capacity) { filled = tot; start = 0; }
+            else { filled = A.capacity - A.guard; start = (tot + A.guard) % A.capacity; }
+            const float ub = rng_uniform(A.rng, 0u, (uint32_t)b);
+            int64_t i = (int64_t)((double)ub * (double)filled);
+            i = i < filled - 1 ? i : filled - 1;
+            i = i > 0 ? i : 0;
+            id = (start + i) % A.capacity;
+        }
         const float *src = A.data + (size_t)id * TD3_ROW;
         const float v0 = src[lane], v1 = lane < TD3_ROW - 64 ? src[64 + lane] : 0.f;
         float *al = act + w * CA_LD;
@@ -259,7 +264,11 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
     } else {
         QPHASE();
         const int i = w - QB;
-        if (lane < TD3_A) noise_l[i][lane] = fminf(fmaxf(rng_normal(A.rng, 1u, (uint32_t)(min(b0 + i, B - 1) * TD3_A + lane)) * A.sigma, -A.clip), A.clip);    // torch.randn_like(action), td3.py:300
+        if (lane < TD3_A) {
+            const int e = min(b0 + i, B - 1) * TD3_A + lane;
+            const float z = A.noise ? A.noise[e] : rng_normal(A.rng, 1u, (uint32_t)e);                 // torch.randn_like(action), td3.py:300
+            noise_l[i][lane] = fminf(fmaxf(z * A.sigma, -A.clip), A.clip);
+        }
     }
     TEAM_SYNC();
     // gathered rows: s 0..25 | a 26..43 | s2 44..69 | r 70 | not_done 71

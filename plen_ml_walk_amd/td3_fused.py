@@ -33,7 +33,7 @@ class CriticRowsArgs(C.Structure):
                                              "ct_w14", "ct_b14", "ct_w2", "ct_b2", "ct_w5", "ct_b5", "ct_w3", "ct_b3", "ct_w6", "ct_b6",
                                              "c_w14", "c_b14", "c_w2", "c_b2", "c_w5", "c_b5", "c_w3", "c_b3", "c_w6", "c_b6",
                                              "batch", "sa_pi", "t0", "t1", "sa2", "c1", "c2", "dh2", "dh1", "dq", "loss", "db3a", "db3b", "done_count", "rng_bump")]
-                + [("sigma", C.c_float), ("clip", C.c_float), ("max_a", C.c_float), ("gamma", C.c_float), ("B", C.c_int)])
+                + [("sigma", C.c_float), ("clip", C.c_float), ("max_a", C.c_float), ("gamma", C.c_float), ("B", C.c_int), ("idx", C.c_void_p), ("noise", C.c_void_p)])
 
 
 class PolicyRowsArgs(C.Structure):
@@ -395,6 +395,9 @@ class FusedTD3(object):
         self._team_pass = False
         if isinstance(idx, int) and noise is None and (self.rows or self._use_team(idx)):
             return self.critic_backward_rows(data, idx, total, guard, team=self._use_team(idx))
+        if self.team is True and not isinstance(idx, int):          # explicit rows (and noise) through the small-batch kernels: the golden iterations
+            assert idx.dtype == torch.long and idx.is_contiguous() and (noise is None or (noise.is_contiguous() and tuple(noise.shape) == (idx.shape[0], A)))
+            return self.critic_backward_rows(data, int(idx.shape[0]), total, guard, team=True, idx=idx, noise=noise)
         ag, lib, st = self.agent, self.lib, self._stream()
         dev = self.dev
         assert data.dtype == torch.float32 and data.is_contiguous() and data.shape[1] == ROW
@@ -461,14 +464,15 @@ class FusedTD3(object):
         self._probe(4)
         return loss[0]
 
-    def critic_backward_rows(self, data, B, total, guard=0, team=False):
+    def critic_backward_rows(self, data, B, total, guard=0, team=False, idx=None, noise=None):
         """critic_backward() with everything between the sampling and the weight gradients in ONE launch of single-wave workgroups
         (plentd3_critic_rows, csrc/td3_rows.hip): 8 kernels per critic update instead of ~35, and none of them needs more than one free wave slot
         per workgroup to start, which is what the update lacks beside two resident env launches.  Draws its random numbers in-kernel
         (self.rng), so it takes no idx / noise arguments."""
         ag, lib, st = self.agent, self.lib, self._stream()
         dev = self.dev
-        assert data.dtype == torch.float32 and data.is_contiguous() and data.shape[1] == ROW and total is not None
+        assert data.dtype == torch.float32 and data.is_contiguous() and data.shape[1] == ROW and (total is not None or idx is not None)
+        assert team or (idx is None and noise is None)
         new = self._alloc or (lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32))
         with torch.no_grad():
             at, ct, cr = ag.actor_target, ag.critic_target, ag.critic
@@ -480,7 +484,8 @@ class FusedTD3(object):
             if self._done_count is None:
                 self._done_count = torch.zeros(1, device=dev, dtype=torch.int32)
             a = CriticRowsArgs()
-            a.data, a.rng, a.total, a.capacity, a.guard = data.data_ptr(), self.rng.data_ptr(), total.data_ptr(), int(data.shape[0]), int(guard)
+            a.data, a.rng, a.total, a.capacity, a.guard = data.data_ptr(), self.rng.data_ptr(), (total.data_ptr() if total is not None else None), int(data.shape[0]), int(guard)
+            a.idx, a.noise = (idx.data_ptr() if idx is not None else None), (noise.data_ptr() if noise is not None else None)
             for pre, net in (("at", at),):
                 a.at_w1, a.at_b1, a.at_w2, a.at_b2, a.at_w3, a.at_b3 = (t.data_ptr() for t in (net.fc1.weight, net.fc1.bias, net.fc2.weight, net.fc2.bias, net.fc3.weight, net.fc3.bias))
             a.ct_w14, a.ct_b14 = tv["W14"].data_ptr(), tv["b14"].data_ptr()

@@ -267,6 +267,24 @@ def test_fused_td3_update_matches_the_reference_golden_iterations(golden_dir):
         _check_against_golden(g, a, k)
 
 
+def test_reference_golden_iterations_through_the_small_batch_kernels(golden_dir):
+    """The reference's own two recorded train() iterations (td3.py:259-356 at its batch 100: sampled indices and smoothing noise captured from the reference,
+    tests/golden/td3_train.npz) replayed through k_critic_team / k_policy_team / k_wgrad_adam_group (explicit idx / noise in PlenTd3CriticRows): parameters and
+    targets after iteration 1 (critic only) and iteration 2 (critic, actor, Polyak) match the reference's to the tolerance the autograd path is held to."""
+    from plen_ml_walk_amd.td3_fused import FusedTD3
+    g, a, buf = _golden_agent(golden_dir, "cuda")
+    fz = FusedTD3(a, team=True)
+    fz.enable_flat_adam()
+    for k in range(2):
+        idx = torch.as_tensor(g["idx"][k]).cuda().long().contiguous()
+        noise = torch.as_tensor(g["noise"][k]).cuda().contiguous()
+        a.total_it += 1
+        loss = fz.update(buf.data, idx, with_policy=a.total_it % a.policy_freq == 0, noise=noise, all_reduce=False)
+        torch.cuda.synchronize()
+        assert fz._team_pass and "critic" in fz._fused_done and torch.isfinite(loss)
+        _check_against_golden(g, a, k)
+
+
 @pytest.mark.parametrize("B,total", [(4096, 50000), (100, 700), (16, 40), (3, 5)])
 def test_critic_rows_kernel_equals_the_layer_by_layer_update(B, total):
     """plentd3_critic_rows (one launch, 16 batch rows per wave through sampling, targets, critic forward and backward on the matrix cores) against

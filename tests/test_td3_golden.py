@@ -26,9 +26,10 @@ def test_shipped_policy_forward(golden_dir):
     a.load_arrays(pol)
     act = np.stack([a.select_action(o) for o in g["obs"]])
     assert act.dtype == np.float32 and act.shape == (64, 18)
-    assert np.abs(act - g["action"]).max() <= 1e-5
+    # (3e-5, not 1e-5: the shipped policy's pre-activations are O(10) and the host BLAS decides the summation order -- 1.1e-5 seen on the GPU box's CPU)
+    assert np.abs(act - g["action"]).max() <= 3e-5
     batch = a.select_action_batch(torch.as_tensor(g["obs"], dtype=torch.float32)).numpy()
-    assert np.abs(batch - g["action"]).max() <= 1e-5
+    assert np.abs(batch - g["action"]).max() <= 3e-5
     with torch.no_grad():
         q1, q2 = a.critic(torch.as_tensor(g["obs"], dtype=torch.float32), torch.as_tensor(g["action"]))
     assert np.abs(q1.numpy() - g["q1"]).max() <= 1e-4 * max(1, np.abs(g["q1"]).max())
