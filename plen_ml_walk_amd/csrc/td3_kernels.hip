@@ -394,7 +394,14 @@ __global__ void k_store(float *__restrict__ data, const int64_t *__restrict__ to
 // in float would be off by 5e-5 relative, and so would the second moment
 struct AdamCoef { float step_size, bc2_sqrt, b2, w1, w2, eps, tau; };
 static __device__ __forceinline__ AdamCoef adam_coef(float t, double lr, double b1d, double b2d, float eps, float tau) {
-    const double bc1 = 1.0 - pow(b1d, (double)t), bc2 = 1.0 - pow(b2d, (double)t);
+    // beta^t for the integer-valued step count by repeated squaring (<= 24 double multiplies, a few ulp of double: the same float after rounding);
+    // the general double-precision pow() cost 1 us per launch, twice, on every workgroup's critical path
+    double p1 = 1.0, p2 = 1.0, q1 = b1d, q2 = b2d;
+    for (unsigned n = (unsigned)t; n; n >>= 1) {
+        if (n & 1u) { p1 *= q1; p2 *= q2; }
+        q1 *= q1; q2 *= q2;
+    }
+    const double bc1 = 1.0 - p1, bc2 = 1.0 - p2;
     return AdamCoef{(float)(lr / bc1), (float)sqrt(bc2), (float)b2d, (float)(1.0 - b1d), (float)(1.0 - b2d), eps, tau};
 }
 static __device__ __forceinline__ void adam_one(float gi, float &mi, float &vi, float &pi, const AdamCoef &c) {
