@@ -94,6 +94,10 @@ typedef struct PlenTd3CriticRows {
      * then not read) and the raw target-smoothing noise z ~ N(0, 1) to use instead of drawing it ([B][18], scaled and clipped as td3.py:300-301) -- what
      * lets the reference's recorded iterations (indices and noise captured from td3.py) be replayed through these kernels */
     const int64_t *idx; const float *noise;
+    /* plentd3_critic_team only (NULL otherwise): the step counter of the optimiser whose step plentd3_wgrad_adam_group will take on this pass's gradients
+     * (float32 device scalar, torch's capturable `step`): advanced by one by the last workgroup to finish, so that the weight-gradient launch finds it
+     * advanced (PlenTd3AdamFused.step_advanced = 1) and needs no counter protocol of its own */
+    float *adam_step;
 } PlenTd3CriticRows;
 int plentd3_critic_rows(const PlenTd3CriticRows *args, void *stream);
 
@@ -107,6 +111,8 @@ typedef struct PlenTd3PolicyRows {
     float *sa_pi, *a_pi, *p1, *p2, *g1, *dg2, *dg1, *dz, *dp2, *dp1;
     float max_a;
     int B;
+    /* plentd3_policy_team only (NULL otherwise): as PlenTd3CriticRows.adam_step for the actor's optimiser; done_count = device int, zero before the first call */
+    float *adam_step; int *done_count;
 } PlenTd3PolicyRows;
 int plentd3_policy_rows(const PlenTd3PolicyRows *args, void *stream);
 
@@ -127,12 +133,13 @@ int plentd3_wgrad_group(const PlenTd3WgradGroup *group, void *stream);
 /* plentd3_wgrad_group with the optimiser step of plentd3_adam applied where each gradient element is produced (the batch is one reduction chunk, so
  * every element is owned by one workgroup): dW / db of the jobs must point INTO the flat gradient buffer g [n] (dws == K); the element's offset
  * there addresses p, m, v and target (NULL: no Polyak update).  The gradients themselves are not stored: g stays zero.  extra_off: offsets of
- * elements whose gradient is already in g (the critics' head biases): stepped and zeroed here.  step / done_count as plentd3_adam. */
+ * elements whose gradient is already in g (the critics' head biases): stepped and zeroed here.  step / done_count as plentd3_adam, unless step_advanced. */
 #define PLENTD3_ADAM_EXTRAS 4
 typedef struct PlenTd3AdamFused {
     float *p, *g, *m, *v, *step, *target; int *done_count;
     double lr, beta1, beta2; float eps, tau;
     int n, n_extra, extra_off[PLENTD3_ADAM_EXTRAS];
+    int step_advanced;      /* 1: step[0] already holds this step's count (advanced by the pass kernel: adam_step); done_count is then unused */
 } PlenTd3AdamFused;
 int plentd3_wgrad_adam_group(const PlenTd3WgradGroup *group, const PlenTd3AdamFused *adam, void *stream);
 

@@ -447,11 +447,8 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, float *__re
             }
         }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(done_count, 1) == (int)gridDim.x - 1) { done_count[0] = 0; step[0] = t; }
-    }
+    __syncthreads();                            // every wave of this workgroup has read the counter (no fence: the next reader of `step` is the next launch)
+    if (threadIdx.x == 0 && atomicAdd(done_count, 1) == (int)gridDim.x - 1) { done_count[0] = 0; step[0] = t; }
 }
 
 // ---- K15c + K17 in one: the grouped weight gradients of a SMALL batch with the Adam step applied where each gradient element is produced.
@@ -491,7 +488,7 @@ struct WgradAdamStep {
     }
 };
 __global__ __launch_bounds__(256) void k_wgrad_adam_group(PlenTd3WgradGroup G, PlenTd3AdamFused Ad) {
-    const float t = Ad.step[0] + 1.f;
+    const float t = Ad.step_advanced ? Ad.step[0] : Ad.step[0] + 1.f;
     int j = 0;
 #pragma unroll
     for (int k = 1; k < PLENTD3_WGRAD_JOBS; k++) j += (k < G.n_jobs && (int)blockIdx.x >= G.job[k].tile0) ? 1 : 0;
@@ -504,10 +501,12 @@ __global__ __launch_bounds__(256) void k_wgrad_adam_group(PlenTd3WgradGroup G, P
         emit.one(ge, *ge);
         *ge = 0.f;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(Ad.done_count, 1) == (int)gridDim.x - 1) { Ad.done_count[0] = 0; Ad.step[0] = t; }
+    // the step counter: read by every workgroup, so it may only change once all have read it -- the last workgroup to finish writes it (one returning atomic
+    // per workgroup on one address: 2.4 us of tail per launch, 5 us with the device-scope fence a first version put in front of it), unless the pass
+    // kernel that produced the gradients has advanced it already (step_advanced: the small-batch path)
+    if (!Ad.step_advanced) {
+        __syncthreads();                        // every wave of this workgroup has read the counter
+        if (threadIdx.x == 0 && atomicAdd(Ad.done_count, 1) == (int)gridDim.x - 1) { Ad.done_count[0] = 0; Ad.step[0] = t; }
     }
 }
 
@@ -599,11 +598,11 @@ int plentd3_adam(float *p, float *g, float *m, float *v, float *step, int *done_
     hipLaunchKernelGGL(k_adam, dim3(std::min((n + 1023) / 1024, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, step, done_count, n, lr, beta1, beta2, eps, zero_grad, target, tau, copy_out); CHECK();
 }
 int plentd3_critic_rows(const PlenTd3CriticRows *args, void *stream) {
-    if (!args || args->B <= 0 || args->idx || args->noise) return -(int)hipErrorInvalidValue;
+    if (!args || args->B <= 0 || args->idx || args->noise || args->adam_step) return -(int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_critic_rows, dim3((args->B + RB - 1) / RB), dim3(64), 0, (hipStream_t)stream, *args); CHECK();
 }
 int plentd3_policy_rows(const PlenTd3PolicyRows *args, void *stream) {
-    if (!args || args->B <= 0) return -(int)hipErrorInvalidValue;
+    if (!args || args->B <= 0 || args->adam_step) return -(int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_policy_rows, dim3((args->B + RB - 1) / RB), dim3(64), 0, (hipStream_t)stream, *args); CHECK();
 }
 int plentd3_critic_team(const PlenTd3CriticRows *args, void *stream) {
@@ -611,7 +610,7 @@ int plentd3_critic_team(const PlenTd3CriticRows *args, void *stream) {
     hipLaunchKernelGGL(k_critic_team, dim3((args->B + QB - 1) / QB), dim3(64 * TEAM_NW), 0, (hipStream_t)stream, *args); CHECK();
 }
 int plentd3_policy_team(const PlenTd3PolicyRows *args, void *stream) {
-    if (!args || args->B <= 0) return -(int)hipErrorInvalidValue;
+    if (!args || args->B <= 0 || (args->adam_step && !args->done_count)) return -(int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_policy_team, dim3((args->B + QB - 1) / QB), dim3(64 * TEAM_NW), 0, (hipStream_t)stream, *args); CHECK();
 }
 int plentd3_wgrad_group(const PlenTd3WgradGroup *group, void *stream) {
@@ -627,7 +626,7 @@ int plentd3_wgrad_group(const PlenTd3WgradGroup *group, void *stream) {
 }
 int plentd3_wgrad_adam_group(const PlenTd3WgradGroup *group, const PlenTd3AdamFused *adam, void *stream) {
     if (!group || !adam || group->n_jobs < 1 || group->n_jobs > PLENTD3_WGRAD_JOBS || group->B <= 0) return -(int)hipErrorInvalidValue;
-    if (!adam->p || !adam->g || !adam->m || !adam->v || !adam->step || !adam->done_count || adam->n < 1 || adam->n_extra < 0 || adam->n_extra > PLENTD3_ADAM_EXTRAS)
+    if (!adam->p || !adam->g || !adam->m || !adam->v || !adam->step || (!adam->done_count && !adam->step_advanced) || adam->n < 1 || adam->n_extra < 0 || adam->n_extra > PLENTD3_ADAM_EXTRAS)
         return -(int)hipErrorInvalidValue;
     PlenTd3WgradGroup G = *group;
     int tiles = 0;

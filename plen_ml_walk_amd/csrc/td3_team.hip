@@ -401,6 +401,7 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
             A.loss[0] = l; A.db3a[0] += ga; A.db3b[0] += gb;
             A.done_count[0] = 0;
             if (A.rng_bump) A.rng_bump[1] += 1;
+            if (A.adam_step) A.adam_step[0] += 1.f;          // the optimiser step the weight-gradient launch is about to take (PlenTd3AdamFused.step_advanced)
         }
     }
 }
@@ -515,5 +516,9 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
     {
         QPHASE();
         store_masked(quad_nn<false, 4>(act + PA_DP2, PA_LD, mkrs(A.a_w2, (size_t)TD3_H * TD3_H * 4), TD3_H, n0, TD3_H, q), PA_P1, -1, A.dp1, q);
+    }
+    // the last workgroup to finish advances the actor optimiser's step counter for the weight-gradient launch that follows (as k_critic_team)
+    if (A.adam_step && threadIdx.x == 0) {
+        if (atomicAdd(A.done_count, 1) == (int)((B + QB - 1) / QB) - 1) { A.done_count[0] = 0; A.adam_step[0] += 1.f; }
     }
 }

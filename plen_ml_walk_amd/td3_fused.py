@@ -33,14 +33,14 @@ class CriticRowsArgs(C.Structure):
                                              "ct_w14", "ct_b14", "ct_w2", "ct_b2", "ct_w5", "ct_b5", "ct_w3", "ct_b3", "ct_w6", "ct_b6",
                                              "c_w14", "c_b14", "c_w2", "c_b2", "c_w5", "c_b5", "c_w3", "c_b3", "c_w6", "c_b6",
                                              "batch", "sa_pi", "t0", "t1", "sa2", "c1", "c2", "dh2", "dh1", "dq", "loss", "db3a", "db3b", "done_count", "rng_bump")]
-                + [("sigma", C.c_float), ("clip", C.c_float), ("max_a", C.c_float), ("gamma", C.c_float), ("B", C.c_int), ("idx", C.c_void_p), ("noise", C.c_void_p)])
+                + [("sigma", C.c_float), ("clip", C.c_float), ("max_a", C.c_float), ("gamma", C.c_float), ("B", C.c_int), ("idx", C.c_void_p), ("noise", C.c_void_p), ("adam_step", C.c_void_p)])
 
 
 class PolicyRowsArgs(C.Structure):
     """Mirror of PlenTd3PolicyRows (include/plentd3.h)."""
     _fields_ = ([(n, C.c_void_p) for n in ("a_w1", "a_b1", "a_w2", "a_b2", "a_w3", "a_b3", "c_w1", "c_b1", "c_w2", "c_b2", "c_w3",
                                            "sa_pi", "a_pi", "p1", "p2", "g1", "dg2", "dg1", "dz", "dp2", "dp1")]
-                + [("max_a", C.c_float), ("B", C.c_int)])
+                + [("max_a", C.c_float), ("B", C.c_int), ("adam_step", C.c_void_p), ("done_count", C.c_void_p)])
 
 
 class ActorRowsArgs(C.Structure):
@@ -68,7 +68,7 @@ ADAM_EXTRAS = 4
 class AdamFusedArgs(C.Structure):
     """Mirror of PlenTd3AdamFused (include/plentd3.h)."""
     _fields_ = ([(n, C.c_void_p) for n in ("p", "g", "m", "v", "step", "target", "done_count")] + [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
-                ("eps", C.c_float), ("tau", C.c_float), ("n", C.c_int), ("n_extra", C.c_int), ("extra_off", C.c_int * ADAM_EXTRAS)])
+                ("eps", C.c_float), ("tau", C.c_float), ("n", C.c_int), ("n_extra", C.c_int), ("extra_off", C.c_int * ADAM_EXTRAS), ("step_advanced", C.c_int)])
 
 
 TEAM_MAX_BATCH = 512          # FusedTD3(team=None): batches up to this size take the small-batch kernels (csrc/td3_team.hip)
@@ -156,7 +156,7 @@ class FlatAdam(object):
         if steps:
             self.step_t.fill_(steps.pop())
 
-    def fused_args(self, target=None, tau=0.0, extras=()):
+    def fused_args(self, target=None, tau=0.0, extras=(), step_advanced=False):
         """PlenTd3AdamFused for plentd3_wgrad_adam_group: this optimiser's step taken inside the weight-gradient kernel (hyper-parameters as they are now)."""
         st0 = self.opt.state.get(self.params[0])
         if (not st0 or st0["exp_avg"].data_ptr() != self.m.data_ptr()) and not torch.cuda.is_current_stream_capturing():
@@ -166,7 +166,7 @@ class FlatAdam(object):
         a.p, a.g, a.m, a.v, a.step, a.done_count = (t.data_ptr() for t in (self.p, self.g, self.m, self.v, self.step_t, self.done))
         a.target = target.data_ptr() if target is not None else None
         a.lr, a.beta1, a.beta2, a.eps, a.tau = float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(tau)
-        a.n, a.n_extra = self.p.numel(), len(extras)
+        a.n, a.n_extra, a.step_advanced = self.p.numel(), len(extras), int(bool(step_advanced))
         for k, e in enumerate(extras):
             a.extra_off[k] = int(e)
         return a
@@ -208,6 +208,7 @@ class FusedTD3(object):
         self.fuse_adam = os.environ.get("PLEN_TD3_FUSE_ADAM", "1") == "1"
         self._fuse, self._fused_done = None, set()
         self._done_count = None
+        self._policy_done = None
         self._alloc = None           # test hook: allocator of the per-iteration scratch matrices (tests put canary rows behind them)
         self._critic_adam = self._actor_adam = None
         self._zeroed = {}
@@ -246,7 +247,7 @@ class FusedTD3(object):
         if which is not None and self._fuse is not None and which in self._fuse:
             adam = self._critic_adam if which == "critic" else self._actor_adam
             base = adam.g.data_ptr()
-            a = adam.fused_args(target=self._fuse[which], tau=self.agent.tau, extras=[(t.data_ptr() - base) // 4 for t in extras])
+            a = adam.fused_args(target=self._fuse[which], tau=self.agent.tau, extras=[(t.data_ptr() - base) // 4 for t in extras], step_advanced=True)
             _chk(self.lib.plentd3_wgrad_adam_group(C.byref(G), C.byref(a), self._stream()))
             self._fused_done.add(which)
             return
@@ -486,6 +487,8 @@ class FusedTD3(object):
             a = CriticRowsArgs()
             a.data, a.rng, a.total, a.capacity, a.guard = data.data_ptr(), self.rng.data_ptr(), (total.data_ptr() if total is not None else None), int(data.shape[0]), int(guard)
             a.idx, a.noise = (idx.data_ptr() if idx is not None else None), (noise.data_ptr() if noise is not None else None)
+            fused_step = team and self._fuse is not None and "critic" in self._fuse        # the pass kernel advances the step counter for the launch that takes the step
+            a.adam_step = self._critic_adam.step_t.data_ptr() if fused_step else None
             for pre, net in (("at", at),):
                 a.at_w1, a.at_b1, a.at_w2, a.at_b2, a.at_w3, a.at_b3 = (t.data_ptr() for t in (net.fc1.weight, net.fc1.bias, net.fc2.weight, net.fc2.bias, net.fc3.weight, net.fc3.bias))
             a.ct_w14, a.ct_b14 = tv["W14"].data_ptr(), tv["b14"].data_ptr()
@@ -538,6 +541,11 @@ class FusedTD3(object):
                 a.c_w1, a.c_b1, a.c_w2, a.c_b2, a.c_w3 = (t.data_ptr() for t in (cr.fc1.weight, cr.fc1.bias, cr.fc2.weight, cr.fc2.bias, cr.fc3.weight))
                 a.sa_pi, a.a_pi, a.p1, a.p2, a.g1, a.dg2, a.dg1, a.dz, a.dp2, a.dp1 = (t.data_ptr() for t in (sa_pi, a_pi, p1, p2, g1, dg2, dg1, dz, dp2, dp1))
                 a.max_a, a.B = float(ag.max_action), int(B)
+                a.adam_step = a.done_count = None
+                if self._team_pass and self._fuse is not None and "actor" in self._fuse:
+                    if self._policy_done is None:
+                        self._policy_done = torch.zeros(1, device=dev, dtype=torch.int32)
+                    a.adam_step, a.done_count = self._actor_adam.step_t.data_ptr(), self._policy_done.data_ptr()
                 if self._team_pass:
                     _chk(lib.plentd3_policy_team(C.byref(a), st))
                     self._wgrad_group(B, [(dz, p2, ac.fc3.weight.grad, ac.fc3.bias.grad), (dp2, p1, ac.fc2.weight.grad, ac.fc2.bias.grad),
