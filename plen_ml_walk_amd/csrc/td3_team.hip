@@ -222,7 +222,7 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
     __shared__ float team_lds[TEAM_NW][TEAM_LDS_PER_WAVE];
     __shared__ __attribute__((aligned(16))) float act[QB * CA_LD];
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), wq = w & 3, half = w >> 2;
-    const int B = A.B, b0 = blockIdx.x * QB;
+    const int B = A.B, b0 = blockIdx.x * QB, n_team = (B + QB - 1) / QB;
     float *lds = team_lds[w];
 #ifdef TEAM_STAMPS
     int team_stamp_k = 1;
@@ -351,10 +351,44 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
             lsum = ea * ea * inv + eb * eb * inv;
         }
         lsum = wave_sum(lsum); ga = wave_sum(ga); gb = wave_sum(gb);
-        // the loss and the two head biases' gradients: one partial per workgroup, parked in unused columns of the workgroup's own scratch row and summed
-        // in order by the last workgroup to finish (below): the sums do not depend on the finishing order (same bits every run), and loss[0] is a
-        // plain store that nobody has to zero first
-        if (lane == 0) { float *park = A.t1 + (size_t)b0 * 2 * TD3_H + TD3_H; park[0] = lsum; park[1] = ga; park[2] = gb; }
+        // the loss and the two head biases' gradients: one partial per workgroup, parked in unused columns of the workgroup's own scratch row; the last
+        // workgroup to get HERE sums them in workgroup order (the sums do not depend on the arrival order: same bits every run; loss[0] is a plain store
+        // that nobody has to zero first) and advances the counters -- every workgroup is past its draws from the random stream by now.  (At the END of the
+        // kernel, behind a barrier and a fence that waited for the last layer's stores, and with the partials fetched one after the other, this
+        // protocol was 8 us of every update.)
+        int last = 0;
+        if (lane == 0) {
+            float *park = A.t1 + (size_t)b0 * 2 * TD3_H + TD3_H;
+            park[0] = lsum; park[1] = ga; park[2] = gb;
+            __threadfence();
+            last = atomicAdd(A.done_count, 1) == n_team - 1;
+        }
+        if (__builtin_amdgcn_readfirstlane(last)) {
+            __threadfence();
+            float l = 0.f, sa = 0.f, sb = 0.f;
+            for (int c0 = 0; c0 < n_team; c0 += 64) {            // one workgroup's partials per lane, then added in lane order
+                const int k = c0 + lane;
+                float pl = 0.f, pa = 0.f, pb = 0.f;
+                if (k < n_team) {
+                    const float *park = A.t1 + (size_t)k * QB * 2 * TD3_H + TD3_H;
+                    pl = __hip_atomic_load(park, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pa = __hip_atomic_load(park + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pb = __hip_atomic_load(park + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                const int m = min(64, n_team - c0);
+                for (int i = 0; i < m; i++) {
+                    l += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pl), i));
+                    sa += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pa), i));
+                    sb += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pb), i));
+                }
+            }
+            if (lane == 0) {
+                A.loss[0] = l; A.db3a[0] += sa; A.db3b[0] += sb;
+                A.done_count[0] = 0;
+                if (A.rng_bump) A.rng_bump[1] += 1;
+                if (A.adam_step) A.adam_step[0] += 1.f;          // the optimiser step the weight-gradient launch is about to take (PlenTd3AdamFused.step_advanced)
+            }
+        }
     }
     TEAM_SYNC();
     // ---- dh2 = dq (x) w3 where the hidden unit was active: wave = (row, critic), 4 columns per lane ----
@@ -383,25 +417,6 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
 #pragma unroll
             for (int i = 0; i < 4; i++) acc[i] = act[i * CA_LD + CA_C1 + oc + col] > 0.f ? acc[i] : 0.f;
             quad_store(nullptr, 0, A.dh1, 2 * TD3_H, oc, acc, q);
-        }
-    }
-    // the last workgroup to finish adds up the partial sums and advances the random stream's call counter: every wave has read it by then
-    TEAM_SYNC();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(A.done_count, 1) == (int)gridDim.x - 1) {
-            __threadfence();
-            float l = 0.f, ga = 0.f, gb = 0.f;
-            for (int k = 0; k < (int)gridDim.x; k++) {
-                const float *park = A.t1 + (size_t)k * QB * 2 * TD3_H + TD3_H;
-                l += __hip_atomic_load(park, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ga += __hip_atomic_load(park + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                gb += __hip_atomic_load(park + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            A.loss[0] = l; A.db3a[0] += ga; A.db3b[0] += gb;
-            A.done_count[0] = 0;
-            if (A.rng_bump) A.rng_bump[1] += 1;
-            if (A.adam_step) A.adam_step[0] += 1.f;          // the optimiser step the weight-gradient launch is about to take (PlenTd3AdamFused.step_advanced)
         }
     }
 }
