@@ -644,7 +644,11 @@ int plentd3_wgrad_adam_group(const PlenTd3WgradGroup *group, const PlenTd3AdamFu
 }
 int plentd3_actor_rows(const PlenTd3ActorRows *args, void *stream) {
     if (!args || args->B <= 0) return -(int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_actor_rows, dim3((args->B + RB - 1) / RB), dim3(64), 0, (hipStream_t)stream, *args); CHECK();
+    // four waves per row block by default (csrc/td3_rows.hip, k_actor_rows4); PLEN_TD3_ACTOR_WAVES=1: the single-wave workgroups
+    static const int waves = [] { const char *e = getenv("PLEN_TD3_ACTOR_WAVES"); return e && atoi(e) == 1 ? 1 : 4; }();
+    if (waves == 4) hipLaunchKernelGGL(k_actor_rows4, dim3((args->B + RB - 1) / RB), dim3(256), 0, (hipStream_t)stream, *args);
+    else hipLaunchKernelGGL(k_actor_rows, dim3((args->B + RB - 1) / RB), dim3(64), 0, (hipStream_t)stream, *args);
+    CHECK();
 }
 int plentd3_stamp(uint64_t *table, const int64_t *counter, int64_t div, int ring, int nslots, int idx, void *stream) {
     hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, (hipStream_t)stream, table, counter, div, ring, nslots, idx); CHECK();

@@ -581,3 +581,46 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
     }
 }
+
+// ---- the same, FOUR waves per 16 envs (one 256-thread workgroup): the collect phase's actor forward is on every vector step's critical path (the env kernel of
+//      a sub-batch cannot start before it) and as one wave per row block it is a chain of 26 dependent k steps of 32 MFMAs: 50 us for 2048 envs, a sixth of
+//      the step.  It runs when its own sub-batch's env launch has retired, so -- unlike the update -- it finds free wave slots on every SIMD and need not be
+//      a single-wave workgroup: each wave takes 64 of a hidden layer's 256 columns, the 18-wide output layer is split along k (64 each) and summed through LDS
+//      in wave order.  Same draws (noise index = element index), same arithmetic per element up to the order of the output layer's four partial sums.
+__global__ __launch_bounds__(256) void k_actor_rows4(PlenTd3ActorRows A) {
+    __shared__ float zp[4][2][64][4];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), r = lane & 15, g = lane >> 4;
+    const int B = A.B, b0 = blockIdx.x * RB;
+    const RowBlock rb{b0, B, r, g, min(b0 + r, B - 1), lane};
+    const size_t Bz = (size_t)B;
+    const rsrc_t r_s = mkrs(A.state, Bz * TD3_S * 4), r_p1 = mkrs(A.p1, Bz * TD3_H * 4), r_p2 = mkrs(A.p2, Bz * TD3_H * 4);
+    dense_relu<4, true>(r_s, rb.aoff(TD3_S), TD3_S, mkrs(A.a_w1, (size_t)TD3_H * TD3_S * 4), TD3_S, A.a_b1, 64 * w, r_p1, TD3_H, rb);
+    __syncthreads();
+    dense_relu<4, false>(r_p1, rb.aoff(TD3_H), TD3_H, mkrs(A.a_w2, (size_t)TD3_H * TD3_H * 4), TD3_H, A.a_b2, 64 * w, r_p2, TD3_H, rb);
+    __syncthreads();
+    {
+        floatx4 acc[2] = {floatx4{0, 0, 0, 0}, floatx4{0, 0, 0, 0}};
+        const int kb = 64 * w;
+        mm_nt<2, false>(r_p2, rb.aoff(TD3_H, kb), mkrs(A.a_w3 + kb, ((size_t)TD3_A * TD3_H - kb) * 4), TD3_H, 0, 64, acc, r, g);
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) zp[w][t][lane][i] = acc[t][i];
+    }
+    __syncthreads();
+    if (w < 2) {
+        const int t = w, j = 16 * t + r;
+        if (j < TD3_A) {
+            const float bv = A.a_b3[j];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int b = b0 + 4 * g + i;
+                if (b < B) {
+                    const float z = ((zp[0][t][lane][i] + zp[1][t][lane][i]) + zp[2][t][lane][i]) + zp[3][t][lane][i];
+                    const int e = b * TD3_A + j;
+                    A.action[e] = fminf(fmaxf(A.max_a * tanhf(z + bv) + rng_normal(A.rng, 2u, (uint32_t)e) * A.sigma, -A.max_a), A.max_a);
+                }
+            }
+        }
+    }
+}
