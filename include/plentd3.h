@@ -69,7 +69,8 @@ int plentd3_polyak(float *target, const float *param, float tau, int n, void *st
 /* td3.py:236-247 / :326-331 / :343-345 optimizer.step() of torch.optim.Adam (no weight decay, no amsgrad) over a network's flat parameter, gradient and
  * moment buffers of n floats: step[0] += 1 (float32 device scalar, torch's capturable `step`); m, v, p updated with torch's bias corrections.
  * Optional extras of the same pass: zero_grad (g = 0 for the next backward), target != NULL (td3.py:348-356: target = tau p + (1 - tau) target),
- * copy_out != NULL (a copy of the new parameters).  done_count: device int, zero before the first call. */
+ * copy_out != NULL (a copy of the new parameters).  done_count: device int, zero before the first call.  p, g, m, v, target and copy_out must be 16-byte
+ * aligned (the kernel moves four floats per access); a misaligned pointer is refused with -hipErrorInvalidValue. */
 int plentd3_adam(float *p, float *g, float *m, float *v, float *step, int *done_count, int n, double lr, double beta1, double beta2, float eps, int zero_grad,
                  float *target, float tau, float *copy_out, void *stream);
 
@@ -117,7 +118,7 @@ typedef struct PlenTd3PolicyRows {
 int plentd3_policy_rows(const PlenTd3PolicyRows *args, void *stream);
 
 /* The same two passes for SMALL batches (the reference's recipe: batch 100, one update per env-step -- plen_td3.py:28, :119-120 -- where the latency
- * of one update is what counts): 16 batch rows per 512-thread workgroup whose 8 waves split every layer's output columns (csrc/td3_team.hip).
+ * of one update is what counts): 4 batch rows per 512-thread workgroup (25 workgroups at batch 100) whose 8 waves split every layer's output columns (csrc/td3_team.hip).
  * Arguments, outputs and arithmetic as plentd3_critic_rows / plentd3_policy_rows (the critics' scalar heads sum in a different order), except that
  * loss[0] is STORED (per-workgroup partials summed in order by the last workgroup to finish), not added to: no zeroing, same bits every run. */
 int plentd3_critic_team(const PlenTd3CriticRows *args, void *stream);
@@ -142,6 +143,35 @@ typedef struct PlenTd3AdamFused {
     int step_advanced;      /* 1: step[0] already holds this step's count (advanced by the pass kernel: adam_step); done_count is then unused */
 } PlenTd3AdamFused;
 int plentd3_wgrad_adam_group(const PlenTd3WgradGroup *group, const PlenTd3AdamFused *adam, void *stream);
+
+/* The same two passes for LARGE batches (BASELINE.json configs[2]: batch 4096): 16 batch rows per 256-thread workgroup, one workgroup per compute unit at
+ * batch 4096; the four waves split every layer's output features, the products are formed transposed (Y^T = W X^T) so that activations stay in LDS from
+ * the gathered replay rows to the last gradient, and the weights are read PRE-PACKED in matrix-core operand order (csrc/td3_block.hip).
+ * plentd3_pack writes that order: job j packs the N x K matrix M (element (i, k) at src[i rs + k cs]: rs / cs express W or W^T or a column block of it)
+ * into dst, zero-padded to 16-row tiles and 16-k steps: dst float4 ((t KS + s) 64 + lane) = M[16 t + lane % 16][16 s + 4 (lane / 16) + (0..3)],
+ * KS = ceil(K / 16); dst holds ceil(N / 16) KS 256 floats.  f4_0 is filled in by the call.  Run it after every optimiser / Polyak step that changes a
+ * source matrix (3 us for all of a critic's and an actor's matrices). */
+#define PLENTD3_PACK_JOBS 16
+typedef struct PlenTd3PackJob { const float *src; float *dst; int rs, cs, N, K, f4_0; } PlenTd3PackJob;
+typedef struct PlenTd3PackGroup { PlenTd3PackJob job[PLENTD3_PACK_JOBS]; int n_jobs; } PlenTd3PackGroup;
+int plentd3_pack(const PlenTd3PackGroup *group, void *stream);
+/* rows: as plentd3_critic_team (idx / noise / adam_step honoured; loss[0] STORED; t0, t1, sa2 not written).  Packed operands: p_at_w1 (256 x 26), p_at_w2
+ * (256 x 256), p_at_w3 (18 x 256) of the target actor; p_ct_w14 (512 x 44), p_ct_w2, p_ct_w5 of the target critic; p_c_w14, p_c_w2, p_c_w5 of the critic and
+ * p_c_w2t, p_c_w5t = its second layers TRANSPOSED (element (i, k) = W[k][i]) for the input gradients.  partials: scratch float [4 ceil(B / 16)]. */
+typedef struct PlenTd3CriticBlock {
+    PlenTd3CriticRows rows;
+    const float *p_at_w1, *p_at_w2, *p_at_w3, *p_ct_w14, *p_ct_w2, *p_ct_w5, *p_c_w14, *p_c_w2, *p_c_w5, *p_c_w2t, *p_c_w5t;
+    float *partials;
+} PlenTd3CriticBlock;
+int plentd3_critic_block(const PlenTd3CriticBlock *args, void *stream);
+/* rows: as plentd3_policy_team.  Packed operands: p_a_w1 (256 x 26), p_a_w2, p_a_w3 (18 x 256) of the actor; p_c_w14, p_c_w2 of the critic (Q1 = its first 16
+ * tiles of W14 and fc2); transposed for the input gradients: p_c_w2t, p_c_w1ta = (i = action j, k = hidden) -> fc1.weight[k][26 + j] (18 x 256),
+ * p_a_w3t = (i = hidden, k = action) -> fc3.weight[k][i] (256 x 18), p_a_w2t. */
+typedef struct PlenTd3PolicyBlock {
+    PlenTd3PolicyRows rows;
+    const float *p_a_w1, *p_a_w2, *p_a_w3, *p_c_w14, *p_c_w2, *p_c_w2t, *p_c_w1ta, *p_a_w3t, *p_a_w2t;
+} PlenTd3PolicyBlock;
+int plentd3_policy_block(const PlenTd3PolicyBlock *args, void *stream);
 
 /* plen_td3.py:101-104 for a whole vector step as one launch: action [B][18] = clamp(actor(state [B][26]) + N(0, sigma), +-max_a), the noise drawn as
  * plentd3_explore draws it (rng, bumped by the plentd3_store that follows); p1, p2 [B][256] are scratch. */

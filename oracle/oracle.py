@@ -9,6 +9,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# PLEN_ORACLE_LIB_DIR: load libplen_oracle_<dtype>.so from there (an oracle built on other model tables: scripts/pin/margin_pooled.py)
+_LIB_DIR = os.environ.get("PLEN_ORACLE_LIB_DIR") or _HERE
 _LIBS = {}
 
 
@@ -21,8 +23,9 @@ def build(force=False):
 
 def _lib(dtype="f64"):
     if dtype not in _LIBS:
-        path = os.path.join(_HERE, "libplen_oracle_%s.so" % dtype)
+        path = os.path.join(_LIB_DIR, "libplen_oracle_%s.so" % dtype)
         if not os.path.exists(path):
+            assert _LIB_DIR == _HERE, path
             build()
         lib = C.CDLL(path)
         dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)

@@ -512,6 +512,7 @@ __global__ __launch_bounds__(256) void k_wgrad_adam_group(PlenTd3WgradGroup G, P
 
 #include "td3_rows.hip"
 #include "td3_team.hip"
+#include "td3_block.hip"
 
 // ---- K16: timeline probe: slot[0] = the GPU's constant-rate clock (100 MHz) when this one-lane kernel runs.  A node in a captured graph like any
 //      other, so the pipelined trainer's schedule can be read without a profiler serialising it.
@@ -595,6 +596,10 @@ int plentd3_polyak(float *target, const float *param, float tau, int n, void *st
 }
 int plentd3_adam(float *p, float *g, float *m, float *v, float *step, int *done_count, int n, double lr, double beta1, double beta2, float eps, int zero_grad,
                  float *target, float tau, float *copy_out, void *stream) {
+    // k_adam reads and writes four consecutive floats as one 16-byte access: every array must be 16-byte aligned (torch allocations and the flat
+    // parameter buffers are; a sub-view at an odd element offset is not -- refused here rather than faulting on the device)
+    const uintptr_t bits = (uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)target | (uintptr_t)copy_out;
+    if (!p || !g || !m || !v || !step || !done_count || n < 1 || (bits & 15)) return -(int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_adam, dim3(std::min((n + 1023) / 1024, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, step, done_count, n, lr, beta1, beta2, eps, zero_grad, target, tau, copy_out); CHECK();
 }
 int plentd3_critic_rows(const PlenTd3CriticRows *args, void *stream) {
@@ -612,6 +617,26 @@ int plentd3_critic_team(const PlenTd3CriticRows *args, void *stream) {
 int plentd3_policy_team(const PlenTd3PolicyRows *args, void *stream) {
     if (!args || args->B <= 0 || (args->adam_step && !args->done_count)) return -(int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_policy_team, dim3((args->B + QB - 1) / QB), dim3(64 * TEAM_NW), 0, (hipStream_t)stream, *args); CHECK();
+}
+int plentd3_pack(const PlenTd3PackGroup *group, void *stream) {
+    if (!group || group->n_jobs < 1 || group->n_jobs > PLENTD3_PACK_JOBS) return -(int)hipErrorInvalidValue;
+    PlenTd3PackGroup G = *group;
+    int f4 = 0;
+    for (int j = 0; j < G.n_jobs; j++) {
+        const PlenTd3PackJob &J = G.job[j];
+        if (!J.src || !J.dst || J.N < 1 || J.K < 1 || ((uintptr_t)J.dst & 15)) return -(int)hipErrorInvalidValue;
+        G.job[j].f4_0 = f4;
+        f4 += ((J.N + 15) / 16) * ((J.K + 15) / 16) * 64;
+    }
+    hipLaunchKernelGGL(k_pack, dim3((f4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, G); CHECK();
+}
+int plentd3_critic_block(const PlenTd3CriticBlock *args, void *stream) {
+    if (!args || args->rows.B <= 0 || !args->partials || !args->p_at_w1 || !args->p_c_w5t) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_critic_block, dim3((args->rows.B + BLK_R - 1) / BLK_R), dim3(64 * BLK_NW), 0, (hipStream_t)stream, *args); CHECK();
+}
+int plentd3_policy_block(const PlenTd3PolicyBlock *args, void *stream) {
+    if (!args || args->rows.B <= 0 || !args->p_a_w1 || !args->p_a_w2t || (args->rows.adam_step && !args->rows.done_count)) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_policy_block, dim3((args->rows.B + BLK_R - 1) / BLK_R), dim3(64 * BLK_NW), 0, (hipStream_t)stream, *args); CHECK();
 }
 int plentd3_wgrad_group(const PlenTd3WgradGroup *group, void *stream) {
     if (!group || group->n_jobs < 1 || group->n_jobs > PLENTD3_WGRAD_JOBS || group->B <= 0) return -(int)hipErrorInvalidValue;

@@ -104,7 +104,7 @@ class ReplayBuffer(object):
         self.max_size = int(max_size)
         self.ptr = 0
         self.size = 0
-        self.device = torch.device(device) if device is not None else default_device()
+        self.device = _indexed(device) if device is not None else default_device()
         my_path = os.path.abspath(os.path.dirname(__file__))
         self.buffer_path = os.path.join(my_path, "../replay_buffer")
         n, dev = self.max_size, self.device
@@ -173,8 +173,11 @@ class ReplayBuffer(object):
 
     def size_on_device(self):
         """Number of valid rows as an int64 device scalar (what the in-kernel sampling of the fused update reads; refreshed when the size changed)."""
-        if getattr(self, "_size_dev", None) is None or self._size_dev_host != self.size:
-            self._size_dev = torch.tensor(self.size, dtype=torch.long, device=self.device)
+        if getattr(self, "_size_dev", None) is None:
+            self._size_dev = torch.zeros((), dtype=torch.long, device=self.device)
+            self._size_dev_host = None
+        if self._size_dev_host != self.size:           # one persistent scalar, refilled in place (no allocation and no pageable host-to-device copy per call
+            self._size_dev.fill_(self.size)            # while the buffer is still filling: 1e6 train() calls in the reference's recipe; ADVICE r04)
             self._size_dev_host = self.size
         return self._size_dev
 
@@ -243,6 +246,15 @@ def _stacked_views(module, flat):
     o_b14 = 2 * n1
     o_b25 = o_b14 + 2 * h + 2 * module.fc2.weight.numel()
     return {"W14": flat[0:2 * n1].view(2 * h, k), "b14": flat[o_b14:o_b14 + 2 * h], "b25": flat[o_b25:o_b25 + 2 * h]}
+
+
+def _indexed(device):
+    """torch.device('cuda') -> torch.device('cuda', current index): tensors report an indexed device, so an index-less one never compares equal to
+    theirs (TD3Agent(device="cuda") would silently take the autograd iteration in train())."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None and torch.cuda.is_available():
+        return torch.device("cuda", torch.cuda.current_device())
+    return device
 
 
 class _FlatParams(object):
@@ -362,7 +374,7 @@ class TD3Agent(object):
     def __init__(self, state_dim, action_dim, max_action, discount=0.99, tau=0.005, policy_noise=0.2, noise_clip=0.5,
                  policy_freq=2, device=None, lr=3e-4, data_parallel=True):
         self.data_parallel = data_parallel
-        self.device = torch.device(device) if device is not None else default_device()
+        self.device = _indexed(device) if device is not None else default_device()
         self.actor = Actor(state_dim, action_dim, max_action).to(self.device)
         self.critic = Critic(state_dim, action_dim).to(self.device)
         self._broadcast_parameters()                       # every rank starts from rank 0's initialisation

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libplentd3.so")
 EXPORTS = ["plentd3_gather", "plentd3_sample_gather", "plentd3_explore", "plentd3_uniform_actions", "plentd3_store", "plentd3_target_action", "plentd3_q_heads", "plentd3_dh2", "plentd3_relu_mask", "plentd3_colsum", "plentd3_wgrad",
            "plentd3_tanh_out", "plentd3_dtanh", "plentd3_bias_relu", "plentd3_polyak", "plentd3_adam", "plentd3_critic_rows", "plentd3_policy_rows", "plentd3_actor_rows", "plentd3_critic_team", "plentd3_policy_team",
-           "plentd3_wgrad_group", "plentd3_wgrad_adam_group", "plentd3_stamp", "plentd3_version"]
+           "plentd3_wgrad_group", "plentd3_wgrad_adam_group", "plentd3_pack", "plentd3_critic_block", "plentd3_policy_block", "plentd3_stamp", "plentd3_version"]
 ROW, S, A, SA, H = 72, 26, 18, 44, 256
 _lib = None
 
@@ -71,6 +71,30 @@ class AdamFusedArgs(C.Structure):
                 ("eps", C.c_float), ("tau", C.c_float), ("n", C.c_int), ("n_extra", C.c_int), ("extra_off", C.c_int * ADAM_EXTRAS), ("step_advanced", C.c_int)])
 
 
+PACK_JOBS = 16
+
+
+class PackJob(C.Structure):
+    """Mirror of PlenTd3PackJob (include/plentd3.h)."""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p)] + [(n, C.c_int) for n in ("rs", "cs", "N", "K", "f4_0")]
+
+
+class PackGroup(C.Structure):
+    """Mirror of PlenTd3PackGroup (include/plentd3.h)."""
+    _fields_ = [("job", PackJob * PACK_JOBS), ("n_jobs", C.c_int)]
+
+
+class CriticBlockArgs(C.Structure):
+    """Mirror of PlenTd3CriticBlock (include/plentd3.h)."""
+    _fields_ = [("rows", CriticRowsArgs)] + [(n, C.c_void_p) for n in ("p_at_w1", "p_at_w2", "p_at_w3", "p_ct_w14", "p_ct_w2", "p_ct_w5", "p_c_w14", "p_c_w2", "p_c_w5",
+                                                                        "p_c_w2t", "p_c_w5t", "partials")]
+
+
+class PolicyBlockArgs(C.Structure):
+    """Mirror of PlenTd3PolicyBlock (include/plentd3.h)."""
+    _fields_ = [("rows", PolicyRowsArgs)] + [(n, C.c_void_p) for n in ("p_a_w1", "p_a_w2", "p_a_w3", "p_c_w14", "p_c_w2", "p_c_w2t", "p_c_w1ta", "p_a_w3t", "p_a_w2t")]
+
+
 TEAM_MAX_BATCH = 512          # FusedTD3(team=None): batches up to this size take the small-batch kernels (csrc/td3_team.hip)
 
 
@@ -105,6 +129,9 @@ def load():
         lib.plentd3_actor_rows.argtypes = [C.POINTER(ActorRowsArgs), vp]
         lib.plentd3_critic_team.argtypes = [C.POINTER(CriticRowsArgs), vp]
         lib.plentd3_policy_team.argtypes = [C.POINTER(PolicyRowsArgs), vp]
+        lib.plentd3_pack.argtypes = [C.POINTER(PackGroup), vp]
+        lib.plentd3_critic_block.argtypes = [C.POINTER(CriticBlockArgs), vp]
+        lib.plentd3_policy_block.argtypes = [C.POINTER(PolicyBlockArgs), vp]
         lib.plentd3_wgrad_group.argtypes = [C.POINTER(WgradGroup), vp]
         lib.plentd3_wgrad_adam_group.argtypes = [C.POINTER(WgradGroup), C.POINTER(AdamFusedArgs), vp]
         lib.plentd3_adam.argtypes = [vp, vp, vp, vp, vp, vp, i, C.c_double, C.c_double, C.c_double, f, i, vp, f, vp, vp]
@@ -156,11 +183,18 @@ class FlatAdam(object):
         if steps:
             self.step_t.fill_(steps.pop())
 
-    def fused_args(self, target=None, tau=0.0, extras=(), step_advanced=False):
-        """PlenTd3AdamFused for plentd3_wgrad_adam_group: this optimiser's step taken inside the weight-gradient kernel (hyper-parameters as they are now)."""
+    def ensure_bound(self):
+        """Re-bind if optimizer.load_state_dict() (a resumed run) has replaced the state tensors since the last step.  Must run BEFORE a pass kernel that
+        advances step_t (PlenTd3CriticRows.adam_step): bind() refills step_t from the loaded state, and a refill after the kernel's increment would
+        leave the counter one behind for good."""
         st0 = self.opt.state.get(self.params[0])
         if (not st0 or st0["exp_avg"].data_ptr() != self.m.data_ptr()) and not torch.cuda.is_current_stream_capturing():
             self.bind()
+
+    def fused_args(self, target=None, tau=0.0, extras=(), step_advanced=False):
+        """PlenTd3AdamFused for plentd3_wgrad_adam_group: this optimiser's step taken inside the weight-gradient kernel (hyper-parameters as they are now)."""
+        if not step_advanced:        # (with step_advanced the pass kernel has already counted this step: ensure_bound() ran before it was launched)
+            self.ensure_bound()
         g = self.opt.param_groups[0]
         a = AdamFusedArgs()
         a.p, a.g, a.m, a.v, a.step, a.done_count = (t.data_ptr() for t in (self.p, self.g, self.m, self.v, self.step_t, self.done))
@@ -185,7 +219,7 @@ class FlatAdam(object):
 class FusedTD3(object):
     """update(data, idx, with_policy) == td3.td3_update(agent, (data rows idx split into s, a, s2, r, not_done), with_policy)."""
 
-    def __init__(self, agent, seed=0, rows=None, team=None):
+    def __init__(self, agent, seed=0, rows=None, team=None, block=None):
         if agent.device.type != "cuda":
             raise PlenTd3Error("FusedTD3 needs the agent on a HIP device")
         self.agent = agent
@@ -199,10 +233,17 @@ class FusedTD3(object):
         # launches (PipelinedVecTD3Trainer: 0.73 -> 0.66 ms per step); on an otherwise idle GPU the library GEMMs are faster (critic pass 239 vs 315 us)
         self.rows = (os.environ.get("PLEN_TD3_ROWS", "0") == "1") if rows is None else bool(rows)
         # small batches (the reference's batch 100 with one update per env-step: a chain of dependent updates, so latency is what counts): the same
-        # row-local passes with a TEAM of 8 waves per 16 batch rows (csrc/td3_team.hip) and all weight gradients of a pass in one launch
+        # row-local passes with a TEAM of 8 waves per 4 batch rows (csrc/td3_team.hip) and all weight gradients of a pass in one launch
         # (plentd3_wgrad_group): 2 + 1 (Adam) launches per critic update instead of ~35.  None: chosen per call, batch <= TEAM_MAX_BATCH.
         self.team = (None if "PLEN_TD3_TEAM" not in os.environ else os.environ["PLEN_TD3_TEAM"] == "1") if team is None else bool(team)
         self._team_pass = False      # did the last critic pass take the team kernels (policy_backward follows it)
+        # large batches (the benchmark's 4096): 16 batch rows per 256-thread workgroup -- one per compute unit at batch 4096 --, the four waves split every
+        # layer's output features, activations stay in LDS, weights are read pre-packed in matrix-core operand order (csrc/td3_block.hip).  None: chosen per
+        # call, batch > TEAM_MAX_BATCH; the weight gradients stay what `rows` says (single-wave or 4-wave workgroups).
+        self.block = (None if "PLEN_TD3_BLOCK" not in os.environ else os.environ["PLEN_TD3_BLOCK"] == "1") if block is None else bool(block)
+        self._block_pass = False
+        self._packs = {}             # name -> packed copy of a weight matrix (plentd3_pack), rewritten before every pass that reads it
+        self._partials = None
         # one rank, small batch, flat Adam: the optimiser step is taken inside the grouped weight-gradient kernel (plentd3_wgrad_adam_group).
         # update() sets _fuse = {"critic": target-or-None, "actor": target} for the passes it is about to run and reads _fused_done back.
         self.fuse_adam = os.environ.get("PLEN_TD3_FUSE_ADAM", "1") == "1"
@@ -232,6 +273,34 @@ class FusedTD3(object):
         single-wave row kernels (rows=True: the pipelined trainer's update beside resident env launches, where a 512-thread workgroup would wait for
         eight free wave slots on one compute unit)."""
         return (not self.rows and B <= TEAM_MAX_BATCH) if self.team is None else self.team
+
+    def _use_block(self, B):
+        """Large-batch kernels for this batch size?  An explicit block= wins; otherwise every batch beyond the small-batch kernels' range takes them."""
+        return (B > TEAM_MAX_BATCH) if self.block is None else self.block
+
+    def _pack(self, jobs):
+        """jobs: (name, tensor, N, K, rs, cs, element offset): M(i, k) = tensor.flat[offset + i rs + k cs] -> self._packs[name] in matrix-core operand order."""
+        G = PackGroup()
+        assert 1 <= len(jobs) <= PACK_JOBS
+        for J, (name, t, N, K, rs, cs, off) in zip(G.job, jobs):
+            n = ((N + 15) // 16) * ((K + 15) // 16) * 256
+            dst = self._packs.get(name)
+            if dst is None:
+                dst = self._packs[name] = torch.empty(n, device=self.dev, dtype=torch.float32)
+            assert t.dtype == torch.float32 and t.is_contiguous() and dst.numel() == n
+            J.src, J.dst, J.rs, J.cs, J.N, J.K = t.data_ptr() + 4 * off, dst.data_ptr(), rs, cs, N, K
+        G.n_jobs = len(jobs)
+        _chk(self.lib.plentd3_pack(C.byref(G), self._stream()))
+
+    @staticmethod
+    def _nt(name, w):
+        """nn.Linear weight [out][in] as the A operand of Y^T = W X^T"""
+        return (name, w, w.shape[0], w.shape[1], w.shape[1], 1, 0)
+
+    @staticmethod
+    def _tr(name, w):
+        """its transpose (input gradients: dX^T = W^T dY^T)"""
+        return (name, w, w.shape[1], w.shape[0], 1, w.shape[1], 0)
 
     def _wgrad_group(self, B, jobs, which=None, extras=()):
         """Every (dh, x, gw, gb) of `jobs` as _wgrad, in one launch (plentd3_wgrad_group: the batch is one reduction chunk).  With update()'s consent
@@ -394,6 +463,12 @@ class FusedTD3(object):
         idx: LongTensor [B] of replay rows, or an int B with `total` (device int64 scalar: transitions written so far) to draw them here
         (then, with self.rows, everything up to the weight gradients runs as one row-block kernel: critic_backward_rows)."""
         self._team_pass = False
+        self._block_pass = False
+        if isinstance(idx, int) and noise is None and self._use_block(idx):
+            return self.critic_backward_rows(data, idx, total, guard, block=True)
+        if self.block is True and not isinstance(idx, int):            # explicit rows (and noise) through the large-batch kernels: the golden iterations
+            assert idx.dtype == torch.long and idx.is_contiguous() and (noise is None or (noise.is_contiguous() and tuple(noise.shape) == (idx.shape[0], A)))
+            return self.critic_backward_rows(data, int(idx.shape[0]), total, guard, block=True, idx=idx, noise=noise)
         if isinstance(idx, int) and noise is None and (self.rows or self._use_team(idx)):
             return self.critic_backward_rows(data, idx, total, guard, team=self._use_team(idx))
         if self.team is True and not isinstance(idx, int):          # explicit rows (and noise) through the small-batch kernels: the golden iterations
@@ -465,7 +540,7 @@ class FusedTD3(object):
         self._probe(4)
         return loss[0]
 
-    def critic_backward_rows(self, data, B, total, guard=0, team=False, idx=None, noise=None):
+    def critic_backward_rows(self, data, B, total, guard=0, team=False, idx=None, noise=None, block=False):
         """critic_backward() with everything between the sampling and the weight gradients in ONE launch of single-wave workgroups
         (plentd3_critic_rows, csrc/td3_rows.hip): 8 kernels per critic update instead of ~35, and none of them needs more than one free wave slot
         per workgroup to start, which is what the update lacks beside two resident env launches.  Draws its random numbers in-kernel
@@ -473,14 +548,14 @@ class FusedTD3(object):
         ag, lib, st = self.agent, self.lib, self._stream()
         dev = self.dev
         assert data.dtype == torch.float32 and data.is_contiguous() and data.shape[1] == ROW and (total is not None or idx is not None)
-        assert team or (idx is None and noise is None)
+        assert team or block or (idx is None and noise is None)
         new = self._alloc or (lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32))
         with torch.no_grad():
             at, ct, cr = ag.actor_target, ag.critic_target, ag.critic
             tv, cv, gv = ag._critic_target_flat.views, ag._critic_flat.views, ag._critic_grads.views
             batch, sa_pi, sa2, dq = new(B, ROW), new(B, SA), new(B, SA), new(B, 2)
             t0, t1, c1, c2, dh2, dh1 = (new(B, 2 * H) for _ in range(6))
-            loss = new(2) if team else torch.zeros(2, device=dev, dtype=torch.float32)         # (the team kernel stores its loss, the row kernel adds to it)
+            loss = new(2) if (team or block) else torch.zeros(2, device=dev, dtype=torch.float32)         # (the team / block kernels store their loss, the row kernel adds to it)
             self._zero_grads("critic")
             if self._done_count is None:
                 self._done_count = torch.zeros(1, device=dev, dtype=torch.int32)
@@ -488,6 +563,8 @@ class FusedTD3(object):
             a.data, a.rng, a.total, a.capacity, a.guard = data.data_ptr(), self.rng.data_ptr(), (total.data_ptr() if total is not None else None), int(data.shape[0]), int(guard)
             a.idx, a.noise = (idx.data_ptr() if idx is not None else None), (noise.data_ptr() if noise is not None else None)
             fused_step = team and self._fuse is not None and "critic" in self._fuse        # the pass kernel advances the step counter for the launch that takes the step
+            if fused_step:
+                self._critic_adam.ensure_bound()          # a resumed optimiser's state is taken over BEFORE the kernel counts the step
             a.adam_step = self._critic_adam.step_t.data_ptr() if fused_step else None
             for pre, net in (("at", at),):
                 a.at_w1, a.at_b1, a.at_w2, a.at_b2, a.at_w3, a.at_b3 = (t.data_ptr() for t in (net.fc1.weight, net.fc1.bias, net.fc2.weight, net.fc2.bias, net.fc3.weight, net.fc3.bias))
@@ -511,7 +588,23 @@ class FusedTD3(object):
                 self._team_pass = True
                 self._probe(4)
                 return loss[0]
-            _chk(lib.plentd3_critic_rows(C.byref(a), st))
+            if block:       # large batch: 16 rows per 256-thread workgroup, packed weights (csrc/td3_block.hip); weight gradients as below
+                nt, tr = self._nt, self._tr
+                self._pack([nt("at_w1", at.fc1.weight), nt("at_w2", at.fc2.weight), nt("at_w3", at.fc3.weight),
+                            nt("ct_w14", tv["W14"]), nt("ct_w2", ct.fc2.weight), nt("ct_w5", ct.fc5.weight),
+                            nt("c_w14", cv["W14"]), nt("c_w2", cr.fc2.weight), nt("c_w5", cr.fc5.weight), tr("c_w2t", cr.fc2.weight), tr("c_w5t", cr.fc5.weight)])
+                nb = (B + 15) // 16
+                if self._partials is None or self._partials.numel() < 4 * nb:
+                    self._partials = torch.zeros(4 * nb, device=dev, dtype=torch.float32)
+                pa = CriticBlockArgs()
+                pa.rows = a
+                for n_ in ("at_w1", "at_w2", "at_w3", "ct_w14", "ct_w2", "ct_w5", "c_w14", "c_w2", "c_w5", "c_w2t", "c_w5t"):
+                    setattr(pa, "p_" + n_, self._packs[n_].data_ptr())
+                pa.partials = self._partials.data_ptr()
+                _chk(lib.plentd3_critic_block(C.byref(pa), st))
+                self._block_pass = True
+            else:
+                _chk(lib.plentd3_critic_rows(C.byref(a), st))
             self._probe(3)
             # weight gradients (reductions over the batch): last layers, second layers, stacked first layers
             _chk(lib.plentd3_colsum(_p(c2), 2 * H, _p(dq), 2, _p(cr.fc3.weight.grad), B, H, int(self.rows), st))
@@ -530,7 +623,7 @@ class FusedTD3(object):
         s, sa_pi, B = self._saved
         new = self._alloc or (lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32))
         cr = ag.critic
-        if self.rows or self._team_pass:
+        if self.rows or self._team_pass or self._block_pass:
             with torch.no_grad():
                 ac = ag.actor
                 self._zero_grads("actor")
@@ -545,13 +638,26 @@ class FusedTD3(object):
                 if self._team_pass and self._fuse is not None and "actor" in self._fuse:
                     if self._policy_done is None:
                         self._policy_done = torch.zeros(1, device=dev, dtype=torch.int32)
+                    self._actor_adam.ensure_bound()
                     a.adam_step, a.done_count = self._actor_adam.step_t.data_ptr(), self._policy_done.data_ptr()
                 if self._team_pass:
                     _chk(lib.plentd3_policy_team(C.byref(a), st))
                     self._wgrad_group(B, [(dz, p2, ac.fc3.weight.grad, ac.fc3.bias.grad), (dp2, p1, ac.fc2.weight.grad, ac.fc2.bias.grad),
                                           (dp1, s, ac.fc1.weight.grad, ac.fc1.bias.grad)], which="actor")
                     return
-                _chk(lib.plentd3_policy_rows(C.byref(a), st))
+                if self._block_pass:
+                    nt, tr = self._nt, self._tr
+                    self._pack([nt("a_w1", ac.fc1.weight), nt("a_w2", ac.fc2.weight), nt("a_w3", ac.fc3.weight),
+                                nt("c_w14", ag._critic_flat.views["W14"]), nt("c_w2", cr.fc2.weight), tr("c_w2t", cr.fc2.weight),
+                                ("c_w1ta", ag._critic_flat.views["W14"], A, H, 1, SA, S),            # (i = action j, k = hidden) -> fc1.weight[k][26 + j]
+                                tr("a_w3t", ac.fc3.weight), tr("a_w2t", ac.fc2.weight)])
+                    pa = PolicyBlockArgs()
+                    pa.rows = a
+                    for n_ in ("a_w1", "a_w2", "a_w3", "c_w14", "c_w2", "c_w2t", "c_w1ta", "a_w3t", "a_w2t"):
+                        setattr(pa, "p_" + n_, self._packs[n_].data_ptr())
+                    _chk(lib.plentd3_policy_block(C.byref(pa), st))
+                else:
+                    _chk(lib.plentd3_policy_rows(C.byref(a), st))
                 self._wgrad(dz, p2, ac.fc3.weight.grad, ac.fc3.bias.grad)
                 self._wgrad(dp2, p1, ac.fc2.weight.grad, ac.fc2.bias.grad)
                 self._wgrad(dp1, s, ac.fc1.weight.grad, ac.fc1.bias.grad)

@@ -1,5 +1,5 @@
 """Latency of ONE TD3 update at the reference's batch size (100, plen_td3.py:28) for the three shapes of the same arithmetic: layer by layer (library
-GEMMs, ~35 launches), one wave per 16 rows (csrc/td3_rows.hip), a team of 8 waves per 16 rows + grouped weight gradients (csrc/td3_team.hip).
+GEMMs, ~35 launches), one wave per 16 rows (csrc/td3_rows.hip), a team of 8 waves per 4 rows + grouped weight gradients (csrc/td3_team.hip).
 Each is captured as a hipGraph of 32 updates (policy_freq 2: 16 with the delayed policy update) and replayed.
 usage: python scripts/gpu_td3_small_batch.py [batch ...]   -> gpurun_out/r04_td3_small_batch.json"""
 import json, os, sys, time

@@ -359,7 +359,7 @@ def test_policy_rows_kernel_equals_the_layer_by_layer_policy_gradient(B):
 
 @pytest.mark.parametrize("B,total", [(100, 700), (512, 50000), (16, 40), (37, 900), (3, 5)])
 def test_small_batch_team_kernels_equal_the_layer_by_layer_update(B, total):
-    """The small-batch shape of the update (csrc/td3_team.hip: a team of 8 waves per 16 batch rows; every weight gradient of a pass in one
+    """The small-batch shape of the update (csrc/td3_team.hip: a team of 8 waves per 4 batch rows; every weight gradient of a pass in one
     plentd3_wgrad_group launch) against the layer-by-layer path (library GEMMs + one kernel per step) from the same random state: the reference's
     batch 100 (plen_td3.py:28), the largest batch that takes this path by default, one row block exactly, a ragged last block, fewer rows than a
     group of four.  Same sampled rows, same smoothing noise; loss, every critic gradient and every actor gradient agree to f32 summation order;
@@ -432,6 +432,69 @@ def test_adam_step_inside_the_weight_gradient_kernel_equals_the_separate_step():
         assert float(out[fuse][-2]) == 6.0 and float(out[fuse][-1]) == 3.0
     for a_, b_ in zip(out[False], out[True]):
         assert torch.equal(a_, b_)
+
+
+def test_resumed_optimizer_keeps_its_step_count_through_the_fused_small_batch_update():
+    """optimizer.load_state_dict() between updates (a resumed run) replaces the state tensors FlatAdam mirrors; the re-bind has to happen before the pass
+    kernel counts the step, or the fused path's counter stays one behind the separate-Adam path's for good: after a reload at step 4, four
+    more updates leave bitwise equal parameters, moments and step counts (8 / 4) on both paths."""
+    from plen_ml_walk_amd import td3 as T
+    from plen_ml_walk_amd.td3_fused import FusedTD3
+    data = torch.randn(5000, 72, device="cuda")
+    data[:, 70] = torch.rand(5000, device="cuda"); data[:, 71] = (torch.rand(5000, device="cuda") > 0.1).float()
+    tot = torch.tensor(5000, dtype=torch.long, device="cuda")
+    out = {}
+    for fuse in (False, True):
+        torch.manual_seed(33)
+        ag = T.TD3Agent(26, 18, 1.0, data_parallel=False)
+        fz = FusedTD3(ag, seed=4, team=True)
+        fz.enable_flat_adam()
+        fz.fuse_adam = fuse
+        for k in range(4):
+            fz.update(data, 100, with_policy=(k % 2 == 1), all_reduce=False, total=tot)
+        torch.cuda.synchronize()
+        for opt in (ag.critic_optimizer, ag.actor_optimizer):           # what TD3Agent.load() does with the two optimizer files
+            sd = opt.state_dict()
+            sd = {"state": {k_: {n: (v.clone() if torch.is_tensor(v) else v) for n, v in st.items()} for k_, st in sd["state"].items()}, "param_groups": sd["param_groups"]}
+            opt.load_state_dict(sd)
+        for k in range(4, 8):
+            fz.update(data, 100, with_policy=(k % 2 == 1), all_reduce=False, total=tot)
+        torch.cuda.synchronize()
+        out[fuse] = [ag._critic_flat.flat.clone(), ag._actor_flat.flat.clone(), fz._critic_adam.m.clone(), fz._critic_adam.v.clone(), fz._actor_adam.m.clone(),
+                     fz._critic_adam.step_t.clone(), fz._actor_adam.step_t.clone()]
+        assert float(out[fuse][-2]) == 8.0 and float(out[fuse][-1]) == 4.0, (fuse, float(out[fuse][-2]), float(out[fuse][-1]))
+    for a_, b_ in zip(out[False], out[True]):
+        assert torch.equal(a_, b_)
+
+
+def test_agent_given_an_index_less_device_still_takes_the_fused_iteration():
+    """TD3Agent(device="cuda") (no index) and the replay tensor's cuda:0 used to compare unequal, which silently sent train() down the ~170-launch autograd
+    iteration; the size scalar the fused update reads is one persistent device tensor, refilled in place."""
+    from plen_ml_walk_amd import td3 as T
+    a = T.TD3Agent(26, 18, 1.0, device="cuda", data_parallel=False)
+    buf = T.ReplayBuffer(5000, device="cuda")
+    assert a.device.index is not None and buf.device.index is not None
+    buf.add_batch(torch.randn(300, 26), torch.rand(300, 18) * 2 - 1, torch.randn(300, 26), torch.randn(300), (torch.rand(300) < 0.05).float())
+    a.train(buf, 100)
+    assert a._fused is not None and a._fused._team_pass
+    p = buf.size_on_device().data_ptr()
+    buf.add_batch(torch.randn(10, 26), torch.rand(10, 18) * 2 - 1, torch.randn(10, 26), torch.randn(10), torch.zeros(10))
+    assert buf.size_on_device().data_ptr() == p and int(buf.size_on_device()) == 310
+
+
+def test_flat_adam_refuses_a_misaligned_view():
+    """plentd3_adam moves four floats per access: a sub-view at an odd element offset is refused (-hipErrorInvalidValue = -1), not faulted on."""
+    from plen_ml_walk_amd import td3_fused as F
+    lib = F.load()
+    n = 1000
+    p, g, m, v = (torch.zeros(n + 4, device="cuda") for _ in range(4))
+    step, done = torch.zeros((), device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+    st = F.C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.plentd3_adam(F._p(p[1:]), F._p(g), F._p(m), F._p(v), F._p(step), F._p(done), n, 3e-4, 0.9, 0.999, 1e-8, 0, None, 0.0, None, st) == -1
+    assert lib.plentd3_adam(F._p(p), F._p(g), F._p(m), F._p(v), F._p(step), F._p(done), n, 3e-4, 0.9, 0.999, 1e-8, 0, None, 0.0, F._p(p[2:]), st) == -1
+    assert lib.plentd3_adam(F._p(p), F._p(g), F._p(m), F._p(v), F._p(step), F._p(done), n, 3e-4, 0.9, 0.999, 1e-8, 0, None, 0.0, None, st) == 0
+    torch.cuda.synchronize()
+    assert float(step) == 1.0
 
 
 def test_agent_train_takes_the_fused_iteration_on_the_device_and_honours_a_callers_sampling(tmp_path):
@@ -511,8 +574,10 @@ def test_single_transition_add_and_one_kernel_select_action_equal_the_general_pa
     assert np.abs(fast - slow).max() <= 1e-4 and np.abs(slow).max() > 0.1          # (the shipped policy's pre-activations are O(10): 3e-5 observed)
 
 
-def test_small_batch_update_keeps_its_scratch_rows_inside_the_batch():
-    """Canary rows behind every per-iteration scratch matrix of a team-path update at B = 100 (16-row blocks: the last one is ragged) stay untouched."""
+@pytest.mark.parametrize("B", [100, 98, 101])
+def test_small_batch_update_keeps_its_scratch_rows_inside_the_batch(B):
+    """Canary rows behind every per-iteration scratch matrix of a team-path update stay untouched: the reference's batch 100 (25 whole blocks of 4 rows) and two
+    batches whose last block is ragged (98 = 24 blocks + 2 rows, 101 = 25 + 1: the guarded stores of k_critic_team / k_policy_team)."""
     from plen_ml_walk_amd import td3 as T
     from plen_ml_walk_amd.td3_fused import FusedTD3
     torch.manual_seed(5)
@@ -526,10 +591,10 @@ def test_small_batch_update_keeps_its_scratch_rows_inside_the_batch():
         return full[:shape[0]]
     fz._alloc = alloc
     data = torch.randn(400, 72, device="cuda")
-    fz.critic_backward(data, 100, total=torch.tensor(400, dtype=torch.long, device="cuda"))
+    fz.critic_backward(data, B, total=torch.tensor(400, dtype=torch.long, device="cuda"))
     fz.policy_backward()
     torch.cuda.synchronize()
-    assert len(made) >= 10
+    assert len(made) >= 10 and fz._team_pass
     for full, n in made:
         assert bool((full[n:] == 777.0).all()), tuple(full.shape)
 

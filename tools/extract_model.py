@@ -360,11 +360,13 @@ def main():
         moving_joints=moving, base=base, links=links, feet=feet, bodies=bodies, boxes=boxes,
         noncontact_order=noncontact_order, margin=MARGIN)
 
-    out_json = os.path.join(ROOT, "plen_ml_walk_amd/model/plen_model.json")
+    # PLEN_MODEL_OUT=<dir>: write the three tables there instead of over the committed ones (model-table hypotheses, scripts/pin/margin_pooled.py)
+    alt = os.environ.get("PLEN_MODEL_OUT")
+    out_json = os.path.join(alt, "plen_model.json") if alt else os.path.join(ROOT, "plen_ml_walk_amd/model/plen_model.json")
     with open(out_json, "w") as f:
         json.dump(model, f, indent=1)
-    write_raw_header(model, os.path.join(ROOT, "oracle/plen_model_raw.h"))
-    write_merged_header(model, os.path.join(ROOT, "plen_ml_walk_amd/csrc/plen_model_gen.h"))
+    write_raw_header(model, os.path.join(alt, "plen_model_raw.h") if alt else os.path.join(ROOT, "oracle/plen_model_raw.h"))
+    write_merged_header(model, os.path.join(alt, "plen_model_gen.h") if alt else os.path.join(ROOT, "plen_ml_walk_amd/csrc/plen_model_gen.h"))
     print("total mass", total_mass)
     print("zero-pose COM at spawn", model["zero_pose_com_at_spawn"])
     for ft in feet:
