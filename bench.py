@@ -366,6 +366,18 @@ def td3_leg(a, dev, rank, world, dist, steps, warmup):
             out["reference_batch_100"] = {k: r[k] for k in ("value", "unit", "grad_steps_per_s", "ms_per_step", "batch_per_rank", "update_to_data")}
         except Exception as ex:
             out["reference_batch_100"] = {"value": None, "error": repr(ex)}
+        # configs[2] at the REFERENCE'S sample ratio: 100 samples drawn per env-step (plen_td3.py:28 batch 100, :119-120 one update per env-step) = 100
+        # updates of batch 4096 per vector step of 4096 env-steps: learner-bound by construction
+        try:
+            saved = a.td3_updates, a.td3_schedule
+            a.td3_updates, a.td3_schedule = 100, "sync"
+            try:
+                r = _td3_run(a, dev, rank, world, dist, 12, 2, a.td3_batch)
+            finally:
+                a.td3_updates, a.td3_schedule = saved
+            out["reference_sample_ratio"] = {k: r[k] for k in ("value", "unit", "grad_steps_per_s", "ms_per_step", "batch_per_rank", "update_to_data", "schedule")}
+        except Exception as ex:
+            out["reference_sample_ratio"] = {"value": None, "error": repr(ex)}
     return out
 
 
@@ -559,9 +571,76 @@ def _td3_run(a, dev, rank, world, dist, steps, warmup, batch):
            "workload": "BASELINE.json configs[%d]: %d envs per GPU + TD3 (actor 26-256-256-18, twin critic 44-256-256-1, Adam 3e-4, policy_freq 2), exploration N(0, 0.1)" % (2 if world == 1 else 3, n)}
     if pipelined:
         out["episodes_finished_since_start"] = tr.episode_stats()          # device-side bookkeeping of the ring-store kernel (returns of an untrained policy)
+        if batch > 512 and rank == 0:
+            try:
+                out["roofline"] = _td3_roofline(tr, batch, dev)
+            except Exception as ex:
+                out["roofline"] = {"error": repr(ex)}
     for e in envs:
         e.close()
     return out
+
+
+TD3_CRITIC_PASS_MAC = 516096        # multiply-adds per batch row of the critic pass (td3.py:277-323 without the weight gradients): target actor 26x256 + 256x256 + 256x18, twin target
+                                    # critics 2 x (44x256 + 256x256 + 256), twin critics the same, input gradients 2 x 256x256
+MFMA_F32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector rate
+
+
+def _td3_roofline(tr, batch, dev):
+    """The learner's dominant kernel (k_critic_block: the row-local part of a critic update, csrc/td3_block.hip) priced against the fp32 matrix peak, (a) INSIDE the
+    running loop, beside the env launches: device-clock stamps (plentd3_stamp nodes in the update graph, the timeline probes of train_vec) right before and
+    after the kernel over 128 more vector steps of the same trainer, re-captured with the probes in; (b) alone on the idle GPU: HIP events around 20 launches."""
+    import torch
+    tr.recapture()
+    tl = tr.enable_timeline(64)
+    for _ in range(64 * 2 + 40):
+        tr.step()
+    tr.sync()
+    torch.cuda.synchronize()
+    t = tl.cpu().numpy().astype("int64")
+    c = 4 * tr.H
+    ok = (t[:, c + 2] > 0) & (t[:, c + 3] > t[:, c + 2])
+    k_us = float(((t[ok, c + 3] - t[ok, c + 2]) / 100.0).mean())          # 100 MHz ticks
+    upd_us = float(((t[ok, c + 5] - t[ok, c]) / 100.0).mean())
+    flop = 2.0 * TD3_CRITIC_PASS_MAC * batch
+    # alone: the same kernel through the same FusedTD3, nothing else on the GPU
+    fz = tr.fused
+    data, tot = tr.replay.data, tr.total_u
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    lib = fz.lib
+
+    class OnlyPass(object):          # the pass kernel alone: packing and weight gradients skipped
+        def __getattr__(self, n):
+            return (lambda *a_: 0) if n in ("plentd3_pack", "plentd3_wgrad_big", "plentd3_adam_big") else getattr(lib, n)
+    fz.critic_backward(data, batch, total=tot); torch.cuda.synchronize()
+    fz.lib = OnlyPass()
+    try:
+        def one():
+            fz._zeroed = {"critic": True}
+            fz.critic_backward(data, batch, total=tot)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            one(); one()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()                 # (a graph: eagerly the 25 host calls per pass are slower than the kernel)
+        with torch.cuda.graph(g):
+            for _ in range(8):
+                one()
+        g.replay(); torch.cuda.synchronize()
+        ev[0].record()
+        for _ in range(5):
+            g.replay()
+        ev[1].record(); torch.cuda.synchronize()
+    finally:
+        fz.lib = lib
+    alone_us = ev[0].elapsed_time(ev[1]) / 40 * 1e3
+    return {"bound": "mfma_f32", "kernel": "k_critic_block", "achieved": flop / (k_us * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": flop / (k_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, "kernel_us": k_us, "update_us": upd_us, "flop_per_launch": flop,
+            "alone_kernel_us": alone_us, "alone_achieved": flop / (alone_us * 1e-6) / 1e12, "alone_frac": flop / (alone_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+            "note": "algorithmic flop = 2 x %d multiply-adds per batch row x %d rows per launch; kernel_us = mean over %d launches of the device-clock interval between the "
+                    "stamp nodes around the kernel in the update graph, beside two resident env launches (the envs hold every wave slot: the kernel's workgroups wait for "
+                    "retiring env waves and share their SIMDs' issue ports); alone_* = the same launch back to back on the idle GPU (HIP events around 5 replays of a graph of 8: "
+                    "launch gaps included).  rocprofv3 kernel trace of the stand-alone update (75.6 us per launch): profiles/r05_td3_block_kernel_stats.csv" % (TD3_CRITIC_PASS_MAC, batch, int(ok.sum()))}
 
 
 def flatten_for_the_driver(out):

@@ -173,6 +173,20 @@ typedef struct PlenTd3PolicyBlock {
 } PlenTd3PolicyBlock;
 int plentd3_policy_block(const PlenTd3PolicyBlock *args, void *stream);
 
+/* Every weight gradient of a LARGE-batch pass in one launch, reduced deterministically in two stages (csrc/td3_block.hip: k_wgrad_big): the batch is cut into
+ * `chunks` of rows_per_chunk rows; workgroup (job, 32 x 64 tile, chunk) STORES its partial dW[n][k] = sum_b dH[b][n] X[b][k] (and db[n] = sum_b dH[b][n] when boff >= 0)
+ * at partial[chunk stride + goff + n K + k] (boff + n): goff / boff = the element offsets of dW / db in the network's flat gradient buffer, so partial[chunk] has
+ * the bucket's layout (stride >= its length, a multiple of 4).  kind 1: a head row (N = 1, K <= 256, a multiple of 4; dH strided, X 16-byte aligned rows).
+ * plentd3_adam_big then takes plentd3_adam's step on g[i] = bucket[i] + sum_chunks partial[chunk][i] (added in chunk order: same bits every run) and leaves the
+ * bucket zero; reduce_only != 0: bucket[i] = that sum and no step (several ranks: all-reduce the bucket, then plentd3_adam).  partial must be zero wherever no
+ * job writes (the head biases).  wg0 is filled in by the call. */
+#define PLENTD3_WGRAD_BIG_JOBS 8
+typedef struct PlenTd3WgradBigJob { const float *dH; const float *X; int ds, xs, N, K, goff, boff, kind, wg0; } PlenTd3WgradBigJob;
+typedef struct PlenTd3WgradBig { PlenTd3WgradBigJob job[PLENTD3_WGRAD_BIG_JOBS]; int n_jobs, B, chunks, rows_per_chunk, stride; float *partial; } PlenTd3WgradBig;
+int plentd3_wgrad_big(const PlenTd3WgradBig *group, void *stream);
+int plentd3_adam_big(float *p, float *g, float *m, float *v, float *step, int *done_count, int n, double lr, double beta1, double beta2, float eps,
+                     float *target, float tau, float *copy_out, const float *partial, int chunks, int stride, int reduce_only, void *stream);
+
 /* plen_td3.py:101-104 for a whole vector step as one launch: action [B][18] = clamp(actor(state [B][26]) + N(0, sigma), +-max_a), the noise drawn as
  * plentd3_explore draws it (rng, bumped by the plentd3_store that follows); p1, p2 [B][256] are scratch. */
 typedef struct PlenTd3ActorRows {

@@ -40,7 +40,7 @@ TD3_OUT = os.path.join(CSRC, "libplentd3.so")
 
 def build_td3_kernels(force=False):
     """Compile td3_kernels.hip -> csrc/libplentd3.so (gfx950): the fused TD3 update's non-GEMM kernels (include/plentd3.h)."""
-    deps = [TD3_SRC, os.path.join(CSRC, "td3_rows.hip"), os.path.join(CSRC, "td3_team.hip"), os.path.join(os.path.dirname(_HERE), "include", "plentd3.h")]
+    deps = [TD3_SRC, os.path.join(CSRC, "td3_rows.hip"), os.path.join(CSRC, "td3_team.hip"), os.path.join(CSRC, "td3_block.hip"), os.path.join(os.path.dirname(_HERE), "include", "plentd3.h")]
     if not force and os.path.exists(TD3_OUT) and all(os.path.getmtime(TD3_OUT) >= os.path.getmtime(d) for d in deps):
         return TD3_OUT
     subprocess.check_call([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", TD3_OUT, TD3_SRC], cwd=CSRC)

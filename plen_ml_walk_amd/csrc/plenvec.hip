@@ -2169,7 +2169,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(real)
 // Which block an env runs in does not change its result (tests assert bitwise equality with the identity placement).
 // ------------------------------------------------------------------------------------------------
 #define BAL_BUCKETS 256
-__global__ __launch_bounds__(1024) void plen_balance_kernel(int n, int groups, const int *aux, int *perm) {
+__global__ __launch_bounds__(1024) void plen_balance_kernel(int n, int groups, const int *aux, int *perm, int snake) {
     __shared__ int hist[BAL_BUCKETS], base[BAL_BUCKETS];
     const int t = threadIdx.x;
     if (t < BAL_BUCKETS) hist[t] = 0;
@@ -2187,7 +2187,9 @@ __global__ __launch_bounds__(1024) void plen_balance_kernel(int n, int groups, c
         const int b = min(BAL_BUCKETS - 1, max(0, aux[(size_t)e * AUXN + 7]) / 448);
         const int r = atomicAdd(&base[BAL_BUCKETS - 1 - b], 1);        // rank by descending cost
         const int slot = r / groups, g = r % groups;
-        int blk = slot * groups + ((slot & 1) ? groups - 1 - g : g);  // snake over the SIMDs
+        // snake over the SIMDs; or (PLENVEC_BALANCE_ORDER=descending) plain descending cost, block 0 the heaviest and the last block the cheapest: blocks start
+        // in index order, so when other work holds wave slots (a learner beside the envs) the waves that start late are the ones that finish soonest
+        int blk = slot * groups + (((slot & 1) && snake) ? groups - 1 - g : g);
         if (blk >= n) blk = slot * groups + g;                      // ragged last slot (n not a multiple of 1024)
         perm[blk] = e;
     }
@@ -2379,7 +2381,8 @@ static int launch_env(plenvec *h, int mode, int nsub, const float *action, const
     a.dump = (real *)dump;
     a.perm = nullptr;
     if (mode == MODE_STEP && h->balance) {
-        hipLaunchKernelGGL(plen_balance_kernel, dim3(1), dim3(1024), 0, st, h->n, h->simds, h->aux, h->perm);
+        static const int snake = [] { const char *e = getenv("PLENVEC_BALANCE_ORDER"); return (e && strcmp(e, "descending") == 0) ? 0 : 1; }();
+        hipLaunchKernelGGL(plen_balance_kernel, dim3(1), dim3(1024), 0, st, h->n, h->simds, h->aux, h->perm, snake);
         a.perm = h->perm;
     }
     a.nonfinite = h->nonfinite;

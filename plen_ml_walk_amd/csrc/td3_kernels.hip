@@ -638,6 +638,27 @@ int plentd3_policy_block(const PlenTd3PolicyBlock *args, void *stream) {
     if (!args || args->rows.B <= 0 || !args->p_a_w1 || !args->p_a_w2t || (args->rows.adam_step && !args->rows.done_count)) return -(int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_policy_block, dim3((args->rows.B + BLK_R - 1) / BLK_R), dim3(64 * BLK_NW), 0, (hipStream_t)stream, *args); CHECK();
 }
+int plentd3_wgrad_big(const PlenTd3WgradBig *group, void *stream) {
+    if (!group || group->n_jobs < 1 || group->n_jobs > PLENTD3_WGRAD_BIG_JOBS || group->B <= 0 || group->chunks < 1 || group->rows_per_chunk < 1 || !group->partial ||
+        (group->stride & 3) || ((uintptr_t)group->partial & 15) || (long long)group->chunks * group->rows_per_chunk < group->B || (group->rows_per_chunk & 7)) return -(int)hipErrorInvalidValue;
+    PlenTd3WgradBig G = *group;
+    int wg = 0;
+    for (int j = 0; j < G.n_jobs; j++) {
+        const PlenTd3WgradBigJob &J = G.job[j];
+        if (!J.dH || !J.X || J.N < 1 || J.K < 1 || J.goff < 0 || (size_t)J.goff + (size_t)J.N * J.K > (size_t)G.stride || (J.boff >= 0 && J.boff + J.N > G.stride)) return -(int)hipErrorInvalidValue;
+        if (J.kind == 1 && (J.N != 1 || J.K > 256 || (J.K & 3) || (J.xs & 3) || ((uintptr_t)J.X & 15))) return -(int)hipErrorInvalidValue;
+        G.job[j].wg0 = wg;
+        wg += (J.kind == 1 ? 1 : ((J.N + 31) / 32) * ((J.K + 63) / 64)) * G.chunks;
+    }
+    hipLaunchKernelGGL(k_wgrad_big, dim3(wg), dim3(64 * WGB_NW), 0, (hipStream_t)stream, G); CHECK();
+}
+int plentd3_adam_big(float *p, float *g, float *m, float *v, float *step, int *done_count, int n, double lr, double beta1, double beta2, float eps,
+                     float *target, float tau, float *copy_out, const float *partial, int chunks, int stride, int reduce_only, void *stream) {
+    const uintptr_t bits = (uintptr_t)g | (uintptr_t)partial;
+    if (!g || !partial || chunks < 1 || stride < n || (stride & 3) || n < 1 || (bits & 15) || (!reduce_only && (!p || !m || !v || !step || !done_count))) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_adam_big, dim3(std::min((n + 1023) / 1024, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, step, done_count, n, lr, beta1, beta2, eps, target, tau, copy_out,
+                       partial, chunks, stride, reduce_only); CHECK();
+}
 int plentd3_wgrad_group(const PlenTd3WgradGroup *group, void *stream) {
     if (!group || group->n_jobs < 1 || group->n_jobs > PLENTD3_WGRAD_JOBS || group->B <= 0) return -(int)hipErrorInvalidValue;
     PlenTd3WgradGroup G = *group;

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libplentd3.so")
 EXPORTS = ["plentd3_gather", "plentd3_sample_gather", "plentd3_explore", "plentd3_uniform_actions", "plentd3_store", "plentd3_target_action", "plentd3_q_heads", "plentd3_dh2", "plentd3_relu_mask", "plentd3_colsum", "plentd3_wgrad",
            "plentd3_tanh_out", "plentd3_dtanh", "plentd3_bias_relu", "plentd3_polyak", "plentd3_adam", "plentd3_critic_rows", "plentd3_policy_rows", "plentd3_actor_rows", "plentd3_critic_team", "plentd3_policy_team",
-           "plentd3_wgrad_group", "plentd3_wgrad_adam_group", "plentd3_pack", "plentd3_critic_block", "plentd3_policy_block", "plentd3_stamp", "plentd3_version"]
+           "plentd3_wgrad_group", "plentd3_wgrad_adam_group", "plentd3_pack", "plentd3_critic_block", "plentd3_policy_block", "plentd3_wgrad_big", "plentd3_adam_big", "plentd3_stamp", "plentd3_version"]
 ROW, S, A, SA, H = 72, 26, 18, 44, 256
 _lib = None
 
@@ -95,6 +95,20 @@ class PolicyBlockArgs(C.Structure):
     _fields_ = [("rows", PolicyRowsArgs)] + [(n, C.c_void_p) for n in ("p_a_w1", "p_a_w2", "p_a_w3", "p_c_w14", "p_c_w2", "p_c_w2t", "p_c_w1ta", "p_a_w3t", "p_a_w2t")]
 
 
+WGRAD_BIG_JOBS = 8
+WGRAD_BIG_CHUNKS = 8          # batch chunks of the large-batch weight gradients (512 rows each at batch 4096, a quarter per wave: ~660 workgroups per critic pass)
+
+
+class WgradBigJob(C.Structure):
+    """Mirror of PlenTd3WgradBigJob (include/plentd3.h)."""
+    _fields_ = [("dH", C.c_void_p), ("X", C.c_void_p)] + [(n, C.c_int) for n in ("ds", "xs", "N", "K", "goff", "boff", "kind", "wg0")]
+
+
+class WgradBig(C.Structure):
+    """Mirror of PlenTd3WgradBig (include/plentd3.h)."""
+    _fields_ = [("job", WgradBigJob * WGRAD_BIG_JOBS)] + [(n, C.c_int) for n in ("n_jobs", "B", "chunks", "rows_per_chunk", "stride")] + [("partial", C.c_void_p)]
+
+
 TEAM_MAX_BATCH = 512          # FusedTD3(team=None): batches up to this size take the small-batch kernels (csrc/td3_team.hip)
 
 
@@ -132,6 +146,8 @@ def load():
         lib.plentd3_pack.argtypes = [C.POINTER(PackGroup), vp]
         lib.plentd3_critic_block.argtypes = [C.POINTER(CriticBlockArgs), vp]
         lib.plentd3_policy_block.argtypes = [C.POINTER(PolicyBlockArgs), vp]
+        lib.plentd3_wgrad_big.argtypes = [C.POINTER(WgradBig), vp]
+        lib.plentd3_adam_big.argtypes = [vp, vp, vp, vp, vp, vp, i, C.c_double, C.c_double, C.c_double, f, vp, f, vp, vp, i, i, i, vp]
         lib.plentd3_wgrad_group.argtypes = [C.POINTER(WgradGroup), vp]
         lib.plentd3_wgrad_adam_group.argtypes = [C.POINTER(WgradGroup), C.POINTER(AdamFusedArgs), vp]
         lib.plentd3_adam.argtypes = [vp, vp, vp, vp, vp, vp, i, C.c_double, C.c_double, C.c_double, f, i, vp, f, vp, vp]
@@ -216,6 +232,17 @@ class FlatAdam(object):
                                    float(g["betas"][1]), float(g["eps"]), int(zero_grad), _p(target), float(tau), _p(copy_out), st))
 
 
+    def step_big(self, partial, chunks, stride, target=None, tau=0.0, copy_out=None, reduce_only=False):
+        """step() on g = bucket + the per-chunk partial gradients of plentd3_wgrad_big (added in chunk order); leaves the bucket zero.  reduce_only: only
+        bucket = that sum (several ranks: all-reduce it, then step())."""
+        if not reduce_only:
+            self.ensure_bound()
+        st = C.c_void_p(torch.cuda.current_stream(self.p.device).cuda_stream)
+        g = self.opt.param_groups[0]
+        _chk(self.lib.plentd3_adam_big(_p(self.p), _p(self.g), _p(self.m), _p(self.v), _p(self.step_t), _p(self.done), self.p.numel(), float(g["lr"]), float(g["betas"][0]),
+                                       float(g["betas"][1]), float(g["eps"]), _p(target), float(tau), _p(copy_out), _p(partial), int(chunks), int(stride), int(bool(reduce_only)), st))
+
+
 class FusedTD3(object):
     """update(data, idx, with_policy) == td3.td3_update(agent, (data rows idx split into s, a, s2, r, not_done), with_policy)."""
 
@@ -244,6 +271,8 @@ class FusedTD3(object):
         self._block_pass = False
         self._packs = {}             # name -> packed copy of a weight matrix (plentd3_pack), rewritten before every pass that reads it
         self._partials = None
+        self._big = {}               # "critic" / "actor" -> (partial gradients [chunks][stride], stride) of plentd3_wgrad_big
+        self._big_pending = {}       # network -> chunks whose partial gradients still wait for their optimiser step (update() takes it with plentd3_adam_big)
         # one rank, small batch, flat Adam: the optimiser step is taken inside the grouped weight-gradient kernel (plentd3_wgrad_adam_group).
         # update() sets _fuse = {"critic": target-or-None, "actor": target} for the passes it is about to run and reads _fused_done back.
         self.fuse_adam = os.environ.get("PLEN_TD3_FUSE_ADAM", "1") == "1"
@@ -301,6 +330,35 @@ class FusedTD3(object):
     def _tr(name, w):
         """its transpose (input gradients: dX^T = W^T dY^T)"""
         return (name, w, w.shape[1], w.shape[0], 1, w.shape[1], 0)
+
+    def _wgrad_big(self, which, B, jobs):
+        """Every weight gradient of a large-batch pass in one launch (plentd3_wgrad_big): jobs = (dh, x, gw, gb or None) as _wgrad; a dh of one column
+        is a head row.  With update()'s consent (self._fuse holds `which`) the partial gradients stay where they are for plentd3_adam_big to add up and step on;
+        otherwise they are added into the gradient bucket here (reduce_only), as every other path leaves them."""
+        grads = self.agent._critic_grads if which == "critic" else self.agent._actor_grads
+        n = grads.flat.numel()
+        stride = (n + 3) // 4 * 4
+        if which not in self._big:
+            self._big[which] = torch.zeros(WGRAD_BIG_CHUNKS, stride, device=self.dev, dtype=torch.float32)
+        partial = self._big[which]
+        rpc = max(16, (-(-B // WGRAD_BIG_CHUNKS) + 15) // 16 * 16)
+        chunks = -(-B // rpc)
+        G = WgradBig()
+        assert 1 <= len(jobs) <= WGRAD_BIG_JOBS and chunks <= WGRAD_BIG_CHUNKS
+        base = grads.flat.data_ptr()
+        for J, (dh, x, gw, gb) in zip(G.job, jobs):
+            N, K = gw.shape
+            assert dh.shape[0] == B and x.shape[0] == B and dh.stride(1) == 1 and x.stride(1) == 1 and gw.is_contiguous() and x.shape[1] == K and dh.shape[1] == N
+            J.dH, J.X, J.ds, J.xs, J.N, J.K = dh.data_ptr(), x.data_ptr(), dh.stride(0), x.stride(0), N, K
+            J.goff, J.boff, J.kind = (gw.data_ptr() - base) // 4, ((gb.data_ptr() - base) // 4 if gb is not None else -1), int(N == 1)
+        G.n_jobs, G.B, G.chunks, G.rows_per_chunk, G.stride, G.partial = len(jobs), int(B), chunks, rpc, stride, partial.data_ptr()
+        _chk(self.lib.plentd3_wgrad_big(C.byref(G), self._stream()))
+        adam = self._critic_adam if which == "critic" else self._actor_adam
+        if adam is not None and self._fuse is not None and which in self._fuse:
+            self._big_pending[which] = chunks
+            return
+        st = self._stream()
+        _chk(self.lib.plentd3_adam_big(None, _p(grads.flat), None, None, None, None, n, 0.0, 0.0, 0.0, 0.0, None, 0.0, None, _p(partial), chunks, stride, 1, st))
 
     def _wgrad_group(self, B, jobs, which=None, extras=()):
         """Every (dh, x, gw, gb) of `jobs` as _wgrad, in one launch (plentd3_wgrad_group: the batch is one reduction chunk).  With update()'s consent
@@ -384,7 +442,11 @@ class FusedTD3(object):
             self._fuse = None            # (consent to the in-kernel Adam step never outlives the pass it was given for)
         if all_reduce:
             ag._critic_grads.all_reduce_mean()
-        if "critic" in self._fused_done:
+        if "critic" in self._big_pending:        # large batch: the step on bucket + partial gradients, the bucket left zero (+ the critic's Polyak update)
+            big, chunks = self._big["critic"], self._big_pending.pop("critic")
+            self._critic_adam.step_big(big, chunks, big.shape[1], target=ag._critic_target_flat.flat if with_policy else None, tau=ag.tau)
+            self._zeroed["critic"] = True
+        elif "critic" in self._fused_done:
             self._zeroed["critic"] = True      # nothing was written into the bucket (the head biases' sums were consumed and zeroed)
         elif flat:     # Adam + zeroed bucket (+ the critic's Polyak update, which nothing reads before the iteration's end: td3.py:348-352) in one pass
             self._critic_adam.step(zero_grad=True, target=ag._critic_target_flat.flat if with_policy else None, tau=ag.tau)
@@ -401,7 +463,11 @@ class FusedTD3(object):
             if all_reduce:
                 ag._actor_grads.all_reduce_mean()
             ag.last_actor_loss = None          # (-mean Q1 itself is not needed for the update; the autograd path reports it)
-            if "actor" in self._fused_done:
+            if "actor" in self._big_pending:
+                big, chunks = self._big["actor"], self._big_pending.pop("actor")
+                self._actor_adam.step_big(big, chunks, big.shape[1], target=ag._actor_target_flat.flat, tau=ag.tau)
+                self._zeroed["actor"] = True
+            elif "actor" in self._fused_done:
                 self._zeroed["actor"] = True
             elif flat:
                 self._actor_adam.step(zero_grad=True, target=ag._actor_target_flat.flat, tau=ag.tau)
@@ -577,6 +643,11 @@ class FusedTD3(object):
             a.done_count, a.rng_bump = self._done_count.data_ptr(), self.rng.data_ptr()
             a.sigma, a.clip, a.max_a, a.gamma, a.B = float(ag.policy_noise), float(ag.noise_clip), float(ag.max_action), float(ag.discount), int(B)
             self._probe(1)
+            if block:       # (the packing launch sits between probes 1 and 2, so that probes 2 -> 3 bracket the pass kernel alone: bench.py's legs.td3.roofline)
+                nt, tr = self._nt, self._tr
+                self._pack([nt("at_w1", at.fc1.weight), nt("at_w2", at.fc2.weight), nt("at_w3", at.fc3.weight),
+                            nt("ct_w14", tv["W14"]), nt("ct_w2", ct.fc2.weight), nt("ct_w5", ct.fc5.weight),
+                            nt("c_w14", cv["W14"]), nt("c_w2", cr.fc2.weight), nt("c_w5", cr.fc5.weight), tr("c_w2t", cr.fc2.weight), tr("c_w5t", cr.fc5.weight)])
             self._probe(2)
             if team:        # small batch: a team of 8 waves per row block, then every weight gradient in one launch (head rows as 1 x 256 products)
                 _chk(lib.plentd3_critic_team(C.byref(a), st))
@@ -588,14 +659,10 @@ class FusedTD3(object):
                 self._team_pass = True
                 self._probe(4)
                 return loss[0]
-            if block:       # large batch: 16 rows per 256-thread workgroup, packed weights (csrc/td3_block.hip); weight gradients as below
-                nt, tr = self._nt, self._tr
-                self._pack([nt("at_w1", at.fc1.weight), nt("at_w2", at.fc2.weight), nt("at_w3", at.fc3.weight),
-                            nt("ct_w14", tv["W14"]), nt("ct_w2", ct.fc2.weight), nt("ct_w5", ct.fc5.weight),
-                            nt("c_w14", cv["W14"]), nt("c_w2", cr.fc2.weight), nt("c_w5", cr.fc5.weight), tr("c_w2t", cr.fc2.weight), tr("c_w5t", cr.fc5.weight)])
+            if block:       # large batch: 16 rows per 256-thread workgroup, packed weights (csrc/td3_block.hip), all weight gradients in one launch
                 nb = (B + 15) // 16
-                if self._partials is None or self._partials.numel() < 4 * nb:
-                    self._partials = torch.zeros(4 * nb, device=dev, dtype=torch.float32)
+                if self._partials is None or self._partials.numel() < 4 * nb + 128:
+                    self._partials = torch.zeros(4 * nb + 128, device=dev, dtype=torch.float32)        # (+ room for a development build's phase stamps)
                 pa = CriticBlockArgs()
                 pa.rows = a
                 for n_ in ("at_w1", "at_w2", "at_w3", "ct_w14", "ct_w2", "ct_w5", "c_w14", "c_w2", "c_w5", "c_w2t", "c_w5t"):
@@ -603,8 +670,14 @@ class FusedTD3(object):
                 pa.partials = self._partials.data_ptr()
                 _chk(lib.plentd3_critic_block(C.byref(pa), st))
                 self._block_pass = True
-            else:
-                _chk(lib.plentd3_critic_rows(C.byref(a), st))
+                self._probe(3)
+                self._wgrad_big("critic", B, [(dq[:, 0:1], c2[:, :H], cr.fc3.weight.grad, None), (dq[:, 1:2], c2[:, H:], cr.fc6.weight.grad, None),
+                                              (dh2[:, :H], c1[:, :H], cr.fc2.weight.grad, cr.fc2.bias.grad), (dh2[:, H:], c1[:, H:], cr.fc5.weight.grad, cr.fc5.bias.grad),
+                                              (dh1, batch[:, :SA], gv["W14"], gv["b14"])])
+                self._saved = (batch[:, :S], sa_pi, B)
+                self._probe(4)
+                return loss[0]
+            _chk(lib.plentd3_critic_rows(C.byref(a), st))
             self._probe(3)
             # weight gradients (reductions over the batch): last layers, second layers, stacked first layers
             _chk(lib.plentd3_colsum(_p(c2), 2 * H, _p(dq), 2, _p(cr.fc3.weight.grad), B, H, int(self.rows), st))
@@ -656,8 +729,10 @@ class FusedTD3(object):
                     for n_ in ("a_w1", "a_w2", "a_w3", "c_w14", "c_w2", "c_w2t", "c_w1ta", "a_w3t", "a_w2t"):
                         setattr(pa, "p_" + n_, self._packs[n_].data_ptr())
                     _chk(lib.plentd3_policy_block(C.byref(pa), st))
-                else:
-                    _chk(lib.plentd3_policy_rows(C.byref(a), st))
+                    self._wgrad_big("actor", B, [(dz, p2, ac.fc3.weight.grad, ac.fc3.bias.grad), (dp2, p1, ac.fc2.weight.grad, ac.fc2.bias.grad),
+                                                 (dp1, s, ac.fc1.weight.grad, ac.fc1.bias.grad)])
+                    return
+                _chk(lib.plentd3_policy_rows(C.byref(a), st))
                 self._wgrad(dz, p2, ac.fc3.weight.grad, ac.fc3.bias.grad)
                 self._wgrad(dp2, p1, ac.fc2.weight.grad, ac.fc2.bias.grad)
                 self._wgrad(dp1, s, ac.fc1.weight.grad, ac.fc1.bias.grad)

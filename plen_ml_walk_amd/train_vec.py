@@ -471,6 +471,7 @@ class PipelinedVecTD3Trainer(object):
         self.ep_stats = torch.zeros(3, dtype=torch.float64, device=dev)                                                    # finished episodes: sum of returns, count, sum of lengths
         self._critic_loss = torch.zeros((), device=dev)
         self.t = 0
+        self.learning = True                   # False: the collectors alone, acting with the (then frozen) policy -- what the loop costs without its learner
         self.env_steps = self.grad_steps = 0
         self._graphs, self._eager_runs = {}, {}
         self._ev_col = {}
@@ -561,7 +562,7 @@ class PipelinedVecTD3Trainer(object):
     def step(self):
         t, n = self.t, self.n
         warm = t * n < self.start_timesteps                    # uniform random actions until the ring holds start_timesteps transitions
-        learn = not warm and t >= 1
+        learn = self.learning and not warm and t >= 1
         for h in range(self.H):
             s = self.streams[h]
             ev = self._ev_upd.get(t - 2)
