@@ -228,7 +228,9 @@ def env_leg(a, dtype_name, dev, rank, world, dist, steps, warmup, dr=None):
     """Random-action rollout of a.envs_per_gpu envs on this rank; returns the timing dict (max over ranks).  dr: per-env domain randomisation
     (BASELINE.json configs[4]); None = as --dr says."""
     dr = a.dr if dr is None else dr
-    groups = a.groups if a.groups > 0 else (2 if dtype_name == "f32" else 4)
+    # sub-batches: the measured best at 4096 envs per rank (2 x 2048 for f32, 4 x 1024 for f64), but never launches of fewer than 512 envs -- strong scaling over
+    # 8 ranks leaves 512 envs per rank, which run as one launch, not as 4 x 128 (VERDICT r04 weak point 9)
+    groups = a.groups if a.groups > 0 else max(1, min(2 if dtype_name == "f32" else 4, a.envs_per_gpu // 512))
     import torch
     from plen_ml_walk_amd import sharding
     from plen_ml_walk_amd.vec_env import PlenVecEnvPipelined
@@ -569,6 +571,13 @@ def _td3_run(a, dev, rank, world, dist, steps, warmup, batch):
            "collective": ("RCCL all-reduce of the flat critic (155138 f32) and actor (77330 f32) gradient buckets per update, mode %s" % getattr(tr, "allreduce_mode", None)) if world > 1 else None,
            "critic_loss": float(agent.last_critic_loss) if agent.last_critic_loss is not None else None,
            "workload": "BASELINE.json configs[%d]: %d envs per GPU + TD3 (actor 26-256-256-18, twin critic 44-256-256-1, Adam 3e-4, policy_freq 2), exploration N(0, 0.1)" % (2 if world == 1 else 3, n)}
+    if world > 1:
+        # data-parallel invariant: after the same all-reduced updates every rank holds the same parameters, bit for bit (checked on the raw bit patterns)
+        chk = torch.stack([agent._critic_flat.flat.view(torch.int32).to(torch.int64).sum(), agent._actor_flat.flat.view(torch.int32).to(torch.int64).sum()])
+        allc = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(allc, chk)
+        out["parameters_equal_across_ranks"] = bool(all(torch.equal(c, allc[0]) for c in allc))
+        out["collective_backend"] = dist.get_backend()
     if pipelined:
         out["episodes_finished_since_start"] = tr.episode_stats()          # device-side bookkeeping of the ring-store kernel (returns of an untrained policy)
         if batch > 512 and rank == 0:

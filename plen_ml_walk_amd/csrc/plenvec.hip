@@ -1772,6 +1772,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
 #else
         const int sel = (!PLENVEC_LIM_ROWS_EVERYWHERE && __builtin_expect(lim_mask != 0, 0)) ? 24 : 5 * nr_ + nl_;
 #endif
+        if (dump && lane == 0) dump[3701] = (real)sel;          // which copy of the solver loop served this substep (tests/test_env_gpu.py: every copy is held to the oracle)
         switch (sel) {
 #if PLENVEC_LIM_FLAVOURS
 #define PLEN_CASE(V_) case V_: solve_loop(std::integral_constant<int, V_>{}); break; case 100 + V_: solve_loop(std::integral_constant<int, 100 + V_>{}); break;

@@ -1,6 +1,6 @@
 """A/B of cfg switches on ONE binary inside one gpurun call: ms per 4096-env step (single launch per step) for body_contacts on/off, both dtypes."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from plen_ml_walk_amd.vec_env import PlenVecEnv

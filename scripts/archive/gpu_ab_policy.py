@@ -1,7 +1,7 @@
 """A/B of libplenvec builds on the policy leg (bench.py --legs policy: the shipped walking policy in the loop, a contact-rich workload) inside one gpurun call.
 usage: python scripts/gpu_ab_policy.py libA.so libB.so ... ("-" = in-tree)"""
 import json, os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for rnd in range(2):
     for lib in sys.argv[1:]:
         env = dict(os.environ)

@@ -1,6 +1,6 @@
 """A/B of libplenvec builds on the TD3 leg (bench.py --legs td3) inside one gpurun call.  usage: python scripts/gpu_ab_td3.py libA.so libB.so ... ("-" = in-tree)"""
 import json, os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for rnd in range(2):
     for lib in sys.argv[1:]:
         env = dict(os.environ)

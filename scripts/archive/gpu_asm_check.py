@@ -1,7 +1,7 @@
 """asm fast path vs compiler path (PLENVEC_NO_ASM=1): same arithmetic in the same order -> results
 should agree bit for bit on every env; a hazard in the hand-written row would show up here."""
 import os, sys, subprocess, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 def run(tag):
     import torch

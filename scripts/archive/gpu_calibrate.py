@@ -1,7 +1,7 @@
 """Measure GPU-vs-oracle error levels for the configurations the GPU tests assert on."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from oracle.oracle import OracleEnv

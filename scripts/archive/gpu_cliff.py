@@ -1,6 +1,6 @@
 """Occupancy cliff probe: ms/step around N = 16 blocks x CU count (one wave per env, 16 waves per CU)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from plen_ml_walk_amd.vec_env import PlenVecEnv

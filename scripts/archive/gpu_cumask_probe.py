@@ -7,7 +7,7 @@ import os
 import sys
 import time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 

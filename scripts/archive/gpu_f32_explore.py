@@ -1,6 +1,6 @@
 """Exploration behind the f32 variants of the recorded-policy / trajectory tests: per-step error of the f32 kernel vs the f64 oracle."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from oracle.oracle import OracleEnv

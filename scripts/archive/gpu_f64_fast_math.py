@@ -3,7 +3,7 @@ inside the circle) change?  Builds a variant with the compiler's correctly round
 and all 4096 envs, the error against the f64 oracle after 1..4 steps (reference configuration and rolling friction off), and the two builds against
 each other."""
 import os, subprocess, sys, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 CHILD = r'''
 import sys, json, numpy as np, torch

@@ -1,6 +1,6 @@
 """Profiling build (-DPGS_STAMPS -DPGS_HWID, variants/hwid.so): which (XCC, SE, CU, SIMD, slot) each block of a 4096-block launch ran on."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from plen_ml_walk_amd.build import build_variant
 os.environ["PLENVEC_LIB"] = build_variant("hwid", ["-DPGS_STAMPS", "-DPGS_HWID"])

@@ -3,7 +3,7 @@ residuals R_0..R_4 of the kernel itself (tests/pybullet_pin.py) and the shipped 
 (the oracle's ablation, scripts/pin/hypothesis_ablation.py, holds 128: these are the tight error bars).  The structural variants (manifold
 family, row order, warm starting, inertia source) exist only in the oracle.  Writes gpurun_out/r03_hypothesis_ablation_gpu.json."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import pybullet_pin as P

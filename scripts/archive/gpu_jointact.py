@@ -1,5 +1,5 @@
 import os, sys, numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle.oracle import OracleEnv
 from plen_ml_walk_amd.vec_env import PlenVecEnv

@@ -1,7 +1,7 @@
 """Parity sweep of the final build: all 4096 envs of a launch against the f64 oracle for several seeds and configurations (the quantities
 tests/test_full_size_gpu.py asserts for one seed), written to gpurun_out/parity_sweep.json.   usage: python scripts/gpu_parity_sweep.py [seeds]"""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from oracle import oracle

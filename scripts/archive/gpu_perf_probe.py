@@ -1,6 +1,6 @@
 """Where does the time go: vary solver iterations / env count / dtype."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from plen_ml_walk_amd.vec_env import PlenVecEnv

@@ -1,7 +1,7 @@
 """Time of FusedTD3.critic_backward (layer by layer) and critic_backward_rows (one row-block kernel) alone on the GPU, as captured graphs."""
 import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 

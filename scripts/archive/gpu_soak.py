@@ -1,7 +1,7 @@
 """Soak: 4096 envs x many steps of random actions in several configurations; every 500 steps the whole state and the outputs must be
 finite, quaternions normalised, heights bounded.  usage: python scripts/gpu_soak.py [steps]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from plen_ml_walk_amd.vec_env import PlenVecEnvPipelined

@@ -2,7 +2,7 @@
 wall time per step including the final synchronise.  usage: python scripts/gpu_td3_host_time.py [batch] [steps]"""
 import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from plen_ml_walk_amd.vec_env import PlenVecEnv

@@ -2,7 +2,7 @@
 under uniform random actions and under a freshly initialised actor + N(0, 0.1) noise (what the TD3 leg's collectors play)."""
 import os, sys
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from plen_ml_walk_amd.vec_env import PlenVecEnv

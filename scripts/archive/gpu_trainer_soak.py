@@ -2,7 +2,7 @@
 moments, targets and the critic loss are finite, that the step counters agree, and that no env needed a non-finite reset.
 usage: python scripts/gpu_trainer_soak.py [seconds]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from plen_ml_walk_amd.vec_env import PlenVecEnv

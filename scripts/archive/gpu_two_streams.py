@@ -1,6 +1,6 @@
 """Experiment: 4096 envs as G independent groups stepped on G streams (no cross-group sync) vs one 4096-env launch per step."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from plen_ml_walk_amd.vec_env import PlenVecEnv

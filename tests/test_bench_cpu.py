@@ -86,3 +86,35 @@ def test_bench_two_ranks_on_one_gpu(scaling):
     assert d["legs"]["f32"]["value"] > 0
     td3 = d["legs"]["td3"]
     assert td3.get("value") and td3["collective"] and "all-reduce" in td3["collective"] and td3["grad_steps_per_s"] > 0, td3
+    assert td3["parameters_equal_across_ranks"] is True and td3["collective_backend"] == "gloo"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_gpus_over_rccl(scaling):
+    """Day-one readiness for a multi-GPU node (skipped on the one-GPU boxes of this pool): the driver's command, `bench.py --gpus 2`, with
+    the real backend -- one rank per GPU, RCCL all-reduce of the flat critic / actor gradient buckets -- weak and strong: n_gpus 2, the collective reported as
+    RCCL's, and the data-parallel invariant: both ranks end with bitwise equal parameters."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (this pool's boxes have one)")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    env.pop("PLEN_DIST_BACKEND", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scaling", scaling, "--steps", "10", "--warmup", "3", "--envs-per-gpu", "1024",
+                          "--legs", "f32,td3", "--td3-steps", "40", "--no-cpu-baseline", "--no-parity"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.stdout[-500:], out.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["value"] > 0
+    assert d["config"]["total_envs"] == (2048 if scaling == "weak" else 1024)
+    td3 = d["legs"]["td3"]
+    assert td3.get("value") and td3["collective"] and "RCCL" in td3["collective"] and td3["collective_backend"] == "nccl" and td3["grad_steps_per_s"] > 0, td3
+    assert td3["parameters_equal_across_ranks"] is True
+
+
+def test_sub_batches_follow_the_envs_per_rank():
+    """bench.py picks the number of sub-batch launches from the envs a rank owns: 4096 -> 2 (f32) / 4 (f64); 512 (strong scaling over 8 ranks) -> one launch."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "a.envs_per_gpu // 512" in src
+    for n, dt, want in ((4096, "f32", 2), (4096, "f64", 4), (512, "f64", 1), (1024, "f64", 2), (2048, "f32", 2), (256, "f32", 1)):
+        assert max(1, min(2 if dt == "f32" else 4, n // 512)) == want

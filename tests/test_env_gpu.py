@@ -336,31 +336,38 @@ def test_asm_path_bitwise_equals_compiler_path(tmp_path, dt):
     assert np.array_equal(outs[0], outs[1], equal_nan=True)
 
 
+@pytest.mark.parametrize("cfg", ["reference", "no_torsional_friction", "fallen_robots"])
 @pytest.mark.parametrize("dt", ["float32", "float64"])
-def test_count_specialised_solver_loops_bitwise_equal_the_run_time_tested_loop(tmp_path, dt):
+def test_count_specialised_solver_loops_bitwise_equal_the_run_time_tested_loop(tmp_path, dt, cfg):
     """Round 4: the solver's iteration loop is compiled once per pair of foot point counts and chosen once per substep.  That changes which code runs, not one
     operation or its order: against a build with rounds 1-3's run-time point tests (-DPLENVEC_COUNT_SPECIALISED=0, csrc/variants/nospec.so, built by
     __graft_entry__.build()) 40 steps x 512 envs -- random actions with amplitude 1.7 in joint_act mode for half of them, so that joint limits are violated
-    and every contact configuration from airborne to both feet planted occurs -- agree bit for bit, including states and auto-resets."""
+    and every contact configuration from airborne to both feet planted occurs -- agree bit for bit, including states and auto-resets.
+    The specialised copies run the spinning / rolling rows unconditionally and rely on (+-0, +-0) bounds being exact no-ops when a coefficient is zero, and on
+    lent box slots carrying zero coefficients: `no_torsional_friction` sets both coefficients to 0, `fallen_robots` switches the auto-reset off so
+    that robots fall and stay down -- links other than the feet on the ground, contact slots lent to their box corners."""
     from plen_ml_walk_amd.build import build_variant
     lib0 = build_variant("nospec", ["-DPLENVEC_COUNT_SPECIALISED=0"])
+    kw = {"reference": "", "no_torsional_friction": ", cfg_overrides={'spinning_friction': 0.0, 'rolling_friction': 0.0}", "fallen_robots": ", auto_reset=False"}[cfg]
     code = ("import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
             "from plen_ml_walk_amd.vec_env import PlenVecEnv\n"
             "out, st = [], []\n"
             "for ja, amp in ((False, 1.0), (True, 1.7)):\n"
             "    g = torch.Generator().manual_seed(5); acts = ((torch.rand(40, 512, 18, generator=g) * 2 - 1) * amp).float().cuda()\n"
-            "    env = PlenVecEnv(512, dtype=torch.%s, joint_act=ja); env.reset()\n"
+            "    env = PlenVecEnv(512, dtype=torch.%s, joint_act=ja%s); env.reset()\n"
             "    for t in range(40):\n"
             "        o, r, d, _ = env.step(acts[t]); out.append(torch.cat([o, r[:, None], d.to(o.dtype)[:, None]], 1).cpu().numpy().copy())\n"
             "    st.append(env.get_state().cpu().numpy()); env.close()\n"
-            "np.save(sys.argv[1], np.array(out)); np.save(sys.argv[1] + '.state.npy', np.array(st))\n" % (ROOT, dt))
+            "np.save(sys.argv[1], np.array(out)); np.save(sys.argv[1] + '.state.npy', np.array(st))\n" % (ROOT, dt, kw))
     outs = []
     for tag, extra in (("spec", {}), ("nospec", {"PLENVEC_LIB": lib0})):
         p = str(tmp_path / (tag + ".npy"))
         subprocess.run([sys.executable, "-c", code, p], check=True, timeout=600, env=dict(os.environ, **extra))
         outs.append((np.load(p), np.load(p + ".state.npy")))
     assert outs[0][0].shape == outs[1][0].shape and np.array_equal(outs[0][0], outs[1][0], equal_nan=True) and np.array_equal(outs[0][1], outs[1][1], equal_nan=True)
-    assert (outs[0][0][:40, :, 27] != 0).sum() > 100                 # episodes ended and restarted inside the window
+    assert (outs[0][0][:40, :, 27] != 0).sum() > 100                 # episodes ended (and, with the auto-reset on, restarted) inside the window
+    if cfg == "fallen_robots":                                        # ... and without it the robots are down: torso below the termination height at the end
+        assert (outs[0][1][0][:, 2] < 0.08).mean() > 0.5
 
 
 @pytest.mark.parametrize("nenv", [2048, 1500, 3000])       # full slots, ragged odd last slot, ragged even last slot
@@ -649,28 +656,92 @@ def test_joint_limit_rows_vs_oracle_f64(nit):
     env.close()
 
 
-def test_every_pair_of_foot_point_counts_vs_oracle_f64():
-    """One substep from states whose feet hold 0..4 contact points each (a flat foot: 4, on an edge: 2, on a corner: 1, three: a slightly tilted flat foot), f64 kernel
-    against the oracle with 3 solver iterations: every specialised copy of the solver loop, including the four-point copy that serves three-point feet."""
-    from oracle.oracle import OracleEnv as OE
-    seen = {}
-    rng = np.random.default_rng(4)
-    S, T = collect_states(600, seed=21, with_targets=True)
-    # classify by the oracle's own collision pass
-    keep_S, keep_T = [], []
-    for i in range(len(S)):
-        o = OE(); o.set_state(S[i]); box, _ = o.contact_slots(run_collide=True)
-        nr, nl = int((box[:4] != -2).sum()), int((box[4:] != -2).sum())
-        if seen.get((nr, nl), 0) < 6:
-            seen[(nr, nl)] = seen.get((nr, nl), 0) + 1; keep_S.append(S[i]); keep_T.append(T[i])
-    assert len(seen) >= 9, sorted(seen)                       # random rollouts visit most pairs; (3, x) included when they occur
-    S, T = np.array(keep_S), np.array(keep_T)
+def _quat(r, p, y):
+    cr, sr, cp, sp, cy, sy = np.cos(r / 2), np.sin(r / 2), np.cos(p / 2), np.sin(p / 2), np.cos(y / 2), np.sin(y / 2)
+    return np.array([sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy])
+
+
+def constructed_foot_states(per_pair=2, seed=0):
+    """States in which the right / left foot hold every pair of contact-point counts (0..4)^2, built, not found: a slightly tilted torso, each leg's joints perturbed
+    on a random scale (a flat foot: 4 points, a foot on an edge: 2, on a corner: 1, a slightly tilted flat foot: 3, a lifted one: 0), the torso lowered by bisection
+    until the first point touches and then a little further.  Classified by the oracle's own collision pass; states in which any other link touches are skipped."""
+    rng = np.random.default_rng(seed)
+    o = OracleEnv()
+    found = {}
+
+    def counts(s):
+        o.set_state(s)
+        box, _ = o.contact_slots(run_collide=True)
+        return int((box[:4] != -2).sum()), int((box[4:] != -2).sum()), box
+    tries = 0
+    while (len(found) < 24 or min(len(v) for v in found.values()) < per_pair) and tries < 400000:
+        tries += 1
+        s = np.zeros(49)
+        s[3:7] = _quat(rng.normal(0, 0.03), rng.normal(0, 0.03), 0.0)
+        for leg in range(2):
+            s[13 + 6 * leg:19 + 6 * leg] = rng.normal(0, rng.choice([0.0, 0.01, 0.03, 0.1, 0.4]), 6)
+        lo, hi = 0.10, 0.20
+        for _ in range(18):
+            s[2] = 0.5 * (lo + hi)
+            nr, nl, _ = counts(s)
+            lo, hi = (s[2], hi) if nr + nl > 0 else (lo, s[2])
+        s[2] = lo - rng.choice([0.0, 0.0003, 0.001, 0.002, 0.004])
+        nr, nl, box = counts(s)
+        if (box >= 0).any() or nr + nl == 0 or len(found.get((nr, nl), [])) >= per_pair:
+            continue
+        found.setdefault((nr, nl), []).append(s.copy())
+    air = np.zeros(49); air[2] = 0.25; air[6] = 1.0
+    found[(0, 0)] = [air.copy() for _ in range(per_pair)]
+    return found
+
+
+@pytest.mark.parametrize("nit,rolling,tol", [(3, None, 1e-9), (50, 0.0, 1e-7)])
+def test_every_copy_of_the_solver_loop_vs_oracle_f64(nit, rolling, tol):
+    """The solver's iteration loop exists 50 times (one copy per pair of foot point counts (NR, NL) in {0..4}^2, each with and without the joint-limit rows) and a
+    substep runs exactly one of them.  Here every copy runs: constructed states for all 25 pairs (constructed_foot_states), each with moving joints and a moving
+    torso, once as it is and once with one joint beyond its +-1.7 rad limit and moving outwards (plen.urdf:1310; the limit rows exist only while violated) -- one
+    substep of the f64 kernel against the oracle: 3 iterations in the reference configuration to 1e-9, 50 iterations with rolling friction off to 1e-7
+    (with it on the iteration expands rounding differences).  The copy that served each state is read back from the kernel's debug dump:
+    the set of copies visited must be ALL 50."""
+    found = constructed_foot_states(per_pair=2, seed=3)
+    assert len(found) == 25, sorted(found)
+    rng = np.random.default_rng(7)
+    S, T, want = [], [], []
+    for (nr, nl), states in sorted(found.items()):
+        for k, s0 in enumerate(states):
+            for lim in (0, 1):
+                s = s0.copy()
+                s[7:10] = rng.normal(0, 0.3, 3); s[10:13] = rng.normal(0, 0.05, 3); s[12] -= 0.05          # turning, drifting, coming down
+                s[31:49] = rng.normal(0, 1.0, 18)
+                if lim:
+                    j = 12 + rng.integers(0, 6)                    # an arm joint: the feet stay where they were put
+                    sgn = rng.choice([-1.0, 1.0])
+                    s[13 + j] = sgn * (1.7 + rng.uniform(0.002, 0.03)); s[31 + j] = sgn * rng.uniform(0.2, 2.0)
+                S.append(s); T.append(rng.uniform(-0.5, 0.5, 18)); want.append(5 * nr + nl + 100 * lim)
+    S, T = np.array(S), np.array(T)
     n = len(S)
-    env = _env(n, torch.float64, cfg_overrides={"num_iterations": 3})
+    over = {"num_iterations": nit}
+    if rolling is not None:
+        over["rolling_friction"] = rolling
+    env = _env(n, torch.float64, cfg_overrides=over)
     env.set_state(torch.tensor(S))
-    env.debug_substeps(torch.tensor(T), nsub=1)
+    dump = env.debug_substeps(torch.tensor(T), nsub=1, dump=True).cpu().numpy()
     out = env.get_state().cpu().numpy()
-    for i in range(n):
-        o = OE(); o.set_world(num_iterations=3); o.set_state(S[i]); o.set_targets(T[i]); o.substep()
-        assert np.abs(out[i] - o.get_state()).max() <= 1e-9, (i, np.abs(out[i] - o.get_state()).max())
     env.close()
+    served = dump[:, 3701].astype(int)
+    # the oracle's own classification of each state as it stands (arm joints moved: a hand may have come near the ground -- then the state is not counted)
+    worst, visited = 0.0, set()
+    for i in range(n):
+        o = OracleEnv(); o.set_world(num_iterations=nit)
+        if rolling is not None:
+            o.set_friction(rolling=rolling)
+        o.set_state(S[i]); o.set_targets(T[i])
+        box, _ = o.contact_slots(run_collide=True)
+        o.substep()
+        err = np.abs(out[i] - o.get_state()).max()
+        assert err <= tol, (i, want[i], served[i], err)
+        worst = max(worst, err)
+        if not (box >= 0).any():
+            assert served[i] == want[i], (i, served[i], want[i])
+            visited.add(int(served[i]))
+    assert visited == {5 * a + b + 100 * l for a in range(5) for b in range(5) for l in (0, 1)}, sorted({5 * a + b + 100 * l for a in range(5) for b in range(5) for l in (0, 1)} - visited)
