@@ -12,8 +12,11 @@
  * be compared with PyBullet output component by component.  What pins it (round 3, tests/pybullet_pin.py, tests/test_pybullet_pin.py): the
  * reference's recorded command log trajectories/<joint>_cmd.npy is the shipped actor's deterministic output along a PyBullet episode,
  * a_t = actor_3229999(obs_t^PyBullet), i.e. 500 x 18 equations on PyBullet's own observations: this oracle's reset observation satisfies
- * them to observation errors of ~1e-4 and its observation after one full-range control step to a few 1e-3, and every Bullet default
- * assumed below is a sharp optimum of those residuals (profiles/r03_hypothesis_ablation.json).  The physics
+ * them to observation errors of ~1e-4 and its observation after one full-range control step to a few 1e-3.  Of the Bullet defaults assumed
+ * below, the iteration count, the row order and erp2 are sharp optima of the reset residual R_0; the motor gains, joint damping, maximum
+ * force and velocity clamp are NOT (nominal R_0 / R_1 prefer 5-10 % more damping, the robust score and the stance pin do not), and no variant
+ * of any of them wins on the chaos-robust objectives (round 4: profiles/r04_ablation.json, r04_ablation_pooled.json; round 5, the compound
+ * margin in the link inertias: profiles/r05_margin_pooled.json) -- the documented values stay.  The physics
  * restates Bullet's published multibody algorithm (era ~2.89, early 2020) as documented in DESIGN.md section "Oracle":
  *   btMultiBody::computeAccelerationsArticulatedBodyAlgorithmMultiDof  (Featherstone ABA, explicit
  *       gyroscopic term, semi-implicit Euler: v += dt*a before the constraint solve),

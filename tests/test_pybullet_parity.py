@@ -58,3 +58,120 @@ def test_observations_against_pybullet(tmp_path):
     print(res)
     assert res["reset_err"] <= 1e-3
     assert res["first_step_contact_flags_equal"] >= 0.9
+
+
+class _StubBullet(object):
+    """A stand-in for the `pybullet` MODULE with exactly the public calls tests/pybullet_harness.py makes, its physics supplied by this repository's oracle:
+    the harness cannot be run against the real engine on this project's machines, and a one-command check that is never executed rots.
+    Driving it through the stub executes every line of the harness -- robot emission, world set-up, the reference's call order in reset / step / observe --
+    and, because the engine behind the stub IS the oracle, the comparison it reports must come out at exactly zero."""
+    DIRECT, POSITION_CONTROL, JOINT_REVOLUTE, JOINT_FIXED = 2, 2, 0, 4
+    __version__ = "stub (oracle engine)"
+
+    def __init__(self):
+        from oracle.oracle import OracleEnv
+        self.o = OracleEnv()
+        self.state = np.zeros(49)
+        self.calls = []
+
+    def __getattr__(self, name):              # any call the harness starts to make that the stub does not know fails loudly
+        raise AttributeError("pybullet stub has no %r: extend tests/test_pybullet_parity.py::_StubBullet" % name)
+
+    def connect(self, mode):
+        self.calls.append("connect"); return 0
+
+    def disconnect(self, cid):
+        self.calls.append("disconnect")
+
+    def setRealTimeSimulation(self, v): pass
+    def resetSimulation(self): pass
+    def setAdditionalSearchPath(self, path): pass
+    def getAPIVersion(self): return 0
+
+    def setGravity(self, x, y, z):
+        assert (x, y, z) == (0, 0, -9.81)
+
+    def loadURDF(self, path, pos=None, quat=None):
+        if path == "plane.urdf":
+            return 0
+        root = ET.parse(path).getroot()       # the emitted robot: what a real importer would be handed
+        assert len(root.findall("joint")) == 32 and pos == [0, 0, 0.158]
+        return 1
+
+    def changeDynamics(self, body, link, **kw):
+        self.calls.append(("changeDynamics", body, link, tuple(sorted(kw.items()))))
+
+    def getNumJoints(self, body): return 32
+
+    def getJointInfo(self, body, j):
+        return (j, b"joint", self.JOINT_REVOLUTE if j in H.MOVING else self.JOINT_FIXED)
+
+    def getQuaternionFromEuler(self, e):
+        assert list(e) == [0, 0, 0]
+        return (0.0, 0.0, 0.0, 1.0)
+
+    def getEulerFromQuaternion(self, q):       # pybullet.c getEulerFromQuaternion, as the oracle's observation computes it
+        x, y, z, w = q
+        sarg = -2.0 * (x * z - w * y)
+        if sarg <= -0.99999:
+            return (0.0, -0.5 * np.pi, 2 * np.arctan2(x, -y))
+        if sarg >= 0.99999:
+            return (0.0, 0.5 * np.pi, 2 * np.arctan2(-x, y))
+        return (np.arctan2(2 * (y * z + w * x), w * w - x * x - y * y + z * z), np.arcsin(sarg), np.arctan2(2 * (x * y + w * z), w * w + x * x - y * y - z * z))
+
+    def resetBasePositionAndOrientation(self, body, pos, quat):
+        self.state[:] = 0.0
+        self.state[0:3] = pos; self.state[3:7] = quat
+        self.o.reset()                        # (clears the oracle's episode bookkeeping; the state is injected next)
+        self.o.set_state(self.state)
+
+    def resetJointState(self, body, j, q):
+        k = H.MOVING.index(j)
+        self.state[13 + k] = q; self.state[31 + k] = 0.0
+        self.o.set_state(self.state)
+
+    def setJointMotorControlArray(self, bodyUniqueId, jointIndices, controlMode, targetPositions, forces):
+        assert list(jointIndices) == H.MOVING and controlMode == self.POSITION_CONTROL and list(forces) == [0.15] * 18
+        self.o.set_targets(np.asarray(targetPositions, dtype=np.float64))
+
+    def stepSimulation(self):
+        self.o.substep()
+        self.state = self.o.get_state()
+
+    def getBasePositionAndOrientation(self, body):
+        s = self.o.get_state(); return tuple(s[0:3]), tuple(s[3:7])
+
+    def getBaseVelocity(self, body):
+        s = self.o.get_state(); return tuple(s[10:13]), tuple(s[7:10])
+
+    def getJointStates(self, body, joints):
+        s = self.o.get_state(); return [(s[13 + k], s[31 + k], None, 0.0) for k in range(18)]
+
+    def getContactPoints(self, a, b, linkIndexA):
+        c = self.o.contacts()
+        return [()] * int(c["right"] if linkIndexA == 11 else c["left"])
+
+
+def test_harness_runs_end_to_end_against_a_stub_pybullet(tmp_path, monkeypatch):
+    """tests/pybullet_harness.py -- the one command to run the day PyBullet is at hand -- executed here against a stub `pybullet` whose engine is the oracle:
+    the emitted robot loads, the reference's call order (plen_env.py:275-315, 439-481, 558-570, 638-667, 768-822) goes through, the foot / link dynamics are
+    set as the reference sets them, and the harness's comparison of "PyBullet" with the oracle reports zero error on the reset stance, on 8 first steps and on
+    20 steps of the recorded policy commands; its step timer returns a rate."""
+    import sys
+    import types
+    stub = _StubBullet()
+    mod = types.ModuleType("pybullet")
+    for name in dir(stub):
+        if not name.startswith("_") or name == "__version__":
+            setattr(mod, name, getattr(stub, name))
+    data = types.ModuleType("pybullet_data"); data.getDataPath = lambda: str(tmp_path)
+    monkeypatch.setitem(sys.modules, "pybullet", mod); monkeypatch.setitem(sys.modules, "pybullet_data", data)
+    res = H.compare_with_oracle(str(tmp_path), n_first_steps=8, replay_steps=20)
+    assert res["reset_err"] <= 1e-12 and res["first_step_max_abs_err"] <= 1e-12 and res["first_step_contact_flags_equal"] == 1.0
+    assert res["policy_replay_steps_within_1e4"] == 20 and max(res["policy_replay_err_per_step"]) <= 1e-12
+    feet = [c for c in stub.calls if c[0] == "changeDynamics" and c[1] == 1 and c[2] in (11, 19) and dict(c[3]).get("rollingFriction") == 0.1]
+    assert len(feet) == 2 and all(dict(c[3]) == {"lateralFriction": 0.8, "spinningFriction": 0.1, "rollingFriction": 0.1} for c in feet)      # plen_env.py:439-456
+    assert sum(1 for c in stub.calls if c[0] == "changeDynamics" and dict(c[3]).get("restitution") == 0.5 and c[1] == 1) == 32                 # plen_env.py:472-481
+    t = H.time_steps(str(tmp_path), budget_s=0.3)
+    assert t["value"] > 0 and t["cores"] == 1 and t["env_steps"] >= 1
+    assert "disconnect" in stub.calls
