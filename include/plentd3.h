@@ -198,6 +198,13 @@ typedef struct PlenTd3ActorRows {
 } PlenTd3ActorRows;
 int plentd3_actor_rows(const PlenTd3ActorRows *args, void *stream);
 
+/* plentd3_actor_rows in the shape of the large-batch passes (16 envs per 256-thread workgroup, packed weights p_a_w1 (256 x 26), p_a_w2 (256 x 256), p_a_w3
+ * (18 x 256) of the acting network, plentd3_pack): same draws, same arithmetic up to summation order; rows.p1 / rows.p2 are not written (may be NULL). */
+typedef struct PlenTd3ActorBlock { PlenTd3ActorRows rows; const float *p_a_w1, *p_a_w2, *p_a_w3; } PlenTd3ActorBlock;
+int plentd3_actor_block(const PlenTd3ActorBlock *args, void *stream);
+/* development (scripts/gpu_clock_probe.py): `workgroups` single-wave workgroups that issue 32 iters matrix-core instructions each and nothing else;
+ * sink: float [64 workgroups] or NULL */
+int plentd3_dev_mfma_spin(int workgroups, int iters, float *sink, void *stream);
 /* development: table[(*counter / div) % ring][idx] = the device's constant-rate clock (wall_clock64, 100 MHz) at this point of the stream (table is
  * [ring][nslots] uint64; counter NULL = row 0).  A graph node like the rest: successive replays fill successive rows, no profiler in the way */
 int plentd3_stamp(uint64_t *table, const int64_t *counter, int64_t div, int ring, int nslots, int idx, void *stream);

@@ -91,21 +91,34 @@ static __device__ __forceinline__ void blk_mm(const BlkPre<NT> &pre, rsrc_t wp, 
     // three stages in flight: the loads of step s + 2 are issued before the MFMAs of step s (an L2 hit is ~500 cycles under load, a step of NT = 4 tiles
     // is 512 cycles of matrix pipe); left alone the compiler sinks the loads to their first use
     // (the B operand comes from LDS, ~100 cycles away: one step ahead is enough)
-    floatx4 a[3][NT], b[2];
+    floatx4 a[3][NT], b[3];
 #pragma unroll
     for (int t = 0; t < NT; t++) { a[0][t] = pre.a0[t]; a[1][t] = pre.a1[t]; }
     b[0] = loadB(0);
-#pragma unroll
-    for (int s = 0; s < KS; s++) {
-        if (s + 2 < KS) loadA(s + 2, a[(s + 2) % 3]);
-        if (s + 1 < KS) b[(s + 1) % 2] = loadB(s + 1);
+    auto step = [&](int s, int i, bool more2, bool more1) {          // k step s in ring slot i (compile-time at every call site)
+        if (more2) loadA(s + 2, a[(i + 2) % 3]);
+        if (more1) b[(i + 1) % 3] = loadB(s + 1);
         if (s == (KS > 2 ? KS - 2 : 0)) tail();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int v = 0; v < 4; v++)
 #pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s % 3][t][v], b[s % 2][v], acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][t][v], b[i][v], acc[t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+    };
+    if constexpr (KS >= 8) {
+        // a real loop over groups of three k steps (the ring's period) instead of KS unrolled copies: the unrolled passes were ~55 KB of straight-line code
+        // streaming through the 64 KB instruction cache a pair of compute units shares WITH THE ENV WAVES beside them (scripts/gpu_clock_probe.py: the envs'
+        // longest waves took 25 % more cycles beside the update, none beside matrix-core instructions alone)
+        constexpr int G = (KS - 2) / 3;                    // whole groups whose loads all exist (s + 2 < KS throughout)
+        int s0 = 0;
+#pragma unroll 1
+        for (int gi = 0; gi < G; gi++, s0 += 3) { step(s0, 0, true, true); step(s0 + 1, 1, true, true); step(s0 + 2, 2, true, true); }
+#pragma unroll
+        for (int s = 3 * G; s < KS; s++) step(s, s % 3, s + 2 < KS, s + 1 < KS);
+    } else {
+#pragma unroll
+        for (int s = 0; s < KS; s++) step(s, s % 3, s + 2 < KS, s + 1 < KS);
     }
 }
 
@@ -801,4 +814,71 @@ __global__ __launch_bounds__(256) void k_adam_big(float *__restrict__ p, float *
     if (reduce_only) return;
     __syncthreads();
     if (threadIdx.x == 0 && atomicAdd(done_count, 1) == (int)gridDim.x - 1) { done_count[0] = 0; step[0] = t; }
+}
+
+// ---- the collect phase's action (plen_td3.py:101-104): a = clamp(actor(state) + N(0, sigma), +-max_a), 16 envs per workgroup, in the shape of the passes above
+//      (packed weights, transposed products, activations in LDS).  It is on every vector step's critical path -- a sub-batch's env launch cannot start before it --
+//      and k_actor_rows4 (unpacked weights, activations through global memory) took 20 us per 2048 envs alone, 30-67 us beside the other collector's env launch.
+//      Same draws as k_actor_rows (noise index = element index); p1 / p2 are not written.
+__global__ __launch_bounds__(64 * BLK_NW) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_actor_block(PlenTd3ActorBlock P) {
+    const PlenTd3ActorRows &A = P.rows;
+    __shared__ __attribute__((aligned(16))) float Sb[BLK_R * PB_LD_SA];
+    __shared__ __attribute__((aligned(16))) float Xb[BLK_R * BLK_LD_W];
+    __shared__ __attribute__((aligned(16))) float Yb[BLK_R * BLK_LD_W];
+    const int B = A.B, b0 = blockIdx.x * BLK_R;
+    BLK_WAVE();
+    BlkPre<4> pre;
+    {
+        const Blk k = blk_ids(wv);
+        pre = blk_pre<4, 2>(mkrs(P.p_a_w1, (size_t)16 * 2 * 1024), 4 * k.w, k);
+        for (int i = BLK_TID(k); i < BLK_R * PB_LD_SA; i += 64 * BLK_NW) {
+            const int row = i / PB_LD_SA, c = i - row * PB_LD_SA;
+            Sb[i] = c < TD3_S ? A.state[(size_t)min(b0 + row, B - 1) * TD3_S + c] : 0.f;
+        }
+    }
+    TEAM_LDS_BARRIER();
+    {
+        const Blk k = blk_ids(wv);
+        blk_dense_relu<4, 2, false>(pre, mkrs(P.p_a_w1, (size_t)16 * 2 * 1024), 4 * k.w, Sb, PB_LD_SA, 0, A.a_b1, Xb, BLK_LD_W, 4 * k.w, k);
+        pre = blk_pre<4, 16>(mkrs(P.p_a_w2, (size_t)16 * 16 * 1024), 4 * k.w, k);
+    }
+    TEAM_LDS_BARRIER();
+    {
+        const Blk k = blk_ids(wv);
+        blk_dense_relu<4, 16>(pre, mkrs(P.p_a_w2, (size_t)16 * 16 * 1024), 4 * k.w, Xb, BLK_LD_W, 0, A.a_b2, Yb, BLK_LD_W, 4 * k.w, k);
+    }
+    TEAM_LDS_BARRIER();
+    {
+        const Blk k = blk_ids(wv);
+        blk_split_k(mkrs(P.p_a_w3, (size_t)2 * 16 * 1024), Yb, Xb, k);
+    }
+    TEAM_LDS_BARRIER();
+    {
+        const Blk k = blk_ids(wv);
+        if (k.w < 2) {
+            const floatx4 z = blk_split_sum(Xb, k.w, k);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int j = 16 * k.w + 4 * k.g + i, b = b0 + k.r;
+                if (j < TD3_A && b < B) {
+                    const int e = b * TD3_A + j;
+                    A.action[e] = fminf(fmaxf(A.max_a * tanhf(z[i] + A.a_b3[j]) + rng_normal(A.rng, 2u, (uint32_t)e) * A.sigma, -A.max_a), A.max_a);
+                }
+            }
+        }
+    }
+}
+
+// ---- development (scripts/gpu_clock_probe.py): a workload of matrix-core instructions ONLY -- no memory, no LDS, 20 registers, one wave per workgroup -- to see what
+//      the matrix pipe by itself costs env waves that share its SIMD (issue slots: an MFMA holds the vector issue port for 8 of its 32 cycles)
+__global__ __launch_bounds__(64) void k_dev_mfma_spin(int iters, float *sink) {
+    floatx4 acc[4] = {floatx4{0, 0, 0, 0}, floatx4{0, 0, 0, 0}, floatx4{0, 0, 0, 0}, floatx4{0, 0, 0, 0}};
+    const float a = (float)threadIdx.x * 1e-3f, b = 1.0f;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+    }
+    if (sink) sink[blockIdx.x * 64 + threadIdx.x] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
 }

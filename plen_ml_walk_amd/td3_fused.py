@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libplentd3.so")
 EXPORTS = ["plentd3_gather", "plentd3_sample_gather", "plentd3_explore", "plentd3_uniform_actions", "plentd3_store", "plentd3_target_action", "plentd3_q_heads", "plentd3_dh2", "plentd3_relu_mask", "plentd3_colsum", "plentd3_wgrad",
            "plentd3_tanh_out", "plentd3_dtanh", "plentd3_bias_relu", "plentd3_polyak", "plentd3_adam", "plentd3_critic_rows", "plentd3_policy_rows", "plentd3_actor_rows", "plentd3_critic_team", "plentd3_policy_team",
-           "plentd3_wgrad_group", "plentd3_wgrad_adam_group", "plentd3_pack", "plentd3_critic_block", "plentd3_policy_block", "plentd3_wgrad_big", "plentd3_adam_big", "plentd3_stamp", "plentd3_version"]
+           "plentd3_wgrad_group", "plentd3_wgrad_adam_group", "plentd3_pack", "plentd3_critic_block", "plentd3_policy_block", "plentd3_wgrad_big", "plentd3_adam_big", "plentd3_actor_block", "plentd3_dev_mfma_spin", "plentd3_stamp", "plentd3_version"]
 ROW, S, A, SA, H = 72, 26, 18, 44, 256
 _lib = None
 
@@ -109,6 +109,11 @@ class WgradBig(C.Structure):
     _fields_ = [("job", WgradBigJob * WGRAD_BIG_JOBS)] + [(n, C.c_int) for n in ("n_jobs", "B", "chunks", "rows_per_chunk", "stride")] + [("partial", C.c_void_p)]
 
 
+class ActorBlockArgs(C.Structure):
+    """Mirror of PlenTd3ActorBlock (include/plentd3.h)."""
+    _fields_ = [("rows", ActorRowsArgs)] + [(n, C.c_void_p) for n in ("p_a_w1", "p_a_w2", "p_a_w3")]
+
+
 TEAM_MAX_BATCH = 512          # FusedTD3(team=None): batches up to this size take the small-batch kernels (csrc/td3_team.hip)
 
 
@@ -146,6 +151,8 @@ def load():
         lib.plentd3_pack.argtypes = [C.POINTER(PackGroup), vp]
         lib.plentd3_critic_block.argtypes = [C.POINTER(CriticBlockArgs), vp]
         lib.plentd3_policy_block.argtypes = [C.POINTER(PolicyBlockArgs), vp]
+        lib.plentd3_dev_mfma_spin.argtypes = [i, i, vp, vp]
+        lib.plentd3_actor_block.argtypes = [C.POINTER(ActorBlockArgs), vp]
         lib.plentd3_wgrad_big.argtypes = [C.POINTER(WgradBig), vp]
         lib.plentd3_adam_big.argtypes = [vp, vp, vp, vp, vp, vp, i, C.c_double, C.c_double, C.c_double, f, vp, f, vp, vp, i, i, i, vp]
         lib.plentd3_wgrad_group.argtypes = [C.POINTER(WgradGroup), vp]
@@ -270,6 +277,7 @@ class FusedTD3(object):
         self.block = (None if "PLEN_TD3_BLOCK" not in os.environ else os.environ["PLEN_TD3_BLOCK"] == "1") if block is None else bool(block)
         self._block_pass = False
         self._packs = {}             # name -> packed copy of a weight matrix (plentd3_pack), rewritten before every pass that reads it
+        self._actor_packs = {}       # id(acting network) -> its packed matrices' names and the parameter versions they were made from
         self._partials = None
         self._big = {}               # "critic" / "actor" -> (partial gradients [chunks][stride], stride) of plentd3_wgrad_big
         self._big_pending = {}       # network -> chunks whose partial gradients still wait for their optimiser step (update() takes it with plentd3_adam_big)
@@ -477,12 +485,28 @@ class FusedTD3(object):
                 self.polyak()
         return loss
 
-    def explore(self, state, sigma, actor=None, rng=None):
+    def explore(self, state, sigma, actor=None, rng=None, packed=False):
         """Collect-phase action (plen_td3.py:101-104): clamp(actor(state) + N(0, sigma), +-max_action) -- 3 GEMMs and one fused kernel that draws
         its own noise from `rng` (new_rng(); bumped by the store() that follows).  `actor`: the network to act with (default the online
         actor; the pipelined trainer passes a behaviour copy).  rng None: torch.randn (autograd-path compatible)."""
         ag = self.agent
         ac = ag.actor if actor is None else actor
+        if self.rows and rng is not None and self._use_block(int(state.shape[0])):
+            # large batches: the block kernel on the acting network's packed weights.  packed: the caller has run pack_actor(actor) since the network last changed
+            # (the pipelined trainer does, on the update stream, off the collectors' critical path); otherwise they are packed here, every call -- nothing
+            # observable says whether raw-pointer kernels (the Adam steps) have rewritten the parameters since
+            n = int(state.shape[0])
+            assert state.dtype == torch.float32 and state.is_contiguous() and state.shape[1] == S
+            packs = self.pack_actor(ac, launch=not packed)
+            act = (self._alloc or (lambda *shape: torch.empty(*shape, device=self.dev, dtype=torch.float32)))(n, A)
+            pa = ActorBlockArgs()
+            a = pa.rows
+            a.a_b1, a.a_b2, a.a_b3 = ac.fc1.bias.data_ptr(), ac.fc2.bias.data_ptr(), ac.fc3.bias.data_ptr()
+            a.state, a.rng, a.action = state.data_ptr(), rng.data_ptr(), act.data_ptr()
+            a.sigma, a.max_a, a.B = float(sigma), float(ag.max_action), n
+            pa.p_a_w1, pa.p_a_w2, pa.p_a_w3 = (t.data_ptr() for t in packs)
+            _chk(self.lib.plentd3_actor_block(C.byref(pa), self._stream()))
+            return act
         if self.rows and rng is not None:
             n = int(state.shape[0])
             assert state.dtype == torch.float32 and state.is_contiguous() and state.shape[1] == S
@@ -501,6 +525,17 @@ class FusedTD3(object):
             a = torch.empty_like(pre)
             _chk(self.lib.plentd3_explore(_p(pre), _p(noise), _p(rng), _p(a), float(sigma), float(ag.max_action), pre.numel(), self._stream()))
         return a
+
+    def pack_actor(self, ac, launch=True):
+        """The three weight matrices of an acting network (the online actor, a behaviour copy) in matrix-core operand order for plentd3_actor_block; one set of
+        packed buffers per network object.  launch False: only look the buffers up (they must have been packed since the network last changed)."""
+        names = self._actor_packs.get(id(ac))
+        if names is None:
+            names = self._actor_packs[id(ac)] = tuple("act%d_%s" % (len(self._actor_packs), n_) for n_ in ("w1", "w2", "w3"))
+            launch = True
+        if launch:
+            self._pack([self._nt(names[0], ac.fc1.weight), self._nt(names[1], ac.fc2.weight), self._nt(names[2], ac.fc3.weight)])
+        return tuple(self._packs[n_] for n_ in names)
 
     def uniform_actions(self, n, rng):
         """Warm-up actions U[-1, 1)^18 for n envs (plen_td3.py:91-92), drawn in-kernel from `rng` (bumped by the store() that follows)."""

@@ -461,6 +461,9 @@ class PipelinedVecTD3Trainer(object):
         # behaviour actors: 3 copies of the actor whose parameters are views of their own flat buffers
         self.behaviour = [copy.deepcopy(agent.actor) for _ in range(3)]
         self.bflat = [T._FlatParams(b) for b in self.behaviour]
+        if self.fused._use_block(self.nh):         # (every later change of a behaviour copy is followed by its repacking: _finish)
+            for b in self.behaviour:
+                self.fused.pack_actor(b)
         from .vec_env import worker_stream
         self.streams = [worker_stream(dev, h) for h in range(self.H)]
         self.su = worker_stream(dev, "update")
@@ -500,7 +503,7 @@ class PipelinedVecTD3Trainer(object):
         if random_actions:
             action = self.fused.uniform_actions(nh, self.rngs[h])
         else:
-            action = self.fused.explore(self.state[h], self.agent.max_action * self.expl_noise, actor=self.behaviour[buf], rng=self.rngs[h])
+            action = self.fused.explore(self.state[h], self.agent.max_action * self.expl_noise, actor=self.behaviour[buf], rng=self.rngs[h], packed=True)
         self._stamp(self.base[h], 4 * h + 1)
         next_obs, reward, done, info = env.step(action)
         self._stamp(self.base[h], 4 * h + 2)
@@ -519,6 +522,8 @@ class PipelinedVecTD3Trainer(object):
     def _finish(self, buf_out):
         self.total_u += self.n
         self.bflat[buf_out].flat.copy_(self.agent._actor_flat.flat)
+        if self.fused._use_block(self.nh):     # ... and in matrix-core operand order for the collectors' actor forward, here on the update stream: off their critical path
+            self.fused.pack_actor(self.behaviour[buf_out])
 
     # the same update cut at its collectives (world_size > 1)
     def _seg_critic_backward(self):
@@ -594,6 +599,8 @@ class PipelinedVecTD3Trainer(object):
             with torch.cuda.stream(su):
                 self.total_u += n                               # invariant: total_u == t * n when update t samples (rows of steps < t are complete)
                 self.bflat[(t + 1) % 3].flat.copy_(self.agent._actor_flat.flat)
+                if self.fused._use_block(self.nh):
+                    self.fused.pack_actor(self.behaviour[(t + 1) % 3])
         e = torch.cuda.Event(); e.record(su); self._ev_upd[t] = e
         for k in [k for k in self._ev_upd if k < t - 3]:
             del self._ev_upd[k]

@@ -3,6 +3,7 @@
 Torch is plumbing here (device memory + the current stream); the step itself is libplenvec.so.
 The single-env, reference-shaped facade is plen_ml_walk_amd.plen_env.PlenWalkEnv."""
 import ctypes as C
+import os
 import torch
 from . import _lib as L
 
@@ -166,6 +167,8 @@ _WORKER_STREAMS = {}
 # first-use order of the role streams of a device (PLEN_STREAM_ROLE_ORDER overrides it for experiments; "x" = a throw-away stream)
 _ROLE_ORDER = "2,3,0,1,update,side"
 _ROLE_PRIORITY = {"update": -1}
+if os.environ.get("PLEN_ROLE_PRIORITY"):          # experiments: "update:0,0:-1,1:-1" (HIP dispatch priorities per role; -1 = high)
+    _ROLE_PRIORITY = {k: int(v) for k, v in (kv.split(":") for kv in os.environ["PLEN_ROLE_PRIORITY"].split(","))}
 
 
 def worker_stream(device, role):

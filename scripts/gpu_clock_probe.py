@@ -46,9 +46,28 @@ def learner_graph(B, kw):
     return gr
 
 
-for label, B, kw in (("envs alone", 0, None), ("+ block updates, batch 4096", 4096, dict(rows=False, team=False, block=True)), ("+ block updates, batch 1024", 1024, dict(rows=False, team=False, block=True)),
+import ctypes as C
+from plen_ml_walk_amd import td3_fused as F
+_lib = F.load()
+
+
+def spin_graph(wgs, iters):
+    """~100 us of matrix-core instructions on `wgs` single-wave workgroups, 8 launches per graph"""
+    sink = torch.zeros(wgs * 64, device=dev)
+    with torch.cuda.stream(su):
+        _lib.plentd3_dev_mfma_spin(wgs, iters, C.c_void_p(sink.data_ptr()), C.c_void_p(su.cuda_stream))
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, stream=su):
+        for _ in range(8):
+            _lib.plentd3_dev_mfma_spin(wgs, iters, C.c_void_p(sink.data_ptr()), C.c_void_p(su.cuda_stream))
+    gr._keep = sink
+    return gr
+
+
+for label, B, kw in (("envs alone", 0, None), ("+ MFMA only, 1024 waves x ~100 us", -1, (1024, 200)), ("+ MFMA only, 256 waves x ~100 us", -1, (256, 200)), ("+ block updates, batch 4096", 4096, dict(rows=False, team=False, block=True)), ("+ block updates, batch 1024", 1024, dict(rows=False, team=False, block=True)),
                      ("+ row-kernel updates, batch 4096", 4096, dict(rows=True, team=False, block=False)), ("envs alone again", 0, None)):
-    gr = learner_graph(B, kw) if B else None
+    gr = (spin_graph(*kw) if B < 0 else learner_graph(B, kw)) if B else None
     steps = 120
     for t in range(20):
         for h in range(2):

@@ -133,3 +133,35 @@ def test_reference_golden_iterations_through_the_large_batch_kernels(golden_dir)
         torch.cuda.synchronize()
         assert fz._block_pass and torch.isfinite(loss)
         _check_against_golden(g, a, k)
+
+
+@pytest.mark.parametrize("n", [2048, 37, 16])
+def test_collect_phase_actor_forward_block_kernel_equals_the_row_kernel(n):
+    """plentd3_actor_block (16 envs per workgroup, packed weights, activations in LDS) against plentd3_actor_rows on the same states, the same acting network
+    and the same random state: the same exploration noise is drawn (noise index = element index), the actions agree to f32 summation order; repacking
+    happens exactly when the acting network has changed."""
+    from plen_ml_walk_amd.td3_fused import FusedTD3
+    ag = _agent(8)
+    state = torch.randn(n, 26, device="cuda") * torch.tensor([1.0] * 18 + [0.1, 0.3, 0.3, 0.3, 0.3, 0.3, 1.0, 1.0], device="cuda")
+    out = {}
+    for block in (False, True):
+        fz = FusedTD3(ag, seed=4, rows=True, block=block)
+        rng = FusedTD3.new_rng(ag.device, 77)
+        out[block] = fz.explore(state, 0.1, rng=rng).clone()
+    torch.cuda.synchronize()
+    assert float((out[False] - out[True]).abs().max()) <= 2e-5 and float(out[True].abs().max()) <= 1.0 and float(out[True].std()) > 0.01
+    # packed=True trusts the caller: stale packs after a raw change of the network, fresh ones after pack_actor() -- and without the promise explore() repacks itself
+    fz = FusedTD3(ag, seed=4, rows=True, block=True)
+    rng = FusedTD3.new_rng(ag.device, 77)
+    a0 = fz.explore(state, 0.0, rng=rng).clone()
+    with torch.no_grad():
+        ag._actor_flat.flat.mul_(0.5)
+    stale = fz.explore(state, 0.0, rng=rng, packed=True).clone()
+    fresh = fz.explore(state, 0.0, rng=rng).clone()
+    fz.pack_actor(ag.actor)
+    again = fz.explore(state, 0.0, rng=rng, packed=True).clone()
+    torch.cuda.synchronize()
+    assert float((a0 - fresh).abs().max()) > 1e-3 and float((stale - fresh).abs().max()) > 1e-3 and torch.equal(fresh, again)       # (stale: old matrices, new biases)
+    with torch.no_grad():
+        ref = ag.max_action * torch.tanh(ag.actor.fc3(torch.relu(ag.actor.fc2(torch.relu(ag.actor.fc1(state))))))
+    assert float((fresh - ref).abs().max()) <= 2e-5

@@ -336,8 +336,7 @@ def test_asm_path_bitwise_equals_compiler_path(tmp_path, dt):
     assert np.array_equal(outs[0], outs[1], equal_nan=True)
 
 
-@pytest.mark.parametrize("cfg", ["reference", "no_torsional_friction", "fallen_robots"])
-@pytest.mark.parametrize("dt", ["float32", "float64"])
+@pytest.mark.parametrize("dt,cfg", [("float32", "reference"), ("float64", "reference"), ("float64", "no_torsional_friction"), ("float32", "fallen_robots")])
 def test_count_specialised_solver_loops_bitwise_equal_the_run_time_tested_loop(tmp_path, dt, cfg):
     """Round 4: the solver's iteration loop is compiled once per pair of foot point counts and chosen once per substep.  That changes which code runs, not one
     operation or its order: against a build with rounds 1-3's run-time point tests (-DPLENVEC_COUNT_SPECIALISED=0, csrc/variants/nospec.so, built by
