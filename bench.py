@@ -460,10 +460,8 @@ def policy_leg(a, dev, rank, world, dist, steps, warmup):
     stats = [torch.zeros((), dtype=torch.long, device=dev) for _ in range(H)]         # episodes that ended
     torch.cuda.synchronize(dev)
 
-    fused.pack_actor(agent.actor)               # the policy is fixed: packed once, not once per step
-
     def collect(h):
-        act = fused.explore(state[h], sigma, actor=agent.actor, rng=rngs[h], packed=True)
+        act = fused.explore(state[h], sigma, actor=agent.actor, rng=rngs[h])
         rngs[h][1] += 1
         _, _, d, info = envs[h].step(act)
         stats[h] += (d != 0).sum()                 # (bookkeeping kept to two small kernels: it sits on the collector's critical path)

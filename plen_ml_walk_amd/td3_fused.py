@@ -281,6 +281,7 @@ class FusedTD3(object):
         self._partials = None
         self._big = {}               # "critic" / "actor" -> (partial gradients [chunks][stride], stride) of plentd3_wgrad_big
         self._big_pending = {}       # network -> chunks whose partial gradients still wait for their optimiser step (update() takes it with plentd3_adam_big)
+        self._hold_wgrad, self._held = False, None       # update_first_half() / update_second_half()
         # one rank, small batch, flat Adam: the optimiser step is taken inside the grouped weight-gradient kernel (plentd3_wgrad_adam_group).
         # update() sets _fuse = {"critic": target-or-None, "actor": target} for the passes it is about to run and reads _fused_done back.
         self.fuse_adam = os.environ.get("PLEN_TD3_FUSE_ADAM", "1") == "1"
@@ -448,6 +449,36 @@ class FusedTD3(object):
             loss = self.critic_backward(data, idx, noise, total, guard)
         finally:
             self._fuse = None            # (consent to the in-kernel Adam step never outlives the pass it was given for)
+        return self._after_critic_backward(loss, with_policy, all_reduce, flat, fuse)
+
+    def update_first_half(self, data, B, total, guard=0):
+        """The large-batch iteration cut where its ONE big kernel ends (single rank, flat Adam): sampling, packing and the critic pass kernel here; the weight
+        gradients, both optimiser steps and the delayed policy update in update_second_half().  For a schedule that runs each half in the idle window of a
+        different collector stream (train_vec.PipelinedVecTD3Trainer, inline_update): 81 us and 28 / 87 us alone.  Returns the loss (device scalar)."""
+        assert self._critic_adam is not None and self._use_block(int(B))
+        self._fused_done = set()
+        self._hold_wgrad = True
+        try:
+            loss = self.critic_backward(data, int(B), None, total, guard)
+        finally:
+            self._hold_wgrad = False
+        assert self._held is not None
+        return loss
+
+    def update_second_half(self, loss, with_policy):
+        ag = self.agent
+        # (not cleared: once the first half is a replayed hipGraph its Python does not run again, and the tensors of its capture -- static addresses in the graph's
+        #  private pool -- are what every later capture of a second half has to see)
+        B, jobs = self._held
+        self._fuse = {"critic": ag._critic_target_flat.flat if with_policy else None}
+        try:
+            self._wgrad_big("critic", B, jobs)
+        finally:
+            self._fuse = None
+        return self._after_critic_backward(loss, with_policy, False, True, True)
+
+    def _after_critic_backward(self, loss, with_policy, all_reduce, flat, fuse):
+        ag = self.agent
         if all_reduce:
             ag._critic_grads.all_reduce_mean()
         if "critic" in self._big_pending:        # large batch: the step on bucket + partial gradients, the bucket left zero (+ the critic's Polyak update)
@@ -491,10 +522,11 @@ class FusedTD3(object):
         actor; the pipelined trainer passes a behaviour copy).  rng None: torch.randn (autograd-path compatible)."""
         ag = self.agent
         ac = ag.actor if actor is None else actor
-        if self.rows and rng is not None and self._use_block(int(state.shape[0])):
+        if self.rows and rng is not None and self._use_block(int(state.shape[0])) and (packed or self.block is True):
             # large batches: the block kernel on the acting network's packed weights.  packed: the caller has run pack_actor(actor) since the network last changed
-            # (the pipelined trainer does, on the update stream, off the collectors' critical path); otherwise they are packed here, every call -- nothing
-            # observable says whether raw-pointer kernels (the Adam steps) have rewritten the parameters since
+            # (the pipelined trainer does, on the update stream, off the collectors' critical path); with block=True and no such promise they are packed here, every
+            # call -- nothing observable says whether raw-pointer kernels (the Adam steps) have rewritten the parameters since.  Without either the four-wave row
+            # kernel below runs: its workgroups need no LDS to speak of and start sooner beside a resident env launch (bench.py's policy leg: 11.88 against 11.74 M)
             n = int(state.shape[0])
             assert state.dtype == torch.float32 and state.is_contiguous() and state.shape[1] == S
             packs = self.pack_actor(ac, launch=not packed)
@@ -706,9 +738,13 @@ class FusedTD3(object):
                 _chk(lib.plentd3_critic_block(C.byref(pa), st))
                 self._block_pass = True
                 self._probe(3)
-                self._wgrad_big("critic", B, [(dq[:, 0:1], c2[:, :H], cr.fc3.weight.grad, None), (dq[:, 1:2], c2[:, H:], cr.fc6.weight.grad, None),
-                                              (dh2[:, :H], c1[:, :H], cr.fc2.weight.grad, cr.fc2.bias.grad), (dh2[:, H:], c1[:, H:], cr.fc5.weight.grad, cr.fc5.bias.grad),
-                                              (dh1, batch[:, :SA], gv["W14"], gv["b14"])])
+                jobs = [(dq[:, 0:1], c2[:, :H], cr.fc3.weight.grad, None), (dq[:, 1:2], c2[:, H:], cr.fc6.weight.grad, None),
+                        (dh2[:, :H], c1[:, :H], cr.fc2.weight.grad, cr.fc2.bias.grad), (dh2[:, H:], c1[:, H:], cr.fc5.weight.grad, cr.fc5.bias.grad),
+                        (dh1, batch[:, :SA], gv["W14"], gv["b14"])]
+                if self._hold_wgrad:          # update_first_half(): the weight gradients are launched by update_second_half()
+                    self._held = (B, jobs)
+                else:
+                    self._wgrad_big("critic", B, jobs)
                 self._saved = (batch[:, :S], sa_pi, B)
                 self._probe(4)
                 return loss[0]
