@@ -41,6 +41,10 @@ int plentd3_uniform_actions(const uint64_t *rng, float *a, int n, void *stream);
  * (the reference prints each episode's return and a moving average, plen_env.py:616-636) */
 int plentd3_store(float *data, const int64_t *total, int64_t capacity, const float *s, const float *a, const float *s2, const float *r, const uint8_t *done, uint64_t *rng_bump,
                   float *ep_ret, double *stats, int n, void *stream);
+/* plentd3_store, and then s = next_state (n x 26 floats, a different buffer: the env's current observation, i.e. the reset observation where the episode ended --
+ * plen_td3.py:115 `state = next_state` / :133 `state = env.reset()`) in the same launch */
+int plentd3_store_advance(float *data, const int64_t *total, int64_t capacity, float *s, const float *a, const float *s2, const float *r, const uint8_t *done, uint64_t *rng_bump,
+                          float *ep_ret, double *stats, int n, const float *next_state, void *stream);
 /* td3.py:299-304: sa2 = [s2 | clamp(max_a tanh(pre) + clamp(noise sigma, +-clip), +-max_a)], pre = actor_target's last pre-activation */
 int plentd3_target_action(const float *pre, const float *noise, const uint64_t *rng, const float *batch, float *sa2, float sigma, float clip, float max_a, int B, void *stream);
 /* twin last layers on h2 = [h2_a | h2_b] ([B][512]).  mode 0, td3.py:306-309: y = r + not_done gamma min(q_a, q_b).

@@ -362,9 +362,9 @@ __global__ void k_uniform_actions(const uint64_t *__restrict__ rng, float *__res
 
 // ---- K14: write one vector step into the replay ring (plen_td3.py:109-113): row (total + e) % capacity = s | a | s2 | r | 1 - done_bool,
 //      done_bool = compute_done() fired AND the time limit did not (PLENVEC_DONE_TERMINAL = 1, _TIMELIMIT = 2)
-__global__ void k_store(float *__restrict__ data, const int64_t *__restrict__ total, int64_t capacity, const float *__restrict__ s, const float *__restrict__ a,
+__global__ void k_store(float *__restrict__ data, const int64_t *__restrict__ total, int64_t capacity, float *__restrict__ s, const float *__restrict__ a,
                         const float *__restrict__ s2, const float *__restrict__ r, const uint8_t *__restrict__ done, uint64_t *rng_bump,
-                        float *__restrict__ ep_ret, double *stats, int n) {
+                        float *__restrict__ ep_ret, double *stats, int n, const float *__restrict__ advance) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (rng_bump && t == 0) rng_bump[1] += 1;           // this collect step's action draw is done
     const int e = t / TD3_ROW, c = t % TD3_ROW;
@@ -380,7 +380,12 @@ __global__ void k_store(float *__restrict__ data, const int64_t *__restrict__ to
     }
     const int64_t row = (total[0] + e) % capacity;
     float v;
-    if (c < TD3_S) v = s[(size_t)e * TD3_S + c];
+    if (c < TD3_S) {
+        v = s[(size_t)e * TD3_S + c];
+        // plentd3_store_advance: the state to act on next (the env's current observation: the reset one where the episode ended) replaces the stored one, element by
+        // element in the thread that has just read it -- the collector's `state = obs` copy launch, on its critical path every step, folded in
+        if (advance) s[(size_t)e * TD3_S + c] = advance[(size_t)e * TD3_S + c];
+    }
     else if (c < TD3_SA) v = a[(size_t)e * TD3_A + c - TD3_S];
     else if (c < TD3_SA + TD3_S) v = s2[(size_t)e * TD3_S + c - TD3_SA];
     else if (c == TD3_ROW - 2) v = r[e];
@@ -542,7 +547,12 @@ int plentd3_uniform_actions(const uint64_t *rng, float *a, int n, void *stream) 
 }
 int plentd3_store(float *data, const int64_t *total, int64_t capacity, const float *s, const float *a, const float *s2, const float *r, const uint8_t *done, uint64_t *rng_bump,
                   float *ep_ret, double *stats, int n, void *stream) {
-    hipLaunchKernelGGL(k_store, GRID(n * TD3_ROW), data, total, capacity, s, a, s2, r, done, rng_bump, ep_ret, stats, n); CHECK();
+    hipLaunchKernelGGL(k_store, GRID(n * TD3_ROW), data, total, capacity, const_cast<float *>(s), a, s2, r, done, rng_bump, ep_ret, stats, n, (const float *)nullptr); CHECK();
+}
+int plentd3_store_advance(float *data, const int64_t *total, int64_t capacity, float *s, const float *a, const float *s2, const float *r, const uint8_t *done, uint64_t *rng_bump,
+                          float *ep_ret, double *stats, int n, const float *next_state, void *stream) {
+    if (!next_state || next_state == s) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_store, GRID(n * TD3_ROW), data, total, capacity, s, a, s2, r, done, rng_bump, ep_ret, stats, n, next_state); CHECK();
 }
 int plentd3_wgrad(const float *dH, int dh_stride, const float *X, int x_stride, float *dW, int dw_stride, float *db, int B, int N, int K, int single_wave, void *stream) {
     const int tiles = ((N + 31) / 32) * ((K + 31) / 32);

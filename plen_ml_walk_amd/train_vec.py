@@ -516,10 +516,14 @@ class PipelinedVecTD3Trainer(object):
         self._stamp(self.base[h], 4 * h + 1)
         next_obs, reward, done, info = env.step(action)
         self._stamp(self.base[h], 4 * h + 2)
-        self.fused.store(self.replay.data, self.base[h], self.state[h], action, next_obs, reward, done, rng=self.rngs[h], episodes=(self.ep_ret[h], self.ep_stats))
+        obs = info["obs"]
+        fold = obs.dtype == torch.float32 and obs.is_contiguous()          # (the state <- observation copy rides in the store kernel)
+        self.fused.store(self.replay.data, self.base[h], self.state[h], action, next_obs, reward, done, rng=self.rngs[h], episodes=(self.ep_ret[h], self.ep_stats),
+                         advance=obs if fold else None)
         self._stamp(self.base[h], 4 * h + 3)
         self.base[h] += self.n
-        self.state[h].copy_(info["obs"])
+        if not fold:
+            self.state[h].copy_(obs)
 
     def _update(self, with_policy, buf_out):
         self._stamp(self.total_u, 4 * self.H)
