@@ -434,6 +434,34 @@ def test_adam_step_inside_the_weight_gradient_kernel_equals_the_separate_step():
         assert torch.equal(a_, b_)
 
 
+def test_cached_eager_small_batch_iteration_equals_the_general_path():
+    """FusedTD3._update_team_eager (persistent scratch tensors and argument blocks for the reference's eager train() call) against the general path that rebuilds
+    everything per call: eight updates of batch 100 (every second one with the policy update) from the same state leave bitwise equal parameters, targets, moments,
+    step counts and losses; a second batch size gets its own cache entry."""
+    from plen_ml_walk_amd import td3 as T
+    from plen_ml_walk_amd.td3_fused import FusedTD3
+    data = torch.randn(5000, 72, device="cuda")
+    data[:, 70] = torch.rand(5000, device="cuda"); data[:, 71] = (torch.rand(5000, device="cuda") > 0.1).float()
+    tot = torch.tensor(5000, dtype=torch.long, device="cuda")
+    out = {}
+    for cached in (False, True):
+        torch.manual_seed(35)
+        ag = T.TD3Agent(26, 18, 1.0, data_parallel=False)
+        fz = FusedTD3(ag, seed=4)
+        fz.enable_flat_adam()
+        fz.eager_cache = cached
+        losses = []
+        for k in range(8):
+            losses.append(fz.update(data, 100 if k < 6 else 64, with_policy=(k % 2 == 1), all_reduce=False, total=tot).clone())
+        torch.cuda.synchronize()
+        assert (len(fz._eager) == 2) == cached and fz._team_pass
+        out[cached] = losses + [ag._critic_flat.flat.clone(), ag._actor_flat.flat.clone(), ag._critic_target_flat.flat.clone(), ag._actor_target_flat.flat.clone(),
+                                fz._critic_adam.m.clone(), fz._critic_adam.v.clone(), fz._actor_adam.m.clone(), fz._critic_adam.step_t.clone(), fz._actor_adam.step_t.clone()]
+        assert float(out[cached][-2]) == 8.0 and float(out[cached][-1]) == 4.0
+    for a_, b_ in zip(out[False], out[True]):
+        assert torch.equal(a_, b_)
+
+
 def test_resumed_optimizer_keeps_its_step_count_through_the_fused_small_batch_update():
     """optimizer.load_state_dict() between updates (a resumed run) replaces the state tensors FlatAdam mirrors; the re-bind has to happen before the pass
     kernel counts the step, or the fused path's counter stays one behind the separate-Adam path's for good: after a reload at step 4, four
