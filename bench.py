@@ -371,6 +371,8 @@ def td3_leg(a, dev, rank, world, dist, steps, warmup):
         # configs[2] at the REFERENCE'S sample ratio: 100 samples drawn per env-step (plen_td3.py:28 batch 100, :119-120 one update per env-step) = 100
         # updates of batch 4096 per vector step of 4096 env-steps: learner-bound by construction
         try:
+            if world > 1 and os.environ.get("PLEN_DIST_BACKEND", "nccl") != "nccl":
+                raise RuntimeError("skipped: ~2000 updates with two host-staged (gloo) all-reduces each; measured over RCCL or on one rank")
             saved = a.td3_updates, a.td3_schedule
             a.td3_updates, a.td3_schedule = 100, "sync"
             try:
