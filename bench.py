@@ -645,9 +645,20 @@ def _td3_roofline(tr, batch, dev):
     finally:
         fz.lib = lib
     alone_us = ev[0].elapsed_time(ev[1]) / 40 * 1e3
+    # HBM traffic and matrix-pipe occupancy of the kernel are PMC measurements of the stand-alone update (scripts/gpu_td3_block_pmc.sh; separate passes, FETCH_SIZE in
+    # KiB doubled as MI355X_MICROARCH.md prescribes for gfx950): reported from the committed summary, valid at batch 4096
+    traffic = busy = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r05_td3_block_pmc_v2.json")))["k_critic_block"]
+        if batch == 4096:
+            traffic = pm["FETCH_SIZE"]["mean_per_dispatch"] * 1024 * 2 + pm["WRITE_SIZE"]["mean_per_dispatch"] * 1024
+        busy = pm["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_dispatch"] / (4.0 * pm["SQ_WAVE_CYCLES"]["mean_per_dispatch"])
+    except Exception:
+        pass
     return {"bound": "mfma_f32", "kernel": "k_critic_block", "achieved": flop / (k_us * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": flop / (k_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, "kernel_us": k_us, "update_us": upd_us, "flop_per_launch": flop,
             "alone_kernel_us": alone_us, "alone_achieved": flop / (alone_us * 1e-6) / 1e12, "alone_frac": flop / (alone_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+            "traffic": traffic, "algorithmic_bytes_per_launch": batch * (288 + 4 * 2048 + 288 + 104 + 8) + 1540000, "matrix_pipe_busy_frac_alone": busy,
             "note": "algorithmic flop = 2 x %d multiply-adds per batch row x %d rows per launch; kernel_us = mean over %d launches of the device-clock interval between the "
                     "stamp nodes around the kernel in the update graph, beside two resident env launches (the envs hold every wave slot: the kernel's workgroups wait for "
                     "retiring env waves and share their SIMDs' issue ports); alone_* = the same launch back to back on the idle GPU (HIP events around 5 replays of a graph of 8: "
@@ -680,7 +691,7 @@ def flatten_for_the_driver(out):
     cfg["td3_grad_steps_per_s"] = get(legs, "td3", "grad_steps_per_s")
     cfg["td3_ms_per_step"] = get(legs, "td3", "ms_per_step")
     cfg["td3_batch"] = get(legs, "td3", "batch_per_rank")
-    for k in ("bound", "achieved", "peak", "frac", "kernel_us", "unit"):            # the learner's own roofline (the critic pass kernel, measured inside the leg)
+    for k in ("bound", "achieved", "peak", "frac", "kernel_us", "unit", "alone_frac", "alone_kernel_us", "traffic", "matrix_pipe_busy_frac_alone"):            # the learner's own roofline (the critic pass kernel, measured inside the leg)
         cfg["td3_roofline_" + k] = get(legs, "td3", "roofline", k)
     cfg["td3_update_us"] = get(legs, "td3", "roofline", "update_us")
     cfg["td3_batch100_value"] = get(legs, "td3", "reference_batch_100", "value")

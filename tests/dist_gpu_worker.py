@@ -13,7 +13,8 @@ sys.path.insert(0, ROOT)
 
 def main():
     out, fused = sys.argv[1], int(sys.argv[2])
-    pipelined = len(sys.argv) > 3 and sys.argv[3] == "pipelined"
+    pipelined = len(sys.argv) > 3 and sys.argv[3].startswith("pipelined")
+    batch = 1024 if (len(sys.argv) > 3 and sys.argv[3].endswith("_block")) else 256          # > 512: the large-batch kernels (csrc/td3_block.hip)
     from plen_ml_walk_amd import sharding
     from plen_ml_walk_amd.train_vec import setup_distributed, GraphedVecTD3Trainer, PipelinedVecTD3Trainer
     from plen_ml_walk_amd.vec_env import PlenVecEnv
@@ -28,9 +29,9 @@ def main():
     init = torch.cat([p.detach().reshape(-1) for p in list(agent.actor.parameters()) + list(agent.critic.parameters())]).clone()
     replay = ReplayBuffer(20000, device=dev)
     if pipelined:
-        tr = PipelinedVecTD3Trainer(envs, agent, replay, start_timesteps=512, batch_size=256, seed=1000 + rank)
+        tr = PipelinedVecTD3Trainer(envs, agent, replay, start_timesteps=512, batch_size=batch, seed=1000 + rank)
     else:
-        tr = GraphedVecTD3Trainer(env, agent, replay, start_timesteps=512, batch_size=256, updates_per_step=1, seed=1000 + rank, fused=bool(fused))
+        tr = GraphedVecTD3Trainer(env, agent, replay, start_timesteps=512, batch_size=batch, updates_per_step=1, seed=1000 + rank, fused=bool(fused))
     for _ in range(14 if not pipelined else 24):
         tr.step()
     if pipelined:
@@ -50,7 +51,7 @@ def main():
            "init_equal_across_ranks_after_broadcast": None,
            "moved": float((flat - init).abs().max()), "finite": bool(torch.isfinite(flat).all() and torch.isfinite(agent.last_critic_loss)),
            "rank_local_env_states_differ": bool(not torch.equal(states[0], states[1])),
-           "graphs": sorted(str(k) for k in tr._graphs)}
+           "graphs": sorted(str(k) for k in tr._graphs), "block_pass": bool(getattr(tr.fused, "_block_pass", False)) if getattr(tr, "fused", None) is not None else False}
     with open("%s.rank%d.json" % (out, rank), "w") as f:
         json.dump(res, f)
     for e in envs:

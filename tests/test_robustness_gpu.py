@@ -884,7 +884,7 @@ def test_in_kernel_philox_draws():
     assert abs(float((u[:, :-1] * u[:, 1:]).mean())) < 0.01 and abs(float((u * e).mean())) < 0.01
 
 
-@pytest.mark.parametrize("fused", [1, 0, "pipelined"])
+@pytest.mark.parametrize("fused", [1, 0, "pipelined", "pipelined_block"])
 def test_two_ranks_on_one_gpu_graph_trainer(tmp_path, fused):
     """The multi-rank path of the hipGraph trainer with REAL collectives on GPU tensors (two ranks share this box's one GPU, so gloo instead of
     RCCL): parameters start from rank 0's, the update runs as graph segments with the critic / actor bucket all-reduces between them, and after
@@ -894,12 +894,14 @@ def test_two_ranks_on_one_gpu_graph_trainer(tmp_path, fused):
     out = str(tmp_path / "d")
     env = dict(os.environ, PLEN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "tests", "dist_gpu_worker.py"), out] + (["1", "pipelined"] if fused == "pipelined" else [str(fused)])
+           os.path.join(ROOT, "tests", "dist_gpu_worker.py"), out] + (["1", fused] if str(fused).startswith("pipelined") else [str(fused)])
     subprocess.run(cmd, check=True, timeout=600, env=env, cwd=ROOT)
     r0, r1 = json.load(open(out + ".rank0.json")), json.load(open(out + ".rank1.json"))
-    steps = 24 if fused == "pipelined" else 14          # (the pipelined trainer's 6 update-graph keys need 18 steps to be captured)
+    pipe = str(fused).startswith("pipelined")
+    steps = 24 if pipe else 14          # (the pipelined trainer's 6 update-graph keys need 18 steps to be captured)
     for r in (r0, r1):
-        assert r["world"] == 2 and r["allreduce_mode"] == "eager-between-graphs" and r["grad_steps"] == steps - (2 if fused == "pipelined" else 1)
+        assert r["world"] == 2 and r["allreduce_mode"] == "eager-between-graphs" and r["grad_steps"] == steps - (2 if pipe else 1)
+        assert r["block_pass"] == (fused == "pipelined_block")       # batch 1024: the large-batch kernels, their partial gradients reduced into the bucket for the all-reduce
         assert r["env_steps"] == steps * 256
         assert r["params_equal_across_ranks"] and r["targets_equal_across_ranks"] and r["finite"] and r["moved"] > 1e-4
         assert r["rank_local_env_states_differ"]
