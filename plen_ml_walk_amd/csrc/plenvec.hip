@@ -1409,6 +1409,71 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     // multiply-adds).  Accumulated as register pairs (v_pk_fma_f32), loops over j kept rolled so that only
     // the accumulators are live.
     using vec2 = real __attribute__((ext_vector_type(2)));
+#ifndef PLENVEC_MFMA_DELASSUS
+#define PLENVEC_MFMA_DELASSUS 1          /* 1: A = Y^T Y as nine 16 x 16 tiles on the matrix cores; 0: rounds 1-4's tree-sparse build on the vector unit from broadcast LDS reads */
+#endif
+#if PLENVEC_MFMA_DELASSUS
+    // The dense product on the matrix pipe, which nothing else in this kernel uses: `v_mfma_f{32,64}_16x16x4` takes A[i][k] and B[k][j] as ONE value per lane (i or j = lane % 16,
+    // k = lane / 16), and for A = Y^T Y both operands of tile (ti, tj), k-step s are columns of the same matrix: lane l holds Y[4 s + l / 16][16 t + l % 16] for t = 0..2, s = 0..5 --
+    // 18 strided LDS reads bring the whole of Y into registers in that order (instead of ~270 wave-uniform b128 reads feeding 534 vector multiply-adds: the LDS pipe, shared by all
+    // the waves of a compute unit, is what the old build waited for on a loaded chip).  A tile row of results (rows 16 ti .. 16 ti + 15 of A, all 48 columns) is passed through LDS
+    // -- in the Y buffer itself, whose content sits in the operand registers and is written back afterwards for phase H -- as stage[column][row in tile], so that lane p reads the
+    // sixteen entries A[16 ti ..][p] = A[p][16 ti ..] of ITS row (A is symmetric) as consecutive words.  A slot lent to a box corner needs no dense special case: the product is dense.
+    using acc4 = real __attribute__((ext_vector_type(4)));
+    real Ar[NPORT];
+    real diag = 0;
+    {
+        const int c16 = lane & 15, g4 = lane >> 4;
+        real op[3][6];
+        {
+            const real *src = &s.YT[g4][c16];
+            static_for<3>([&](auto tc) { static_for<6>([&](auto sc) {
+                op[decltype(tc)::value][decltype(sc)::value] = src[4 * decltype(sc)::value * YTS + 16 * decltype(tc)::value];
+            }); });
+        }
+        WSYNC();                                             // every operand is in registers before the buffer is reused
+        constexpr int SS = sizeof(real) == 8 ? 18 : 20;      // words per staged column: 16 + pad (bank-conflict-free b64 / b128 stores and 16-byte-aligned row reads)
+        static_assert(NPORT * SS <= NV * YTS, "the staged tile row must fit the Y buffer");
+        real *stage = &s.YT[0][0];
+        static_for<3>([&](auto tic) {
+            constexpr int ti = decltype(tic)::value;
+            acc4 d[3];
+#pragma unroll
+            for (int tj = 0; tj < 3; tj++) d[tj] = (acc4){0, 0, 0, 0};
+            static_for<6>([&](auto sc) {
+                constexpr int ks = decltype(sc)::value;
+#pragma unroll
+                for (int tj = 0; tj < 3; tj++) {
+                    if constexpr (sizeof(real) == 8) d[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[ti][ks], op[tj][ks], d[tj], 0, 0, 0);
+                    else d[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(op[ti][ks], op[tj][ks], d[tj], 0, 0, 0);
+                }
+            });
+#pragma unroll
+            for (int tj = 0; tj < 3; tj++) {
+                real *col = stage + (16 * tj + c16) * SS;
+                if constexpr (sizeof(real) == 8) {           // D of the f64 form: row = lane / 16 + 4 r, column = lane % 16
+#pragma unroll
+                    for (int r = 0; r < 4; r++) col[g4 + 4 * r] = d[tj][r];
+                } else {                                     // f32 form: row = 4 (lane / 16) + r
+                    *reinterpret_cast<acc4 *>(col + 4 * g4) = d[tj];
+                }
+            }
+            WSYNC();
+            const real *rp = stage + p * SS;
+#pragma unroll
+            for (int i = 0; i < 16; i++) Ar[16 * ti + i] = rp[i];
+            const real dsel = rp[p & 15];
+            if ((p >> 4) == ti) diag = dsel;                 // A[p][p], the same sum as the row's own entry
+            WSYNC();
+        });
+        {
+            real *dst = &s.YT[g4][c16];
+            static_for<3>([&](auto tc) { static_for<6>([&](auto sc) {
+                dst[4 * decltype(sc)::value * YTS + 16 * decltype(tc)::value] = op[decltype(tc)::value][decltype(sc)::value];
+            }); });
+        }
+    }
+#else
     vec2 Ar2[NPORT / 2];
 #pragma unroll
     for (int q = 0; q < NPORT / 2; q++) Ar2[q] = (vec2){0, 0};
@@ -1488,12 +1553,17 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         }
     });
     }
+#endif
     const real EPS = sizeof(real) == 8 ? (real)2.220446049250313e-16 : (real)1.1920929e-07;
     const real jdi = diag > EPS ? rcp_(diag) : (real)0;
     if (dump) {
         if (valid_port) {
 #pragma unroll
+#if PLENVEC_MFMA_DELASSUS
+            for (int q = 0; q < NPORT; q++) dump[1216 + p * NPORT + q] = Ar[q];
+#else
             for (int q = 0; q < NPORT; q++) dump[1216 + p * NPORT + q] = Ar2[q / 2][q % 2];
+#endif
             dump[3520 + p] = s.park[0][lane];
             dump[3568 + p] = s.park[1][lane];
         }
@@ -1503,12 +1573,20 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     WSYNC();
     if (valid_port) s.lamP[p] = jdi;
     WSYNC();
+#if PLENVEC_MFMA_DELASSUS
+#pragma unroll
+    for (int q = 0; q < NPORT / 2; q++) {
+        const vec2 a2 = (vec2){Ar[2 * q], Ar[2 * q + 1]} * *reinterpret_cast<const vec2 *>(&s.lamP[2 * q]);
+        Ar[2 * q] = a2[0]; Ar[2 * q + 1] = a2[1];
+    }
+#else
     real Ar[NPORT];
 #pragma unroll
     for (int q = 0; q < NPORT / 2; q++) {
         const vec2 a2 = Ar2[q] * *reinterpret_cast<const vec2 *>(&s.lamP[2 * q]);
         Ar[2 * q] = a2[0]; Ar[2 * q + 1] = a2[1];
     }
+#endif
 
     STAMP();
     FRESH_LANE();
