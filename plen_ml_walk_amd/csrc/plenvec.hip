@@ -115,8 +115,8 @@ __device__ inline float rcp_(float x) { return 1.0f / x; }
 #else
 __device__ inline float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
 #endif
-// f64: the compiler's correctly rounded division / square root are 12 / 15 dependent instructions.  v_rcp_f64 / v_rsq_f64 + two Newton steps are 5 / 9
-// and agree with them to 0 / 1.7 ulp over 1e6 arguments spanning e^+-30 (measured on the MI355X) -- far inside what separates the kernel from the
+// f64: the compiler's correctly rounded division / square root are 12 / 15 dependent instructions.  v_rcp_f64 + two Newton steps / v_rsq_f64 + one third-order step are 5 / 6
+// and agree with them to 0 / < 2 ulp over 1e6 arguments spanning e^+-30 (measured on the MI355X, scripts/ubench/rsqrt_acc.hip) -- far inside what separates the kernel from the
 // oracle anyway (different summation orders).  PLENVEC_EXACT_MATH keeps the divisions.
 #ifdef PLENVEC_EXACT_MATH
 __device__ inline double rcp_(double x) { return 1.0 / x; }
@@ -136,10 +136,12 @@ __device__ inline float rsqrt_(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ inline double rsqrt_(double x) { return 1.0 / sqrt(x); }
 #else
 __device__ __forceinline__ double rsqrt_(double x) {
-    const double h = 0.5 * x;
-    double y = __builtin_amdgcn_rsq(x);
-    y = y * __builtin_fma(-(h * y), y, 1.5);
-    return y * __builtin_fma(-(h * y), y, 1.5);
+    // ONE third-order step on v_rsq_f64 (y0 good to 2^-23): with r = 1 - x y0^2,  x^-1/2 = y0 (1 + r/2 + 3/8 r^2 + O(r^3)), truncation 5/16 r^3 < 2^-66.  Four dependent
+    // operations behind the rsq (x y0, r, y0 r | p, fma) where two Newton steps took six: the pivots of the factorization are one chain of 24 of these.
+    // (scripts/ubench/rsqrt_acc.hip: max error against 1 / sqrt(x) in ulp.)
+    const double y0 = __builtin_amdgcn_rsq(x);
+    const double r = __builtin_fma(-(x * y0), y0, 1.0);
+    return __builtin_fma(y0 * r, __builtin_fma(r, 0.375, 0.5), y0);
 }
 #endif
 __device__ inline float sqrt_(float x) { return sqrtf(x); }
@@ -487,6 +489,49 @@ __device__ __forceinline__ void pgs_row2d(real &e, const real blo, const real bh
         }
     }
 }
+// f64, count-specialised loops: the normal row of contact point K < 2 of foot F -- the row of pgs_row2d, and behind it the row's delta is ALSO subtracted in the three torsional
+// lanes of that foot (52 + 3 F ..) from a value those lanes do not otherwise use: blo for the foot's first point, bhi for its second (both start at 0 there, like the normal lane's
+// own blo = -u_n, and see the same subtractions: bit for bit the normal lane's blo after the pass; dvec stays 0 in those lanes, so the passes' own `blo -= dvec` leave them alone).
+// The torsional bounds of every iteration need -u_n of their foot's points; rounds 1-4 fetched all four through the LDS crossbar (`ds_bpermute` pairs on the wave's dependent
+// chain, once per iteration), and the delta is in a scalar register here anyway.  Measured (scripts/gpu_ab64.py, same box): f64 +1.0 %; f32 +-0 (its normal pass grows by what
+// the bounds save: the f32 kernel issues, it does not wait), so the f32 kernel keeps the gather.
+#ifndef PLENVEC_TRACK_NORMALS
+#define PLENVEC_TRACK_NORMALS 1
+#endif
+template <bool FAST, int PP, int F, int K>
+__device__ __forceinline__ void pgs_row_normal(double &e, double &blo, double &bhi, double &dvec, const double acol, const int lane) {
+    static_assert(K == 0 || K == 1, "points 2 and 3 of a foot keep the gather");
+    if constexpr (FAST) {
+#define PLEN_F64_NORMAL_ROW(TRK_)                                                                                                          \
+        asm volatile("s_lshl_b64 exec, 1, %[pp]\n\t"                                                                                       \
+                     "v_max_f64 v[2:3], -%[e], %[lo]\n\t"                                                                                  \
+                     "v_min_f64 v[2:3], v[2:3], %[hi]\n\t"                                                                                 \
+                     "s_mov_b64 exec, -1\n\t"                                                                                              \
+                     "v_readlane_b32 s4, v2, %[pp]\n\t"                                                                                    \
+                     "v_readlane_b32 s5, v3, %[pp]\n\t"                                                                                    \
+                     "s_nop 1\n\t"                                                                                                         \
+                     "v_fmac_f64 %[e], s[4:5], %[a]\n\t"                                                                                   \
+                     "s_lshl_b64 exec, 7, %[t0]\n\t"                                                                                       \
+                     "v_add_f64 " TRK_ ", " TRK_ ", -s[4:5]\n\t"                                                                           \
+                     "s_mov_b64 exec, -1\n\t"                                                                                              \
+                     : [e] "+v"(e), "+{v[2:3]}"(dvec), [lo] "+v"(blo), [hi] "+v"(bhi)                                                       \
+                     : [a] "v"(acol), [pp] "i"(lane_of_port(PP)), [t0] "i"(52 + 3 * F)                                                      \
+                     : "s4", "s5", "scc")
+        if constexpr (K == 0) PLEN_F64_NORMAL_ROW("%[lo]"); else PLEN_F64_NORMAL_ROW("%[hi]");
+#undef PLEN_F64_NORMAL_ROW
+    } else {
+#pragma clang fp contract(off)
+        constexpr int L = lane_of_port(PP), T0 = 52 + 3 * F;
+        const double d = clamp_neg(e, blo, bhi);
+        const double db = bcast(d, L);
+        e = fma_(db, acol, e);
+        __builtin_amdgcn_sched_barrier(0);
+        dvec = wrlane_late<L>(dvec, db);
+        const bool tl = lane >= T0 && lane < T0 + 3;
+        if constexpr (K == 0) blo = tl ? blo - db : blo; else bhi = tl ? bhi - db : bhi;
+    }
+}
+
 // The 18 motor rows of one pass as ONE straight-line block (fast paths; text generated by tools/gen_motor_pass.py into plen_motor_pass_gen.h).
 // REV = false: Bullet's sorted order NC_ORDER (odd iterations), REV = true: reversed (even iterations).
 //   f64: per row  s_lshl_b64 exec, 1, lane | clamp into dvec = v[2:3] (that lane only) | s_mov_b64 exec, -1 | v_readlane pair | s_nop 1 | fmac.
@@ -581,9 +626,12 @@ __device__ __forceinline__ float quad_bcast0(float x) {
 }
 __device__ __forceinline__ double quad_bcast0(double x) { return dpp64_all<0x00 /* quad_perm:[0,0,0,0] */, false>(x); }
 
+#ifndef PLENVEC_CONE_STRAIGHT
+#define PLENVEC_CONE_STRAIGHT 1
+#endif
 template <bool FAST, int PN, typename real>
 __device__ __forceinline__ void pgs_cone(real &e, const real u, real &dvec, const real lmv, const real jdi, const real aA, const real aB,
-                                         const int lane) {
+                                         const int lane, unsigned *slide_stat = nullptr) {
 #pragma clang fp contract(off)      // same roundings in every instantiation: fused ops are written out
     constexpr int LA = lane_of_port(PN + 1), LB = lane_of_port(PN + 2);
     const real w = u - e;                           // candidate lambda * diag of this lane's row
@@ -596,6 +644,19 @@ __device__ __forceinline__ void pgs_cone(real &e, const real u, real &dvec, cons
     else {
 #ifdef PLENVEC_EXACT_MATH
         scale = len2 >= lmv * lmv ? (len2 > 0 ? lmv / sqrt_(len2) : (real)0) : (real)1;
+#elif PLENVEC_CONE_STRAIGHT
+        // f64, straight-line: a pair OUTSIDE its friction circle is the rule, not the exception (scripts/gpu_slide_stats.py: some pair slides in 95 % of the iterations of
+        // random-action rollouts and 87 % under the walking policy), so the test-and-branch of rounds 2-4 (compare, ballot, scalar AND, branch: four steps of the wave's
+        // dependent chain in front of the reciprocal square root it almost never skipped) is gone, and lm / |s| comes out of ONE third-order step on v_rsq_f64
+        // (y0 to 2^-23; with r = 1 - x y0^2:  lm y0 (1 + r (1/2 + 3/8 r)), truncation 5/16 r^3 < 2^-66) in which lm is folded: rsq, x y0 | lm y0, r, lm y0 r | p, fma = four
+        // dependent steps behind the rsq where two Newton steps and the product took seven.  min(1, t) as in the f32 path: NaN (|s| = 0: 0 * inf) gives 1.
+        {
+            const real y0 = __builtin_amdgcn_rsq(len2);
+            const real a_ = len2 * y0, ly0 = lmv * y0;
+            const real r_ = __builtin_fma(-a_, y0, (real)1);
+            const real p_ = __builtin_fma(r_, (real)0.375, (real)0.5), lr = ly0 * r_;
+            scale = min_((real)1, __builtin_fma(lr, p_, ly0));
+        }
 #else
         // f64: a correctly rounded square root and division are ~28 instructions of the ~55 this pair costs.  (1) a pair inside its friction circle
         // needs neither (scale = 1): only the pair's own two lanes decide, so one scalar test skips them; (2) a sliding pair gets
@@ -609,6 +670,9 @@ __device__ __forceinline__ void pgs_cone(real &e, const real u, real &dvec, cons
         const unsigned half = (LA & 32) ? (unsigned)(bal >> 32) : (unsigned)bal;
         unsigned any_slide;
         asm("s_and_b32 %0, %1, %2" : "=s"(any_slide) : "s"(half), "n"((1u << (LA & 31)) | (1u << (LB & 31))) : "scc");
+#ifdef PLEN_SLIDE_STATS
+        if (slide_stat && any_slide) *slide_stat |= 1u;
+#endif
         if (any_slide) {
             const real t = lmv * rsqrt_(len2);                // for every lane, so that the block is straight-line code (selects, no nested exec regions
             scale = slide ? (len2 > 0 ? t : (real)0) : (real)1;       // and the scalar registers they hold); len2 == 0 gives NaN here, discarded by the select
@@ -1661,6 +1725,9 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     const bool has_spin = P.mu_spin > 0, has_roll = P.mu_roll > 0;
     STAMP();
     int it = 0;
+#ifdef PLEN_SLIDE_STATS      // diagnostic build (scripts/gpu_slide_stats.py, f64): iterations of this substep in which some lateral pair was outside its friction circle
+    unsigned slide_now = 0, slide_prev = 0, slide_iters = 0, slide_flips = 0;
+#endif
     const int npts = __builtin_amdgcn_readfirstlane(5 * __builtin_popcount(act & 0xfu) + __builtin_popcount((act >> 4) & 0xfu));      // 5 NR + NL: a foot's occupied slots are a prefix
     PLEN_ASSERT_FULL_EXEC();
     // LSPEC >= 0: this copy of the WHOLE iteration loop is compiled for these point counts (5 NR + NL; 0 = airborne: motor rows only), so that the choice is made
@@ -1731,9 +1798,10 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             // (points out of range carry blo = bhi = 0 and mu*lambda_n = 0: their rows would be exact no-ops)
             each_point([&](auto fc_, auto kc) {
                 constexpr int PP = port_normal(4 * decltype(fc_)::value + decltype(kc)::value);
-                pgs_row2d<FAST, PP>(e, blo, bhi, dvec, Ar[PP], lane);
+                if constexpr (PLENVEC_TRACK_NORMALS && sizeof(real) == 8 && SPEC >= 0 && decltype(kc)::value < 2) pgs_row_normal<FAST, PP, decltype(fc_)::value, decltype(kc)::value>(e, blo, bhi, dvec, Ar[PP], lane);
+                else pgs_row2d<FAST, PP>(e, blo, bhi, dvec, Ar[PP], lane);
             });
-            blo -= dvec; exceed |= OVER(dvec); dvec = 0;     // bhi of a normal row is 1e30 or 0: unchanged
+            blo -= dvec; exceed |= OVER(dvec); dvec = 0;     // bhi of a normal row is 1e30 or 0: unchanged (f64: the torsional lanes carry copies of -u_n in blo / bhi, pgs_row_normal; dvec is 0 there)
             ISTAMP(2);
             // -- torsional friction: spinning rows (all points), then rolling rows (all points) --
             // Bounds of a point's three torsional rows (spin lane, two roll lanes; each lane has its own
@@ -1749,7 +1817,9 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                 // has one or two, scripts/gpu_slot_distribution_actor.py): +0.65 % (f32: -0.3 ... -0.7 %, the branch costs more than two gathers: eager there)
                 real nt10, nt11, nt12 = 0, nt13 = 0, t20, t21, t22 = 0, t23 = 0;
                 {
-                    const real nbv0 = gather_addr(blo, tors_addr), nbv1 = gather_addr(blo, tors_addr + 16);     // -u_n of point k of this lane's foot
+                    // -u_n of point k of this lane's foot: through the LDS crossbar, or (f64, count-specialised loops) kept up to date in the torsional lanes themselves by the normal rows
+                    constexpr bool TRACKED = PLENVEC_TRACK_NORMALS && sizeof(real) == 8 && SPEC >= 0;
+                    const real nbv0 = TRACKED ? blo : gather_addr(blo, tors_addr), nbv1 = TRACKED ? bhi : gather_addr(blo, tors_addr + 16);
                     const real lim0 = mul_rn_(fc0, nbv0), lim1 = mul_rn_(fc1, nbv1);
                     // bounds of point k's rows: [-(lim + u), lim - u] while its normal impulse is positive (nbv = -u_n < 0), else [0, 0].  As two fused
                     // operations on a 0/1 factor m instead of an add, a subtract, a negation and two selects each: u * m is exact, so fma(u, m, lim) rounds
@@ -1795,7 +1865,11 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                 const real lmv = quad_bcast0(mul_rn_(nfcn, blo));
                 each_point([&](auto fc_, auto kc) {
                     constexpr int PN = port_normal(4 * decltype(fc_)::value + decltype(kc)::value);
+#ifdef PLEN_SLIDE_STATS
+                    pgs_cone<FAST, PN>(e, u0, dvec, lmv, jdi, Ar[PN + 1], Ar[PN + 2], lane, &slide_now);
+#else
                     pgs_cone<FAST, PN>(e, u0, dvec, lmv, jdi, Ar[PN + 1], Ar[PN + 2], lane);
+#endif
                 });
             }
             // Bullet's residual of a pair is |dA + dB|: after the pass every pair's deltas sit in its two lanes of dvec,
@@ -1826,6 +1900,9 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         ISTAMP(7);
         // (the rare scalar rows, joint limits, keep their max in res_i)
         const bool stop = (res_i <= thr_i && exceed == 0) || it >= n_iter - 1;
+#ifdef PLEN_SLIDE_STATS
+        slide_iters += slide_now; slide_flips += (slide_now != slide_prev && it > 0) ? 1u : 0u; slide_prev = slide_now; slide_now = 0;
+#endif
         it++;
         return stop;
 #undef OVER
@@ -1882,6 +1959,9 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     solve_loop(std::integral_constant<int, LOOP_GENERIC>{});
 #endif
     iters = it;
+#ifdef PLEN_SLIDE_STATS
+    if (dump && lane == 0) { dump[3702] = (real)slide_iters; dump[3703] = (real)slide_flips; }
+#endif
     // issue-slot estimate of this substep (setup + iterations x (motor pass + rows of the active contact points)), for the placement
     // of the env in the NEXT launch (plen_balance_kernel)
     load += P.cost_setup + it * (P.cost_it0 + P.cost_pt * __builtin_popcount(act) + (act ? P.cost_act : 0));
