@@ -213,7 +213,13 @@ static __device__ __forceinline__ floatx4 blk_split_sum(const float *park, int t
 
 // ---- weight packing: M (N x K; element (i, k) at src[i rs + k cs]) -> MFMA A-operand order, zero-padded to 16-row tiles and 16-k steps:
 //      dst float4 ((t KS + s) 64 + lane) = M[16 t + (lane % 16)][16 s + 4 (lane / 16) + (0..3)]
+// Issue priority of the update's waves (s_setprio 0..3; env waves run at 0): an experiment knob, -DBLK_PRIO=n.  The update shares every SIMD with resident env waves.
+#ifndef BLK_PRIO
+#define BLK_PRIO 0
+#endif
+#define BLK_SETPRIO() do { if (BLK_PRIO) __builtin_amdgcn_s_setprio(BLK_PRIO); } while (0)
 __global__ __launch_bounds__(256) void k_pack(PlenTd3PackGroup G) {
+    BLK_SETPRIO();
     const int e = blockIdx.x * 256 + threadIdx.x;
     int j = 0;
 #pragma unroll
@@ -235,6 +241,7 @@ __global__ __launch_bounds__(256) void k_pack(PlenTd3PackGroup G) {
 //      beside env launches that hold every wave slot of the chip (train_vec.PipelinedVecTD3Trainer), and a workgroup that needs more waits for more to retire.
 //      Hence two 256-wide activation buffers only: the twin critics go through them one after the other.
 __global__ __launch_bounds__(64 * BLK_NW) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_critic_block(PlenTd3CriticBlock P) {
+    BLK_SETPRIO();
     const PlenTd3CriticRows &A = P.rows;
     __shared__ __attribute__((aligned(16))) float Rb[BLK_R * BLK_LD_ROW];
     __shared__ __attribute__((aligned(16))) float Ub[BLK_R * BLK_LD_W];
@@ -509,6 +516,7 @@ static __device__ __forceinline__ void blk_back_mask(const BlkPre<4> &pre, rsrc_
     }
 }
 __global__ __launch_bounds__(64 * BLK_NW) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_policy_block(PlenTd3PolicyBlock P) {
+    BLK_SETPRIO();
     const PlenTd3PolicyRows &A = P.rows;
     __shared__ __attribute__((aligned(16))) float Sb[BLK_R * PB_LD_SA];
     __shared__ __attribute__((aligned(16))) float Zb[BLK_R * PB_LD_DZ];
@@ -656,6 +664,7 @@ __global__ __launch_bounds__(64 * BLK_NW) __attribute__((amdgpu_waves_per_eu(4, 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 #define WGB_NW 4
 __global__ __launch_bounds__(64 * WGB_NW) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_wgrad_big(PlenTd3WgradBig G) {
+    BLK_SETPRIO();
     __shared__ float red[WGB_NW - 1][64][33];             // the partial tiles of waves 1..3 (33: the lanes' rows fall on different banks)
     int j = 0;
 #pragma unroll
@@ -786,6 +795,7 @@ __global__ __launch_bounds__(64 * WGB_NW) __attribute__((amdgpu_waves_per_eu(4, 
 __global__ __launch_bounds__(256) void k_adam_big(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, float *step, int *done_count, int n,
                                                   double lr, double b1d, double b2d, float eps, float *__restrict__ target, float tau, float *__restrict__ copy_out,
                                                   const float *__restrict__ partial, int chunks, int stride, int reduce_only) {
+    BLK_SETPRIO();
     const float t = reduce_only ? 1.f : step[0] + 1.f;
     const AdamCoef c = adam_coef(t, lr, b1d, b2d, eps, tau);
     typedef float f4 __attribute__((ext_vector_type(4)));

@@ -14,7 +14,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libplentd3.so")
+LIB_PATH = os.environ.get("PLENTD3_LIB") or os.path.join(_HERE, "csrc", "libplentd3.so")          # (PLENTD3_LIB: an A/B build, scripts/ only)
 EXPORTS = ["plentd3_gather", "plentd3_sample_gather", "plentd3_explore", "plentd3_uniform_actions", "plentd3_store", "plentd3_store_advance", "plentd3_target_action", "plentd3_q_heads", "plentd3_dh2", "plentd3_relu_mask", "plentd3_colsum", "plentd3_wgrad",
            "plentd3_tanh_out", "plentd3_dtanh", "plentd3_bias_relu", "plentd3_polyak", "plentd3_adam", "plentd3_critic_rows", "plentd3_policy_rows", "plentd3_actor_rows", "plentd3_critic_team", "plentd3_policy_team",
            "plentd3_wgrad_group", "plentd3_wgrad_adam_group", "plentd3_pack", "plentd3_critic_block", "plentd3_policy_block", "plentd3_wgrad_big", "plentd3_adam_big", "plentd3_actor_block", "plentd3_dev_mfma_spin", "plentd3_stamp", "plentd3_version"]

@@ -10,7 +10,7 @@ from plen_ml_walk_amd.td3 import ReplayBuffer, TD3Agent
 from plen_ml_walk_amd.train_vec import PipelinedVecTD3Trainer
 dev = torch.device("cuda", 0)
 out = {}
-for learning in (True, False):
+for learning in ((True,) if os.environ.get("ONLY_LEARNING") == "1" else (True, False)):
     n, H = 4096, 2
     torch.manual_seed(0)
     agent = TD3Agent(26, 18, 1.0, device=dev)
@@ -32,4 +32,5 @@ for learning in (True, False):
     for e in envs:
         e.close()
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r05_td3_collectors_only.json"), "w"), indent=1)
+if os.environ.get("ONLY_LEARNING") != "1":
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r05_td3_collectors_only.json"), "w"), indent=1)
