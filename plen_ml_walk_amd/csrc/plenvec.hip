@@ -392,6 +392,20 @@ __host__ __device__ constexpr int lane_of_port(int p) {
     return 20 + 4 * (4 * f + (l - 3) / 3) + (l - 3) % 3;
 }
 #define LANE_NORMAL0 20          /* lane of the normal port of point 0; point c: + 4c */
+// Y = L^-T J^T in 16-port x 4-coordinate pieces (the matrix-core operands of the Delassus build): is piece (port tile t, coordinate step s) structurally zero?
+// ports 0..15: every limb's joints -> nothing; 16..31: joints 16, 17 (left arm: base + coordinates 21..23) and the right foot (base + 6..11) -> coordinates 12..19;
+// 32..47: port 32 (right foot) and the left foot (base + 12..17) -> coordinates 20..23.  static_asserts below tie this to the model's supports.
+__host__ __device__ constexpr bool y_tile_zero(int t, int s) { return (t == 1 && (s == 3 || s == 4)) || (t == 2 && s == 5); }
+static constexpr unsigned port_support(int p) { return p < 18 ? ANC[6 + p] : ANC[5 + (p < 33 ? GEN_RFOOT_BODY : GEN_LFOOT_BODY)]; }      // coordinates that can move port p (no slot lent)
+static constexpr bool y_tile_zero_is_sound() {
+    for (int t = 0; t < 3; t++)
+        for (int s_ = 0; s_ < 6; s_++)
+            if (y_tile_zero(t, s_))
+                for (int p = 16 * t; p < 16 * t + 16; p++)
+                    if (port_support(p) & (0xfu << (4 * s_))) return false;
+    return true;
+}
+static_assert(y_tile_zero_is_sound(), "y_tile_zero() names a piece of Y that the model's kinematic tree can fill");
 
 __device__ __forceinline__ unsigned absbits(float x) { return __builtin_bit_cast(unsigned, x) & 0x7fffffffu; }
 __device__ __forceinline__ unsigned absbits(double x) { return __builtin_bit_cast(unsigned, (float)x) & 0x7fffffffu; }
@@ -1504,14 +1518,23 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             acc4 d[3];
 #pragma unroll
             for (int tj = 0; tj < 3; tj++) d[tj] = (acc4){0, 0, 0, 0};
-            static_for<6>([&](auto sc) {
-                constexpr int ks = decltype(sc)::value;
-#pragma unroll
-                for (int tj = 0; tj < 3; tj++) {
-                    if constexpr (sizeof(real) == 8) d[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[ti][ks], op[tj][ks], d[tj], 0, 0, 0);
-                    else d[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(op[ti][ks], op[tj][ks], d[tj], 0, 0, 0);
-                }
-            });
+            // Tree sparsity at tile granularity: ports 16..31 (the left arm's last two joints, the right foot) are not supported by coordinates 12..19, ports 32..47 (the right
+            // foot's last port, the left foot) not by 20..23 -- those operand registers are all zeros, their products exact no-ops: 39 instead of 54 matrix instructions
+            // (a slot lent to a box corner breaks the pattern: every product then; `lent` is wave-uniform).
+            auto products = [&](auto dense_c) {
+                static_for<6>([&](auto sc) {
+                    constexpr int ks = decltype(sc)::value;
+                    static_for<3>([&](auto tjc) {
+                        constexpr int tj = decltype(tjc)::value;
+                        constexpr bool zero = y_tile_zero(ti, ks) || y_tile_zero(tj, ks);
+                        if constexpr (decltype(dense_c)::value || !zero) {
+                            if constexpr (sizeof(real) == 8) d[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[ti][ks], op[tj][ks], d[tj], 0, 0, 0);
+                            else d[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(op[ti][ks], op[tj][ks], d[tj], 0, 0, 0);
+                        }
+                    });
+                });
+            };
+            if (__builtin_expect(lent != 0, 0)) products(std::true_type{}); else products(std::false_type{});
 #pragma unroll
             for (int tj = 0; tj < 3; tj++) {
                 real *col = stage + (16 * tj + c16) * SS;

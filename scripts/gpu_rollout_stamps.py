@@ -34,6 +34,13 @@ ph = np.diff(d[:, 3800:3811].double().cpu().numpy(), axis=1)
 names = ["kinematics", "body_dyn+subtree", "S,M,tau", "cholesky", "v* solve", "collision+J+Y", "A build", "rows setup", "PGS+apply", "integrate"]
 print("%s, %s actions: mean contact points %.2f; substep total %.0f cycles (mean over envs), slowest env %.0f" % (dt, what, npt.mean(), ph.sum(1).mean(), ph.sum(1).max()))
 for k, nme in enumerate(names): print("   %-18s %8.0f  %5.1f %%" % (nme, ph[:, k].mean(), 100 * ph[:, k].mean() / ph.sum(1).mean()))
+es = np.diff(d[:, 3850:3857].double().cpu().numpy(), axis=1)
+print("inside collision+J+Y (mean over envs):")
+for k, nme in enumerate(["foot manifolds", "foot Jacobians", "box near test (+ rare path)", "J rows -> regs", "port velocities", "back subst + store"]): print("   %-28s %8.0f" % (nme, es[:, k].mean()))
+lent = (aux[:, 7] & 0xff) != 0
+print("   envs with a contact slot lent to a box corner: %.1f %%; their box section %.0f cycles, the others' %.0f" % (100 * lent.mean(), es[lent, 2].mean() if lent.any() else 0, es[~lent, 2].mean()))
+its = d[:, 3700].cpu().numpy()
+print("solver iterations per substep: mean %.1f, %.1f %% run all %d" % (its.mean(), 100 * (its >= its.max()).mean(), its.max()))
 sec = ["motors(+limits)", "normals", "tors bounds", "spin rows", "roll rows", "cone pairs", "wave max"]
 tot = np.zeros((n, 7))
 for itn in (3, 4):
