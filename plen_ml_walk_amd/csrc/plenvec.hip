@@ -392,6 +392,14 @@ __host__ __device__ constexpr int lane_of_port(int p) {
     return 20 + 4 * (4 * f + (l - 3) / 3) + (l - 3) % 3;
 }
 #define LANE_NORMAL0 20          /* lane of the normal port of point 0; point c: + 4c */
+// lanes of the normal rows / of the first row of every lateral pair of a copy with NR right-foot and NL left-foot points (a foot's points are its first slots)
+__host__ __device__ constexpr unsigned long long normal_lanes(int nr, int nl) {
+    unsigned long long m = 0;
+    for (int k = 0; k < nr; k++) m |= 1ull << lane_of_port(port_normal(k));
+    for (int k = 0; k < nl; k++) m |= 1ull << lane_of_port(port_normal(4 + k));
+    return m;
+}
+__host__ __device__ constexpr unsigned long long lateral_a_lanes(int nr, int nl) { return normal_lanes(nr, nl) << 1; }
 // Y = L^-T J^T in 16-port x 4-coordinate pieces (the matrix-core operands of the Delassus build): is piece (port tile t, coordinate step s) structurally zero?
 // ports 0..15: every limb's joints -> nothing; 16..31: joints 16, 17 (left arm: base + coordinates 21..23) and the right foot (base + 6..11) -> coordinates 12..19;
 // 32..47: port 32 (right foot) and the left foot (base + 12..17) -> coordinates 20..23.  static_asserts below tie this to the model's supports.
@@ -427,6 +435,20 @@ __device__ __forceinline__ unsigned absbits(double x) { return __builtin_bit_cas
                  : [e] "+v"(e), "+{" DV_ "}"(dvec)                                                                                        \
                  : [lo] "v"(lo), [hi] "v"(hi), [a] "v"(acol), [pp] "i"(L)                                                                 \
                  : "s4", "s5", "scc")
+// the normal row of an occupied slot (f64, count-specialised loops): no upper clamp (pgs_row_normal says why)
+template <int L>
+__device__ __forceinline__ void f64_row_asm_lower(double &e, const double lo, double &dvec, const double acol) {
+    asm volatile("s_lshl_b64 exec, 1, %[pp]\n\t"
+                 "v_max_f64 v[2:3], -%[e], %[lo]\n\t"
+                 "s_mov_b64 exec, -1\n\t"
+                 "v_readlane_b32 s4, v2, %[pp]\n\t"
+                 "v_readlane_b32 s5, v3, %[pp]\n\t"
+                 "s_nop 1\n\t"
+                 "v_fmac_f64 %[e], s[4:5], %[a]\n\t"
+                 : [e] "+v"(e), "+{v[2:3]}"(dvec)
+                 : [lo] "v"(lo), [a] "v"(acol), [pp] "i"(L)
+                 : "s4", "s5", "scc");
+}
 template <int L, bool NEGLO = false, int DVR = 0>
 __device__ __forceinline__ void f64_row_asm(double &e, const double lo, const double hi, double &dvec, const double acol) {
     // NEGLO: the lower bound arrives as its negative (torsional rows: -(lim + u) kept as lim + u): a source modifier instead of an instruction
@@ -506,6 +528,8 @@ __device__ __forceinline__ void pgs_row2d(real &e, const real blo, const real bh
 // f64, count-specialised loops: the normal row of contact point K < 2 of foot F -- the row of pgs_row2d, and behind it the row's delta is ALSO subtracted in the three torsional
 // lanes of that foot (52 + 3 F ..) from a value those lanes do not otherwise use: blo for the foot's first point, bhi for its second (both start at 0 there, like the normal lane's
 // own blo = -u_n, and see the same subtractions: bit for bit the normal lane's blo after the pass; dvec stays 0 in those lanes, so the passes' own `blo -= dvec` leave them alone).
+// The row has no upper clamp: an occupied slot's normal impulse is bounded by 1e30 above (`bhi`, never reached: min(x, 1e30) = x for every finite x and max() has already
+// dropped a NaN), and the count-specialised loops run the rows of occupied slots only -- four vector instructions instead of five.
 // The torsional bounds of every iteration need -u_n of their foot's points; rounds 1-4 fetched all four through the LDS crossbar (`ds_bpermute` pairs on the wave's dependent
 // chain, once per iteration), and the delta is in a scalar register here anyway.  Measured (scripts/gpu_ab64.py, same box): f64 +1.0 %; f32 +-0 (its normal pass grows by what
 // the bounds save: the f32 kernel issues, it does not wait), so the f32 kernel keeps the gather.
@@ -519,7 +543,6 @@ __device__ __forceinline__ void pgs_row_normal(double &e, double &blo, double &b
 #define PLEN_F64_NORMAL_ROW(TRK_)                                                                                                          \
         asm volatile("s_lshl_b64 exec, 1, %[pp]\n\t"                                                                                       \
                      "v_max_f64 v[2:3], -%[e], %[lo]\n\t"                                                                                  \
-                     "v_min_f64 v[2:3], v[2:3], %[hi]\n\t"                                                                                 \
                      "s_mov_b64 exec, -1\n\t"                                                                                              \
                      "v_readlane_b32 s4, v2, %[pp]\n\t"                                                                                    \
                      "v_readlane_b32 s5, v3, %[pp]\n\t"                                                                                    \
@@ -536,7 +559,7 @@ __device__ __forceinline__ void pgs_row_normal(double &e, double &blo, double &b
     } else {
 #pragma clang fp contract(off)
         constexpr int L = lane_of_port(PP), T0 = 52 + 3 * F;
-        const double d = clamp_neg(e, blo, bhi);
+        const double d = max_(-e, blo);
         const double db = bcast(d, L);
         e = fma_(db, acol, e);
         __builtin_amdgcn_sched_barrier(0);
@@ -1774,6 +1797,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
 #define PLENVEC_UNROLL_PARITY 0          /* measured and left off: 1 = the loop body once per iteration parity (even: reversed non-contact rows, odd: sorted order), no parity test: +0.8 % (f64 and f32) for +400 KB of code */
 #endif
     // one solver iteration; ODD: compile-time parity (PLENVEC_UNROLL_PARITY) or -1 = tested at run time.  Returns Bullet's exit condition; advances `it`.
+    real dv0 = 0, dv1 = 0, dv2 = 0, dv3 = 0;          // the torsional rows' deltas of a foot's point k (deferred commit, like dvec)
     auto iteration = [&](auto odd_c) -> bool {
         constexpr int ODD = decltype(odd_c)::value;
         res_i = 0;
@@ -1784,9 +1808,17 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         unsigned long long exceed = 0;
 #define OVER(x_) __ballot((float)abs_(x_) > thr_f)
         // -- non-contact rows: sorted order (motors, then limits) on odd iterations, reversed on even ones --
+        // HOISTED (this whole loop is compiled for known point counts): the per-pass delta vectors are never zeroed inside the loop -- the lanes a copy's rows write are the
+        // same in every iteration and are rewritten before each commit, every other lane was zero at loop entry and stays so -- and the residual tests mask the ballot with the
+        // constant set of lanes the pass owns (a lane may still hold ANOTHER pass's delta of the previous iteration).  The motor rows' commit rides on the normal rows'
+        // (disjoint lanes of the same vector; nothing between the two passes reads the motor lanes' bounds).  Same operations on the same values as the generic loop,
+        // which commits and zeroes after every pass: 20-25 vector instructions fewer per iteration (f64), 12-15 (f32).
+        constexpr bool HOISTED = LSPEC != LOOP_GENERIC;
+        constexpr int HCNT = HOISTED ? LSPEC % 100 : 0;
+        constexpr unsigned long long MOTOR_LANES = (1ull << ND) - 1ull;
         if (ODD < 0 ? (it & 1) != 0 : ODD == 1) {
             pgs_motor_pass<FAST, false>(e, blo, bhi, dvec, Ar, lane);
-            blo -= dvec; bhi -= dvec; exceed |= OVER(dvec); dvec = 0;
+            if constexpr (!HOISTED) { blo -= dvec; bhi -= dvec; exceed |= OVER(dvec); dvec = 0; }
             if (LIM_ROWS && __builtin_expect(lim_mask != 0, 0)) {      // rare: kept out of the hot loop's instruction stream
                 static_for<ND>([&](auto ic) {
                     constexpr int PP = NC_ORDER[decltype(ic)::value];
@@ -1801,8 +1833,9 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                 });
             }
             pgs_motor_pass<FAST, true>(e, blo, bhi, dvec, Ar, lane);
-            blo -= dvec; bhi -= dvec; exceed |= OVER(dvec); dvec = 0;
+            if constexpr (!HOISTED) { blo -= dvec; bhi -= dvec; exceed |= OVER(dvec); dvec = 0; }
         }
+        if constexpr (HOISTED && HCNT == 0) { blo -= dvec; bhi -= dvec; exceed |= OVER(dvec); }        // airborne copy: only the motor lanes of dvec are ever written
         ISTAMP(1);
         if (LSPEC == LOOP_GENERIC ? act != 0u : (LSPEC % 100) > 0) {     // airborne: one branch skips every contact row
             // One copy of the contact section per set of touching feet (right, left, both), chosen here once per iteration: inside a copy
@@ -1822,9 +1855,16 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             each_point([&](auto fc_, auto kc) {
                 constexpr int PP = port_normal(4 * decltype(fc_)::value + decltype(kc)::value);
                 if constexpr (PLENVEC_TRACK_NORMALS && sizeof(real) == 8 && SPEC >= 0 && decltype(kc)::value < 2) pgs_row_normal<FAST, PP, decltype(fc_)::value, decltype(kc)::value>(e, blo, bhi, dvec, Ar[PP], lane);
+                else if constexpr (PLENVEC_TRACK_NORMALS && sizeof(real) == 8 && SPEC >= 0 && FAST) f64_row_asm_lower<lane_of_port(PP)>(e, blo, dvec, Ar[PP]);
                 else pgs_row2d<FAST, PP>(e, blo, bhi, dvec, Ar[PP], lane);
             });
-            blo -= dvec; exceed |= OVER(dvec); dvec = 0;     // bhi of a normal row is 1e30 or 0: unchanged (f64: the torsional lanes carry copies of -u_n in blo / bhi, pgs_row_normal; dvec is 0 there)
+            if constexpr (HOISTED) {
+                // motor and normal lanes together; bhi of an occupied normal lane is 1e30 (1e30 - d = 1e30), the lateral lanes' bounds are never read
+                blo -= dvec; bhi -= dvec; exceed |= OVER(dvec) & (MOTOR_LANES | normal_lanes(NR, NL));
+            } else {
+                blo -= dvec; exceed |= OVER(dvec); dvec = 0;     // bhi of a normal row is 1e30 or 0: unchanged
+            }
+            // (f64, count-specialised loops: the torsional lanes carry copies of -u_n in blo / bhi, pgs_row_normal; dvec is 0 there)
             ISTAMP(2);
             // -- torsional friction: spinning rows (all points), then rolling rows (all points) --
             // Bounds of a point's three torsional rows (spin lane, two roll lanes; each lane has its own
@@ -1838,28 +1878,42 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             if (SPEC >= 0 || has_spin || has_roll) {
                 // f64: the bounds of a foot's third and fourth point only when some foot has a third point (a foot's points are a prefix; in use a touching foot
                 // has one or two, scripts/gpu_slot_distribution_actor.py): +0.65 % (f32: -0.3 ... -0.7 %, the branch costs more than two gathers: eager there)
-                real nt10, nt11, nt12 = 0, nt13 = 0, t20, t21, t22 = 0, t23 = 0;
+                // KMAX: the bounds, deltas and commits of point k exist only where some foot has a point k (count-specialised copies)
+                constexpr int KMAX = SPEC >= 0 ? (NR > NL ? NR : NL) : 4;
+                real nt10 = 0, nt11 = 0, nt12 = 0, nt13 = 0, t20 = 0, t21 = 0, t22 = 0, t23 = 0;
                 {
                     // -u_n of point k of this lane's foot: through the LDS crossbar, or (f64, count-specialised loops) kept up to date in the torsional lanes themselves by the normal rows
                     constexpr bool TRACKED = PLENVEC_TRACK_NORMALS && sizeof(real) == 8 && SPEC >= 0;
-                    const real nbv0 = TRACKED ? blo : gather_addr(blo, tors_addr), nbv1 = TRACKED ? bhi : gather_addr(blo, tors_addr + 16);
-                    const real lim0 = mul_rn_(fc0, nbv0), lim1 = mul_rn_(fc1, nbv1);
                     // bounds of point k's rows: [-(lim + u), lim - u] while its normal impulse is positive (nbv = -u_n < 0), else [0, 0].  As two fused
                     // operations on a 0/1 factor m instead of an add, a subtract, a negation and two selects each: u * m is exact, so fma(u, m, lim) rounds
                     // exactly like lim + u; with m = 0 it leaves lim = fc * 0 = +-0, the empty interval.  pt1 is the NEGATED lower bound (the rows negate it
                     // with a source modifier).  f64: 32 -> 16 vector instructions per iteration.
-                    const real m0 = nbv0 < 0 ? (real)1 : (real)0, m1 = nbv1 < 0 ? (real)1 : (real)0;
-                    nt10 = fma_(u0, m0, lim0); nt11 = fma_(u1, m1, lim1);
-                    t20 = fma_(-u0, m0, lim0); t21 = fma_(-u1, m1, lim1);
+                    const real nbv0 = TRACKED ? blo : gather_addr(blo, tors_addr);
+                    const real lim0 = mul_rn_(fc0, nbv0);
+                    const real m0 = nbv0 < 0 ? (real)1 : (real)0;
+                    nt10 = fma_(u0, m0, lim0); t20 = fma_(-u0, m0, lim0);
+                    if constexpr (KMAX > 1) {
+                        const real nbv1 = TRACKED ? bhi : gather_addr(blo, tors_addr + 16);
+                        const real lim1 = mul_rn_(fc1, nbv1);
+                        const real m1 = nbv1 < 0 ? (real)1 : (real)0;
+                        nt11 = fma_(u1, m1, lim1); t21 = fma_(-u1, m1, lim1);
+                    }
                 }
-                if ((SPEC >= 0 && (NR > 2 || NL > 2)) || (SPEC < 0 && (sizeof(real) == 4 || (act & 0xccu)))) {
-                    const real nbv2 = gather_addr(blo, tors_addr + 32), nbv3 = gather_addr(blo, tors_addr + 48);
-                    const real lim2 = mul_rn_(fc2, nbv2), lim3 = mul_rn_(fc3, nbv3);
-                    const real m2 = nbv2 < 0 ? (real)1 : (real)0, m3 = nbv3 < 0 ? (real)1 : (real)0;
-                    nt12 = fma_(u2, m2, lim2); nt13 = fma_(u3, m3, lim3);
-                    t22 = fma_(-u2, m2, lim2); t23 = fma_(-u3, m3, lim3);
+                // f64: the bounds of a foot's third and fourth point only when some foot has a third point (a foot's points are a prefix; in use a touching foot
+                // has one or two, scripts/gpu_slot_distribution_actor.py): +0.65 % (f32: -0.3 ... -0.7 %, the branch costs more than two gathers: eager there)
+                if ((SPEC >= 0 && KMAX > 2) || (SPEC < 0 && (sizeof(real) == 4 || (act & 0xccu)))) {
+                    const real nbv2 = gather_addr(blo, tors_addr + 32);
+                    const real lim2 = mul_rn_(fc2, nbv2);
+                    const real m2 = nbv2 < 0 ? (real)1 : (real)0;
+                    nt12 = fma_(u2, m2, lim2); t22 = fma_(-u2, m2, lim2);
+                    if constexpr (KMAX > 3) {
+                        const real nbv3 = gather_addr(blo, tors_addr + 48);
+                        const real lim3 = mul_rn_(fc3, nbv3);
+                        const real m3 = nbv3 < 0 ? (real)1 : (real)0;
+                        nt13 = fma_(u3, m3, lim3); t23 = fma_(-u3, m3, lim3);
+                    }
                 }
-                real dv0 = 0, dv1 = 0, dv2 = 0, dv3 = 0;
+                if constexpr (!HOISTED) { dv0 = 0; dv1 = 0; dv2 = 0; dv3 = 0; }
                 ISTAMP(3);
                 if (SPEC >= 0 || has_spin) {
                     each_point([&](auto fc_, auto kc) {
@@ -1878,8 +1932,15 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                                                 k == 0 ? dv0 : k == 1 ? dv1 : k == 2 ? dv2 : dv3, Ar[PP + 2], lane);
                     });
                 }
-                u0 += dv0; u1 += dv1; u2 += dv2; u3 += dv3;
-                exceed |= OVER(absmax4(dv0, dv1, dv2, dv3));
+                // (dv_k is written in the torsional lanes of the feet that have a point k and nowhere else: no lane mask on its residual test)
+                u0 += dv0;
+                if constexpr (KMAX > 1) u1 += dv1;
+                if constexpr (KMAX > 2) u2 += dv2;
+                if constexpr (KMAX > 3) u3 += dv3;
+                if constexpr (KMAX == 1) exceed |= OVER(dv0);
+                else if constexpr (KMAX == 2) exceed |= OVER(max_(abs_(dv0), abs_(dv1)));
+                else if constexpr (KMAX == 3) exceed |= OVER(max_(max_(abs_(dv0), abs_(dv1)), abs_(dv2)));
+                else exceed |= OVER(absmax4(dv0, dv1, dv2, dv3));
             }
             ISTAMP(5);
             // -- lateral friction, cone-coupled pairs --
@@ -1897,8 +1958,13 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             }
             // Bullet's residual of a pair is |dA + dB|: after the pass every pair's deltas sit in its two lanes of dvec,
             // so one DPP add forms all the sums at once in the A lanes (instead of two VALU ops per pair)
-            exceed |= OVER((dvec + shift_down1(dvec)) * selA);
-            u0 += dvec; dvec = 0;
+            if constexpr (HOISTED) {
+                exceed |= OVER(dvec + shift_down1(dvec)) & lateral_a_lanes(NR, NL);     // (the first lane of every pair the copy owns; motor and normal lanes of dvec hold this iteration's deltas)
+                u0 += dvec;                                                            // u0 means something in the torsional and lateral lanes only
+            } else {
+                exceed |= OVER((dvec + shift_down1(dvec)) * selA);
+                u0 += dvec; dvec = 0;
+            }
                     };
 #if PLENVEC_COUNT_SPECIALISED
             // one copy per (points of the right foot, points of the left foot), chosen by a binary search on the scalar unit (<= 5 compares) instead of
