@@ -106,6 +106,9 @@ __device__ __constant__ double c_range_hi[ND] = {1.57, 1.5, 0.75, 0.3, 1.2, 0.4,
 // 18 limit constraints follow in the same DoF order.
 #define NC_ORDER_LIST 6, 5, 8, 7, 4, 1, 0, 3, 2, 15, 14, 17, 16, 13, 10, 9, 12, 11
 
+#ifndef PLENVEC_MFMA_MASS
+#define PLENVEC_MFMA_MASS 1          /* 1: the mass matrix M = S (I S)^T as three 16 x 16 tiles on the matrix cores; 0: rounds 1-4's per-lane column from 72 broadcast LDS reads */
+#endif
 // ---------------------------------------------------------------- math wrappers
 // f32: 1-ulp hardware reciprocal / reciprocal square root where a correctly rounded division is not part of the contract
 // PLENVEC_EXACT_MATH (experiment build, scripts/gpu_f32_exact_math.py): correctly rounded division / square root and libm sine / cosine in
@@ -1191,6 +1194,12 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         cross3(t1, &Sk[0], mc);
 #pragma unroll
         for (int i = 0; i < 3; i++) f[i] = cm * Sk[3 + i] + t1[i];
+#if PLENVEC_MFMA_MASS
+        // M = S (I S)^T on the matrix cores (below, outside this branch): this lane's column of I S -- n | f -- goes to LDS next to S, in the M buffer (free until the results land)
+        real *nf_row = &s.M[0][0] + 8 * k;
+#pragma unroll
+        for (int i = 0; i < 3; i++) { nf_row[i] = n[i]; nf_row[3 + i] = f[i]; }
+#else
         // lane k writes its whole column: M[r][k] for the supporting DoFs r <= k, zero elsewhere (so the lower triangle ends up
         // zero: phase C factors the upper triangle in place, rows = lanes).  The keep/zero decision is a sign-extended bit of one
         // per-lane mask ANDed onto the value: no compares, no predicated stores.
@@ -1200,6 +1209,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             const real val = s.S[r][0] * n[0] + s.S[r][1] * n[1] + s.S[r][2] * n[2] + s.S[r][3] * f[0] + s.S[r][4] * f[1] + s.S[r][5] * f[2];
             s.M[r][k] = keep_if(val, keep, r);
         }
+#endif
         // generalized bias force (motors are constraints, so no joint torque here)
         real tau;
         if (k < 3) tau = -s.I[0][13 + k];
@@ -1213,6 +1223,57 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         s.tau[k] = tau;
     }
     WSYNC();
+#if PLENVEC_MFMA_MASS
+    {
+        // M[r][k] = S_r . (I S)_k, a 24 x 6 by 6 x 24 product: both factors are "one row of six per DoF" in LDS, so lane l takes X[16 t + l % 16][4 s + l / 16] of either as
+        // its operand of tile t, step s (rows >= 24 and columns 6, 7 read as zero): 8 strided reads, 6 matrix instructions for the three tiles of the upper triangle, and the
+        // results go straight to M (a D register holds rows 16 tr + l / 16 + 4 j (f64) or 16 tr + 4 (l / 16) + j (f32) of column 16 tc + l % 16) under the support mask of their
+        // column -- where rounds 1-4 had every lane read all of S as 72 wave-wide broadcasts for 144 multiply-adds.  The matrix instruction adds i = 0..5 in order, like the old sum.
+        using acc4 = real __attribute__((ext_vector_type(4)));
+        const int c16 = lane & 15, g4 = lane >> 4;
+        const real *nfb = &s.M[0][0];
+        real oS[2][2], oN[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+                const int r = 16 * t + c16, i = 4 * st + g4;
+                const bool ok = r < NV && i < 6;
+                const int at = ok ? 8 * r + i : 0;
+                const real a_ = (&s.S[0][0])[at], b_ = nfb[at];
+                oS[t][st] = ok ? a_ : (real)0; oN[t][st] = ok ? b_ : (real)0;
+            }
+        WSYNC();                  // every operand is in registers before M is overwritten
+        acc4 d00 = {0, 0, 0, 0}, d01 = {0, 0, 0, 0}, d11 = {0, 0, 0, 0};
+#pragma unroll
+        for (int st = 0; st < 2; st++) {
+            if constexpr (sizeof(real) == 8) {
+                d00 = __builtin_amdgcn_mfma_f64_16x16x4f64(oS[0][st], oN[0][st], d00, 0, 0, 0);
+                d01 = __builtin_amdgcn_mfma_f64_16x16x4f64(oS[0][st], oN[1][st], d01, 0, 0, 0);
+                d11 = __builtin_amdgcn_mfma_f64_16x16x4f64(oS[1][st], oN[1][st], d11, 0, 0, 0);
+            } else {
+                d00 = __builtin_amdgcn_mfma_f32_16x16x4f32(oS[0][st], oN[0][st], d00, 0, 0, 0);
+                d01 = __builtin_amdgcn_mfma_f32_16x16x4f32(oS[0][st], oN[1][st], d01, 0, 0, 0);
+                d11 = __builtin_amdgcn_mfma_f32_16x16x4f32(oS[1][st], oN[1][st], d11, 0, 0, 0);
+            }
+        }
+        // column masks: M[r][k] is kept for the DoFs r <= k that support k, +0 elsewhere (phase C factors the upper triangle in place and relies on the zeros)
+        const int k0 = c16, k1 = 16 + (c16 & 7);
+        const unsigned keep0 = c_anc[k0] & ((2u << k0) - 1u), keep1 = c_anc[k1] & ((2u << k1) - 1u);
+        const bool col1 = c16 < 8;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int rl = sizeof(real) == 8 ? g4 + 4 * j : 4 * g4 + j;          // row inside the tile
+            s.M[rl][k0] = keep_if(d00[j], keep0, rl);
+            if (col1) s.M[rl][k1] = keep_if(d01[j], keep1, rl);
+            if (rl < 8) {
+                s.M[16 + rl][k0] = 0;                                              // rows 16..23, columns 0..15: below the diagonal
+                if (col1) s.M[16 + rl][k1] = keep_if(d11[j], keep1, 16 + rl);
+            }
+        }
+    }
+    WSYNC();
+#endif
     if (dump && lane < NV) {
 #pragma unroll
         for (int r = 0; r < NV; r++) dump[r * NV + lane] = r <= lane ? s.M[r][lane] : s.M[lane][r];
