@@ -568,7 +568,9 @@ def _td3_run(a, dev, rank, world, dist, steps, warmup, batch):
                              "does 1 step of batch 100 per single env-step, plen_td3.py:119-120)" % (a.td3_updates, batch, n, a.td3_updates * batch / n),
            "hip_graphs": True,
            "schedule": ("actor/learner overlap: %d sub-batches of %d envs and the update on %d HIP streams, acting policy two updates old (train_vec.PipelinedVecTD3Trainer); "
-                        "update and actor forward as row-block MFMA kernels of single-wave workgroups (csrc/td3_rows.hip), flat Adam kernel" % (H, n // H, H + 1))
+                        "update: %s; actor forward of the collect phase as 16 envs per four-wave workgroup on packed weights (k_actor_block)" % (
+                            H, n // H, H + 1, "large-batch kernels (csrc/td3_block.hip: 16 batch rows per four-wave workgroup, activations in LDS, packed weights, one weight-gradient "
+                            "launch per pass consumed by the Adam step)" if batch > 512 else "small-batch / row-block kernels (csrc/td3_team.hip, td3_rows.hip)"))
                        if pipelined else "synchronous: collect all envs, then update (train_vec.GraphedVecTD3Trainer)",
            "collective": ("RCCL all-reduce of the flat critic (155138 f32) and actor (77330 f32) gradient buckets per update, mode %s" % getattr(tr, "allreduce_mode", None)) if world > 1 else None,
            "critic_loss": float(agent.last_critic_loss) if agent.last_critic_loss is not None else None,
