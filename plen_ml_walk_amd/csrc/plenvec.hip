@@ -1855,7 +1855,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
 #endif
     constexpr bool LIM_ROWS = PLENVEC_LIM_FLAVOURS ? (LSPEC == LOOP_GENERIC || LSPEC >= 100) : (PLENVEC_LIM_ROWS_EVERYWHERE || LSPEC == LOOP_GENERIC || (PLENVEC_COUNT_SPECIALISED == 2 && LSPEC == 24));
 #ifndef PLENVEC_UNROLL_PARITY
-#define PLENVEC_UNROLL_PARITY 0          /* measured and left off: 1 = the loop body once per iteration parity (even: reversed non-contact rows, odd: sorted order), no parity test: +0.8 % (f64 and f32) for +400 KB of code */
+#define PLENVEC_UNROLL_PARITY 1          /* 1 (shipped since round 5): the loop body once per iteration parity (even: reversed non-contact rows, odd: sorted order), no `it & 1` test and one taken branch per TWO iterations: f64 +0.6 % random / +0.9 % walking, f32 +1.2 % / +1.0 % (scripts/gpu_ab64.py, gpu_ab_walk.py) for +370 KB of code; round 4 measured +0.8 % and left it off */
 #endif
     // one solver iteration; ODD: compile-time parity (PLENVEC_UNROLL_PARITY) or -1 = tested at run time.  Returns Bullet's exit condition; advances `it`.
     real dv0 = 0, dv1 = 0, dv2 = 0, dv3 = 0;          // the torsional rows' deltas of a foot's point k (deferred commit, like dvec)
