@@ -677,7 +677,11 @@ __device__ __forceinline__ void pgs_cone(real &e, const real u, real &dvec, cons
     const real w = u - e;                           // candidate lambda * diag of this lane's row
     const real s = w * jdi;                         // candidate lambda
     const real q = s * s;
-    const real len2 = q + quad_swap12(q);           // |s|^2 of the pair, in both of its lanes
+    real len2;                                      // |s|^2 of the pair, in both of its lanes
+    if constexpr (FAST && sizeof(real) == 4) {
+        // the partner's term as the DPP operand of the add itself (the compiler keeps mov_dpp + add apart); s_nop 1: a DPP source must be two wait states old
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 quad_perm:[0,2,1,3] row_mask:0xf bank_mask:0xf" : "=v"(len2) : "v"(q));
+    } else len2 = q + quad_swap12(q);
     real scale;
     // Bullet clamps row A to |lim*sin(atan2(sA,sB))| and row B to |lim*cos(..)|: a radial projection onto the circle
     if constexpr (sizeof(real) == 4) scale = min_(1.0f, lmv * rsqrt_(len2));                   // v_rsq_f32; 0*inf = NaN -> 1 (s == 0 then); 1 ulp, f32 path only
@@ -1820,6 +1824,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     const real selA = (is_lin && pax == 1) ? (real)1 : (real)0;     // 1 in the first lane of every lateral-friction pair
     const int tors_addr = 4 * (LANE_NORMAL0 + 16 * pf);       // byte address (LDS crossbar) of the first normal port's lane of this lane's foot; the next ones: + 16 each
     const real nfcn = (is_lin && pax == 0) ? -mu_g * jdi : (real)0;     // lane PN: mu * lambda_n = nfcn * blo
+    const real nfcnq = quad_bcast0(nfcn);                                // ... the same in every lane of the point's quad (f32 fast path: the product and the quad broadcast of blo are one instruction)
 
     real e = -rv;                  // e = J_port * deltaV - rv
     real dvec = 0;                 // per-pass deltas of the rows hosted by this lane (deferred commit)
@@ -2007,7 +2012,9 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             // -- lateral friction, cone-coupled pairs --
             {
                 // mu * lambda_n of each point: from its normal lane (lane 0 of the point's quad) to the whole quad
-                const real lmv = quad_bcast0(mul_rn_(nfcn, blo));
+                real lmv;
+                if constexpr (FAST && sizeof(real) == 4) asm("s_nop 1\n\tv_mul_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "=v"(lmv) : "v"(blo), "v"(nfcnq));
+                else lmv = quad_bcast0(mul_rn_(nfcn, blo));
                 each_point([&](auto fc_, auto kc) {
                     constexpr int PN = port_normal(4 * decltype(fc_)::value + decltype(kc)::value);
 #ifdef PLEN_SLIDE_STATS
@@ -2020,7 +2027,10 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             // Bullet's residual of a pair is |dA + dB|: after the pass every pair's deltas sit in its two lanes of dvec,
             // so one DPP add forms all the sums at once in the A lanes (instead of two VALU ops per pair)
             if constexpr (HOISTED) {
-                exceed |= OVER(dvec + shift_down1(dvec)) & lateral_a_lanes(NR, NL);     // (the first lane of every pair the copy owns; motor and normal lanes of dvec hold this iteration's deltas)
+                real pair_sum;
+                if constexpr (FAST && sizeof(real) == 4) asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf" : "=v"(pair_sum) : "v"(dvec));
+                else pair_sum = dvec + shift_down1(dvec);
+                exceed |= OVER(pair_sum) & lateral_a_lanes(NR, NL);     // (the first lane of every pair the copy owns; motor and normal lanes of dvec hold this iteration's deltas)
                 u0 += dvec;                                                            // u0 means something in the torsional and lateral lanes only
             } else {
                 exceed |= OVER((dvec + shift_down1(dvec)) * selA);
