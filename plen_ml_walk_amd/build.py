@@ -47,6 +47,13 @@ def build_td3_kernels(force=False):
     return TD3_OUT
 
 
+# The A/B partner of the shipped env library (csrc/variants/nospec.so; tests/test_env_gpu.py holds the two to bitwise equality): every round-4/5 restructuring switched off --
+# run-time point tests instead of the count-specialised solver loops (with their hoisted commits), the Delassus matrix as vector multiply-adds from broadcast LDS reads instead of
+# matrix-core tiles.  (Not the mass matrix: -DPLENVEC_MFMA_MASS=0 changes how the compiler contracts the rest of that phase -- even the bias force, which the switch does not
+# touch, moves in its last bit -- so that pair of builds is equal to rounding, not to the bit: scripts/gpu_twin_check.py.)
+REFERENCE_FORM_FLAGS = ["-DPLENVEC_COUNT_SPECIALISED=0", "-DPLENVEC_MFMA_DELASSUS=0"]
+
+
 def build_variant(name, defines=()):
     """Profiling / A-B builds (scripts/): csrc/variants/<name>.so with extra -D flags, rebuilt when the source is newer."""
     out = os.path.join(CSRC, "variants", name + ".so")

@@ -344,9 +344,14 @@ def test_count_specialised_solver_loops_bitwise_equal_the_run_time_tested_loop(t
     and every contact configuration from airborne to both feet planted occurs -- agree bit for bit, including states and auto-resets.
     The specialised copies run the spinning / rolling rows unconditionally and rely on (+-0, +-0) bounds being exact no-ops when a coefficient is zero, and on
     lent box slots carrying zero coefficients: `no_torsional_friction` sets both coefficients to 0, `fallen_robots` switches the auto-reset off so
-    that robots fall and stay down -- links other than the feet on the ground, contact slots lent to their box corners."""
-    from plen_ml_walk_amd.build import build_variant
-    lib0 = build_variant("nospec", ["-DPLENVEC_COUNT_SPECIALISED=0"])
+    that robots fall and stay down -- links other than the feet on the ground, contact slots lent to their box corners.
+    Round 5: the same twin also builds the Delassus matrix A = Y^T Y as vector multiply-adds from broadcast LDS reads (-DPLENVEC_MFMA_DELASSUS=0) where the shipped
+    kernel uses `v_mfma_f{32,64}_16x16x4` tiles (dense when a slot is lent, the structurally zero pieces skipped otherwise), and commits / zeroes its delta vectors
+    after every pass where the shipped loops do neither: bit for bit the same trajectories says the matrix instruction adds its k terms in order, and that the hoisted
+    commits touch no value a row reads.  (The mass matrix's matrix-core build has no such twin: switching it off changes the compiler's contractions elsewhere in
+    its phase; it is held to the oracle like everything else.)"""
+    from plen_ml_walk_amd.build import build_variant, REFERENCE_FORM_FLAGS
+    lib0 = build_variant("nospec", REFERENCE_FORM_FLAGS)
     kw = {"reference": "", "no_torsional_friction": ", cfg_overrides={'spinning_friction': 0.0, 'rolling_friction': 0.0}", "fallen_robots": ", auto_reset=False"}[cfg]
     code = ("import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
             "from plen_ml_walk_amd.vec_env import PlenVecEnv\n"
