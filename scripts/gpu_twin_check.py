@@ -1,7 +1,10 @@
 """Development: the mass matrix of the matrix-core build against the vector build, entry by entry (debug dump of one substep), f32 and f64.
-usage: python scripts/gpu_twin_check.py   (needs csrc/variants/tw_mass0.so = -DPLENVEC_COUNT_SPECIALISED=0 -DPLENVEC_MFMA_MASS=0)"""
+usage: python scripts/gpu_twin_check.py   (builds csrc/variants/tw_mass0.so = -DPLENVEC_COUNT_SPECIALISED=0 -DPLENVEC_MFMA_MASS=0 when missing; build it here, the GPU box takes minutes)"""
 import os, subprocess, sys, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from plen_ml_walk_amd.build import build_variant
+build_variant("tw_mass0", ["-DPLENVEC_COUNT_SPECIALISED=0", "-DPLENVEC_MFMA_MASS=0"])
 code = ("import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
         "from plen_ml_walk_amd.vec_env import PlenVecEnv\n"
         "env = PlenVecEnv(64, dtype=getattr(torch, sys.argv[2])); env.reset()\n"
