@@ -1927,6 +1927,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             if constexpr (HOISTED) {
                 // motor and normal lanes together; bhi of an occupied normal lane is 1e30 (1e30 - d = 1e30), the lateral lanes' bounds are never read
                 blo -= dvec; bhi -= dvec; exceed |= OVER(dvec) & (MOTOR_LANES | normal_lanes(NR, NL));
+                pin_order(bhi);     // here, not where the next motor pass reads it: the cone rows below overwrite dvec in place, and a pending use would cost a register copy per iteration
             } else {
                 blo -= dvec; exceed |= OVER(dvec); dvec = 0;     // bhi of a normal row is 1e30 or 0: unchanged
             }
