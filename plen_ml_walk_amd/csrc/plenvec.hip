@@ -704,7 +704,7 @@ __device__ __forceinline__ void pgs_cone(real &e, const real u, real &dvec, cons
 #else
         // f64: a correctly rounded square root and division are ~28 instructions of the ~55 this pair costs.  (1) a pair inside its friction circle
         // needs neither (scale = 1): only the pair's own two lanes decide, so one scalar test skips them; (2) a sliding pair gets
-        // lmv * rsqrt_(len2) (v_rsq_f64 and two Newton steps, < 2 ulp of lmv / sqrt(len2); 10 instructions).
+        // lmv * rsqrt_(len2) (< 1 ulp of lmv / sqrt(len2)).  [rounds 2-4's form, kept for -DPLENVEC_CONE_STRAIGHT=0: scripts/gpu_slide_stats.py counts its branch]
         const bool slide = len2 >= lmv * lmv;
         scale = (real)1;
         static_assert((LA >> 5) == (LB >> 5), "both lanes of a pair sit in the same half of the wave");
@@ -1298,7 +1298,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         constexpr int K = NV - 1 - decltype(kc)::value;
         const real piv = bcast(Lr[K], K);
         real rd;
-        rd = rsqrt_(piv);                                  // f32: v_rsq_f32, 1 ulp; f64: v_rsq_f64 + two Newton steps, < 2 ulp
+        rd = rsqrt_(piv);                                  // f32: v_rsq_f32, 1 ulp; f64: v_rsq_f64 + one third-order step, < 1 ulp
         if (lane == 0) s.col[K] = rd;                      // collected below: every lane needs its own 1/L[k][k]
         const real lik = lane < K ? Lr[K] * rd : (real)0;      // L[K][i] in lane i < K; zero on and below the diagonal of L^T
         Lr[K] = lik;
