@@ -684,7 +684,16 @@ __device__ __forceinline__ void pgs_cone(real &e, const real u, real &dvec, cons
     } else len2 = q + quad_swap12(q);
     real scale;
     // Bullet clamps row A to |lim*sin(atan2(sA,sB))| and row B to |lim*cos(..)|: a radial projection onto the circle
-    if constexpr (sizeof(real) == 4) scale = min_(1.0f, lmv * rsqrt_(len2));                   // v_rsq_f32; 0*inf = NaN -> 1 (s == 0 then); 1 ulp, f32 path only
+    if constexpr (sizeof(real) == 4) {
+        // scale = clamp(lm / |s|, 0, 1) as the output modifier of the product itself (v_rsq_f32: 1 ulp, f32 path only): one instruction and one step of the pair's dependent chain
+        // less than mul + min (f32 +1.2 %).  lm >= 0, so the lower clamp never acts; |s|^2 = 0 (both candidates zero, or their squares underflowed) gives inf -> 1 for lm > 0 like
+        // min() did, and NaN -> 0 for lm = 0 (the mode's clamp maps NaN to 0; min() kept 1): the projection onto a friction circle of radius 0, where rounds 1-4 let a
+        // candidate of magnitude < 1e-19 through.  Same instruction in the compiler path (PLENVEC_NO_ASM), so the two stay bit-identical.
+        const real rs_ = rsqrt_(len2);
+        // (s_nop 0: on gfx940+ the consumer of a transcendental result -- rs_ comes from v_rsq_f32 -- must be one wait state behind it; the compiler inserts that for its
+        // own instructions and cannot see into an asm statement)
+        asm("s_nop 0\n\tv_mul_f32_e64 %0, %1, %2 clamp" : "=v"(scale) : "v"(lmv), "v"(rs_));
+    }
     else {
 #ifdef PLENVEC_EXACT_MATH
         scale = len2 >= lmv * lmv ? (len2 > 0 ? lmv / sqrt_(len2) : (real)0) : (real)1;
@@ -693,13 +702,13 @@ __device__ __forceinline__ void pgs_cone(real &e, const real u, real &dvec, cons
         // random-action rollouts and 87 % under the walking policy), so the test-and-branch of rounds 2-4 (compare, ballot, scalar AND, branch: four steps of the wave's
         // dependent chain in front of the reciprocal square root it almost never skipped) is gone, and lm / |s| comes out of ONE third-order step on v_rsq_f64
         // (y0 to 2^-23; with r = 1 - x y0^2:  lm y0 (1 + r (1/2 + 3/8 r)), truncation 5/16 r^3 < 2^-66) in which lm is folded: rsq, x y0 | lm y0, r, lm y0 r | p, fma = four
-        // dependent steps behind the rsq where two Newton steps and the product took seven.  min(1, t) as in the f32 path: NaN (|s| = 0: 0 * inf) gives 1.
+        // dependent steps behind the rsq where two Newton steps and the product took seven; the clamp to [0, 1] rides on the last fma.
         {
             const real y0 = __builtin_amdgcn_rsq(len2);
             const real a_ = len2 * y0, ly0 = lmv * y0;
             const real r_ = __builtin_fma(-a_, y0, (real)1);
             const real p_ = __builtin_fma(r_, (real)0.375, (real)0.5), lr = ly0 * r_;
-            scale = min_((real)1, __builtin_fma(lr, p_, ly0));
+            asm("v_fma_f64 %0, %1, %2, %3 clamp" : "=v"(scale) : "v"(lr), "v"(p_), "v"(ly0));      // clamp(., 0, 1) as the fma's output modifier (see the f32 branch above)
         }
 #else
         // f64: a correctly rounded square root and division are ~28 instructions of the ~55 this pair costs.  (1) a pair inside its friction circle
