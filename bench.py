@@ -457,31 +457,37 @@ def policy_leg(a, dev, rank, world, dist, steps, warmup):
     fused = FusedTD3(agent, seed=1, rows=True)
     envs = [PlenVecEnv(n // H, device=dev) for _ in range(H)]
     streams = [worker_stream(dev, h) for h in range(H)]
-    state = [e.reset().to(torch.float32).clone() for e in envs]
+    state = [e.reset() for e in envs]           # the env's own observation buffer (f32 env): every step rewrites it in place, the next actor forward reads it there
+    assert all(s_.dtype == torch.float32 for s_ in state)
     rngs = [FusedTD3.new_rng(dev, 4242 + h + 1000 * rank) for h in range(H)]
     stats = [torch.zeros((), dtype=torch.long, device=dev) for _ in range(H)]         # episodes that ended
     torch.cuda.synchronize(dev)
+    UNROLL = 4                                   # vector steps per graph replay: a replay costs ~24 us of idle gap on its stream, a collector's step ~0.33 ms
+    steps = max(UNROLL, steps // UNROLL * UNROLL)          # (whole replays)
 
     def collect(h):
         act = fused.explore(state[h], sigma, actor=agent.actor, rng=rngs[h])
         rngs[h][1] += 1
         _, _, d, info = envs[h].step(act)
+        assert info["obs"].data_ptr() == state[h].data_ptr()
         stats[h] += (d != 0).sum()                 # (bookkeeping kept to two small kernels: it sits on the collector's critical path)
-        state[h].copy_(info["obs"])
 
     graphs, runs = {}, {}
 
-    def step():
+    def step():                                  # UNROLL vector steps of every sub-batch
         for h in range(H):
             with torch.cuda.stream(streams[h]):
                 g = graphs.get(h)
                 if g is None:
                     if runs.get(h, 0) < 2:
-                        collect(h); runs[h] = runs.get(h, 0) + 1
+                        for _ in range(UNROLL):
+                            collect(h)
+                        runs[h] = runs.get(h, 0) + 1
                         continue
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=streams[h], capture_error_mode="thread_local"):
-                        collect(h)
+                        for _ in range(UNROLL):
+                            collect(h)
                     graphs[h] = g
                 g.replay()
 
@@ -491,14 +497,14 @@ def policy_leg(a, dev, rank, world, dist, steps, warmup):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(warmup, 60)):            # past the graph captures and the synchronous start (every episode begins at step 0)
+    for _ in range(-(-max(warmup, 60) // UNROLL)):  # past the graph captures and the synchronous start (every episode begins at step 0)
         step()
     barrier()
     for st in stats:
         st.zero_()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for _ in range(steps // UNROLL):
         step()
     barrier()
     dt = sharding.max_over_ranks(time.perf_counter() - t0, dev)
@@ -510,7 +516,7 @@ def policy_leg(a, dev, rank, world, dist, steps, warmup):
             "episode_note": "every env starts an episode at step 0 and the timed window is steps %d..%d: only short episodes can end inside it; unbiased statistics of this "
                             "policy: tests/test_pin_gpu.py (2048 episodes: mean length ~206, ~20 %% reach the 500-step limit)" % (max(warmup, 60), max(warmup, 60) + steps),
             "workload": "SURVEY 8(f) row 1: %d envs per GPU driven by the reference's shipped policy 3229999 (actor forward as a row-block MFMA kernel + N(0, %.2f) "
-                        "exploration noise in the loop), 2 sub-batches on 2 HIP streams, hipGraph replays" % (n, sigma)}
+                        "exploration noise in the loop), 2 sub-batches on 2 HIP streams, hipGraph replays of %d vector steps each" % (n, sigma, UNROLL)}
 
 
 def _td3_run(a, dev, rank, world, dist, steps, warmup, batch):
