@@ -2510,7 +2510,23 @@ __global__ __launch_bounds__(1024) void plen_balance_kernel(int n, int groups, c
         atomicAdd(&hist[BAL_BUCKETS - 1 - b], 1);             // heavy envs first
     }
     __syncthreads();
-    if (t == 0) { int acc = 0; for (int i = 0; i < BAL_BUCKETS; i++) { base[i] = acc; acc += hist[i]; } }
+    // exclusive prefix sum of the 256 bucket counts: one wave-wide scan per 64 buckets (DPP-free: shuffles), then the three carries -- the serial loop of rounds 1-4
+    // (thread 0, 256 dependent LDS round trips) was two thirds of this kernel's 6.4 us, and the kernel sits on every sub-batch's launch chain
+    if (t < BAL_BUCKETS) {
+        const int v = hist[t];
+        int x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d, 64); if ((t & 63) >= d) x += y; }
+        base[t] = x - v;                                      // exclusive within the wave's 64 buckets
+        if ((t & 63) == 63) hist[t] = x;                      // the wave's total, kept in its last bucket's slot (hist is not read again below)
+    }
+    __syncthreads();
+    if (t < BAL_BUCKETS) {
+        int carry = 0;
+#pragma unroll
+        for (int w = 0; w < BAL_BUCKETS / 64 - 1; w++) carry += (t >> 6) > w ? hist[64 * w + 63] : 0;
+        base[t] += carry;
+    }
     __syncthreads();
     for (int e = t; e < n; e += blockDim.x) {
         const int b = min(BAL_BUCKETS - 1, max(0, aux[(size_t)e * AUXN + 7]) / 448);
