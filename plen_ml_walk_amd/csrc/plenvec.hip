@@ -20,7 +20,9 @@
 //
 //   * plen_balance_kernel places envs on SIMDs by cost before every launch (placement never changes results).
 //
-// No MFMA: there is no dense contraction worth a matrix core here (24..48-wide); the kernel is VALU-issue bound.
+// Matrix cores (round 5): the two dense products of a substep -- mass matrix M = S (I S)^T and Delassus matrix A = Y^T Y -- run as v_mfma_f{32,64}_16x16x4 tiles, not for
+// their flops (a per cent of the matrix peak) but to take them off the LDS return path and the vector port; the kernel as a whole is bound by the solver rows' dependent
+// chain and the vector issue port.
 // The library never falls back to the CPU; the oracle under oracle/ is never linked or called.
 #include <hip/hip_runtime.h>
 #include <math.h>
