@@ -45,6 +45,10 @@ int plentd3_store(float *data, const int64_t *total, int64_t capacity, const flo
  * plen_td3.py:115 `state = next_state` / :133 `state = env.reset()`) in the same launch */
 int plentd3_store_advance(float *data, const int64_t *total, int64_t capacity, float *s, const float *a, const float *s2, const float *r, const uint8_t *done, uint64_t *rng_bump,
                           float *ep_ret, double *stats, int n, const float *next_state, void *stream);
+/* plentd3_store_advance (next_state may be NULL: plain plentd3_store), and then *total += step in the same launch (the caller's ring position for its next vector step:
+ * train_vec.py's collectors advance by the rows of ALL collectors).  blocks_done: one zero-initialised unsigned per caller, left at zero by every launch. */
+int plentd3_store_step(float *data, int64_t *total, int64_t capacity, float *s, const float *a, const float *s2, const float *r, const uint8_t *done, uint64_t *rng_bump,
+                       float *ep_ret, double *stats, int n, const float *next_state, int64_t step, unsigned *blocks_done, void *stream);
 /* td3.py:299-304: sa2 = [s2 | clamp(max_a tanh(pre) + clamp(noise sigma, +-clip), +-max_a)], pre = actor_target's last pre-activation */
 int plentd3_target_action(const float *pre, const float *noise, const uint64_t *rng, const float *batch, float *sa2, float sigma, float clip, float max_a, int B, void *stream);
 /* twin last layers on h2 = [h2_a | h2_b] ([B][512]).  mode 0, td3.py:306-309: y = r + not_done gamma min(q_a, q_b).

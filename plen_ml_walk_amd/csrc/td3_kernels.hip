@@ -364,10 +364,17 @@ __global__ void k_uniform_actions(const uint64_t *__restrict__ rng, float *__res
 //      done_bool = compute_done() fired AND the time limit did not (PLENVEC_DONE_TERMINAL = 1, _TIMELIMIT = 2)
 __global__ void k_store(float *__restrict__ data, const int64_t *__restrict__ total, int64_t capacity, float *__restrict__ s, const float *__restrict__ a,
                         const float *__restrict__ s2, const float *__restrict__ r, const uint8_t *__restrict__ done, uint64_t *rng_bump,
-                        float *__restrict__ ep_ret, double *stats, int n, const float *__restrict__ advance) {
+                        float *__restrict__ ep_ret, double *stats, int n, const float *__restrict__ advance, int64_t *total_step, int64_t step, unsigned *blocks_done) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (rng_bump && t == 0) rng_bump[1] += 1;           // this collect step's action draw is done
     const int e = t / TD3_ROW, c = t % TD3_ROW;
+    // plentd3_store_step: *total += step once every block has read it -- the last block to get here does it (each block's first thread counts itself in after the
+    // block's reads; the counter is left at zero for the next launch).  Replaces the caller's one-element add kernel on its critical path.
+    const int64_t total0 = total[0];
+    if (blocks_done) {
+        __syncthreads();
+        if (threadIdx.x == 0 && atomicAdd(blocks_done, 1u) == gridDim.x - 1) { blocks_done[0] = 0; total_step[0] = total0 + step; }
+    }
     if (e >= n) return;
     // episode bookkeeping at full speed (the reference prints every episode's return, plen_env.py:616-636): per-env running return; when the
     // episode ends (any done bit) its return and length go into stats = {sum of returns, episodes, sum of lengths} and the env starts over.
@@ -378,7 +385,7 @@ __global__ void k_store(float *__restrict__ data, const int64_t *__restrict__ to
         if (done[e]) { atomicAdd(stats, (double)ret); atomicAdd(stats + 1, 1.0); atomicAdd(stats + 2, (double)len); ep_ret[2 * e] = 0.f; ep_ret[2 * e + 1] = 0.f; }
         else { ep_ret[2 * e] = ret; ep_ret[2 * e + 1] = len; }
     }
-    const int64_t row = (total[0] + e) % capacity;
+    const int64_t row = (total0 + e) % capacity;
     float v;
     if (c < TD3_S) {
         v = s[(size_t)e * TD3_S + c];
@@ -547,12 +554,17 @@ int plentd3_uniform_actions(const uint64_t *rng, float *a, int n, void *stream) 
 }
 int plentd3_store(float *data, const int64_t *total, int64_t capacity, const float *s, const float *a, const float *s2, const float *r, const uint8_t *done, uint64_t *rng_bump,
                   float *ep_ret, double *stats, int n, void *stream) {
-    hipLaunchKernelGGL(k_store, GRID(n * TD3_ROW), data, total, capacity, const_cast<float *>(s), a, s2, r, done, rng_bump, ep_ret, stats, n, (const float *)nullptr); CHECK();
+    hipLaunchKernelGGL(k_store, GRID(n * TD3_ROW), data, total, capacity, const_cast<float *>(s), a, s2, r, done, rng_bump, ep_ret, stats, n, (const float *)nullptr, (int64_t *)nullptr, (int64_t)0, (unsigned *)nullptr); CHECK();
 }
 int plentd3_store_advance(float *data, const int64_t *total, int64_t capacity, float *s, const float *a, const float *s2, const float *r, const uint8_t *done, uint64_t *rng_bump,
                           float *ep_ret, double *stats, int n, const float *next_state, void *stream) {
     if (!next_state || next_state == s) return -(int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_store, GRID(n * TD3_ROW), data, total, capacity, s, a, s2, r, done, rng_bump, ep_ret, stats, n, next_state); CHECK();
+    hipLaunchKernelGGL(k_store, GRID(n * TD3_ROW), data, total, capacity, s, a, s2, r, done, rng_bump, ep_ret, stats, n, next_state, (int64_t *)nullptr, (int64_t)0, (unsigned *)nullptr); CHECK();
+}
+int plentd3_store_step(float *data, int64_t *total, int64_t capacity, float *s, const float *a, const float *s2, const float *r, const uint8_t *done, uint64_t *rng_bump,
+                       float *ep_ret, double *stats, int n, const float *next_state, int64_t step, unsigned *blocks_done, void *stream) {
+    if (!blocks_done || (next_state && next_state == s)) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_store, GRID(n * TD3_ROW), data, total, capacity, s, a, s2, r, done, rng_bump, ep_ret, stats, n, next_state, total, step, blocks_done); CHECK();
 }
 int plentd3_wgrad(const float *dH, int dh_stride, const float *X, int x_stride, float *dW, int dw_stride, float *db, int B, int N, int K, int single_wave, void *stream) {
     const int tiles = ((N + 31) / 32) * ((K + 31) / 32);

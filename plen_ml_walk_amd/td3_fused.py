@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PLENTD3_LIB") or os.path.join(_HERE, "csrc", "libplentd3.so")          # (PLENTD3_LIB: an A/B build, scripts/ only)
-EXPORTS = ["plentd3_gather", "plentd3_sample_gather", "plentd3_explore", "plentd3_uniform_actions", "plentd3_store", "plentd3_store_advance", "plentd3_target_action", "plentd3_q_heads", "plentd3_dh2", "plentd3_relu_mask", "plentd3_colsum", "plentd3_wgrad",
+EXPORTS = ["plentd3_gather", "plentd3_sample_gather", "plentd3_explore", "plentd3_uniform_actions", "plentd3_store", "plentd3_store_advance", "plentd3_store_step", "plentd3_target_action", "plentd3_q_heads", "plentd3_dh2", "plentd3_relu_mask", "plentd3_colsum", "plentd3_wgrad",
            "plentd3_tanh_out", "plentd3_dtanh", "plentd3_bias_relu", "plentd3_polyak", "plentd3_adam", "plentd3_critic_rows", "plentd3_policy_rows", "plentd3_actor_rows", "plentd3_critic_team", "plentd3_policy_team",
            "plentd3_wgrad_group", "plentd3_wgrad_adam_group", "plentd3_pack", "plentd3_critic_block", "plentd3_policy_block", "plentd3_wgrad_big", "plentd3_adam_big", "plentd3_actor_block", "plentd3_dev_mfma_spin", "plentd3_stamp", "plentd3_version"]
 ROW, S, A, SA, H = 72, 26, 18, 44, 256
@@ -133,6 +133,7 @@ def load():
         lib.plentd3_uniform_actions.argtypes = [vp, vp, i, vp]
         lib.plentd3_store.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, i, vp]
         lib.plentd3_store_advance.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, i, vp, vp]
+        lib.plentd3_store_step.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, i, vp, C.c_int64, vp, vp]
         lib.plentd3_target_action.argtypes = [vp, vp, vp, vp, vp, f, f, f, i, vp]
         lib.plentd3_q_heads.argtypes = [vp] * 12 + [f, i, i, vp]
         lib.plentd3_dh2.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp]
@@ -661,7 +662,7 @@ class FusedTD3(object):
         _chk(self.lib.plentd3_uniform_actions(_p(rng), _p(a), n * A, self._stream()))
         return a
 
-    def store(self, data, total, state, action, next_obs, reward, done, rng=None, episodes=None, advance=None):
+    def store(self, data, total, state, action, next_obs, reward, done, rng=None, episodes=None, advance=None, step=None):
         """One vector step into the packed replay ring at positions (total + e) % capacity (plen_td3.py:109-113); `total` = device int64 scalar.
         rng: the collect stream's random state, whose call counter this kernel advances.  episodes: (ep_ret [n, 2] float32, stats [3] float64) device
         tensors for the episode bookkeeping (running return / length per env; finished episodes summed into stats)."""
@@ -675,6 +676,14 @@ class FusedTD3(object):
             # round-2 contract (float32 stats, 12 bytes) would have its neighbouring allocation overwritten
             assert st.dtype == torch.float64 and st.numel() >= 3 and st.is_contiguous(), "episode stats must be a contiguous float64 tensor of >= 3 elements"
             assert ep is not None and ep.dtype == torch.float32 and tuple(ep.shape) == (n, 2) and ep.is_contiguous(), "ep_ret must be float32 [n, 2]"
+        if step is not None:          # ... and total += step[0] in the same launch (step = (rows, zero-initialised uint32 device scalar))
+            rows, ctr = step
+            assert ctr.dtype in (torch.int32, torch.uint32) and ctr.numel() == 1 and ctr.device == total.device
+            if advance is not None:
+                assert advance.dtype == torch.float32 and advance.is_contiguous() and advance.shape == state.shape and advance.data_ptr() != state.data_ptr()
+            _chk(self.lib.plentd3_store_step(_p(data), _p(total), int(data.shape[0]), _p(state), _p(action), _p(next_obs), _p(reward), _p(done), _p(rng), _p(ep), _p(st), n,
+                                             _p(advance), int(rows), _p(ctr), self._stream()))
+            return
         if advance is not None:       # ... and state <- advance (the observation to act on next) in the same launch
             assert advance.dtype == torch.float32 and advance.is_contiguous() and advance.shape == state.shape and advance.data_ptr() != state.data_ptr()
             _chk(self.lib.plentd3_store_advance(_p(data), _p(total), int(data.shape[0]), _p(state), _p(action), _p(next_obs), _p(reward), _p(done), _p(rng), _p(ep), _p(st), n,

@@ -469,6 +469,7 @@ class PipelinedVecTD3Trainer(object):
         self.su = worker_stream(dev, "update")
         self.state = [e.reset().to(torch.float32).clone() for e in envs]
         self.base = [torch.tensor(h * self.nh, dtype=torch.long, device=dev) for h in range(self.H)]  # next ring row of each sub-batch
+        self._store_ctr = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(self.H)]     # plentd3_store_step's block counters
         self.total_u = torch.zeros((), dtype=torch.long, device=dev)                                  # rows complete before the current step
         self.ep_ret = [torch.zeros(self.nh, 2, device=dev) for _ in range(self.H)]                    # running return / length of every env
         self.ep_stats = torch.zeros(3, dtype=torch.float64, device=dev)                                                    # finished episodes: sum of returns, count, sum of lengths
@@ -518,10 +519,10 @@ class PipelinedVecTD3Trainer(object):
         self._stamp(self.base[h], 4 * h + 2)
         obs = info["obs"]
         fold = obs.dtype == torch.float32 and obs.is_contiguous()          # (the state <- observation copy rides in the store kernel)
+        self._stamp(self.base[h], 4 * h + 3)          # ("end" of the collect step: in front of the store kernel, which moves base on)
+        # (the ring position of this collector's next step, base += rows of ALL collectors, rides in the store kernel: one launch less on the collector's chain)
         self.fused.store(self.replay.data, self.base[h], self.state[h], action, next_obs, reward, done, rng=self.rngs[h], episodes=(self.ep_ret[h], self.ep_stats),
-                         advance=obs if fold else None)
-        self._stamp(self.base[h], 4 * h + 3)
-        self.base[h] += self.n
+                         advance=obs if fold else None, step=(self.n, self._store_ctr[h]))
         if not fold:
             self.state[h].copy_(obs)
 

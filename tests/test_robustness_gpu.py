@@ -1016,3 +1016,46 @@ def test_reference_recipe_two_thousand_updates():
     # Polyak tau 0.005 over 1000 policy updates: the target actor has moved most of the way from the initial actor towards the current one
     assert float((at - a0).abs().max()) > 1e-4 and float((at - a1).abs().mean()) < float((a0 - a1).abs().mean())
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,with_advance", [(2048, True), (37, False), (1, True)])
+def test_store_with_step_equals_store_then_add(n, with_advance):
+    """plentd3_store_step (the ring position advanced inside the store kernel by the last block to arrive) against plentd3_store[_advance] followed by the caller's
+    `total += step`: same ring rows over several wrapping steps, same state hand-over, same `total`, same episode statistics; the block counter is back at zero after
+    every launch.  Reference: plen_td3.py:109-115."""
+    from plen_ml_walk_amd import td3 as T
+    from plen_ml_walk_amd.td3_fused import FusedTD3
+    torch.manual_seed(3)
+    ag = T.TD3Agent(26, 18, 1.0, data_parallel=False)
+    fz = FusedTD3(ag, seed=1)
+    cap, stride = 3 * n + 5, 2 * n                          # (another collector's rows lie between this one's: the ring wraps after two steps)
+    out = {}
+    for mode in ("separate", "fused"):
+        g = torch.Generator(device="cuda").manual_seed(11)
+        data = torch.zeros(cap, 72, device="cuda")
+        total = torch.tensor(7, dtype=torch.long, device="cuda")
+        state = torch.randn(n, 26, device="cuda", generator=g)
+        ep, st = torch.zeros(n, 2, device="cuda"), torch.zeros(3, dtype=torch.float64, device="cuda")
+        ctr = torch.zeros(1, dtype=torch.int32, device="cuda")
+        rng = FusedTD3.new_rng(ag.device, 5)
+        for _ in range(4):
+            action, nxt, rew = torch.randn(n, 18, device="cuda", generator=g), torch.randn(n, 26, device="cuda", generator=g), torch.randn(n, device="cuda", generator=g)
+            done = (torch.rand(n, device="cuda", generator=g) < 0.3).to(torch.uint8) * (1 + (torch.rand(n, device="cuda", generator=g) < 0.5).to(torch.uint8))
+            obs = torch.randn(n, 26, device="cuda", generator=g)
+            if mode == "fused":
+                fz.store(data, total, state, action, nxt, rew, done, rng=rng, episodes=(ep, st), advance=obs if with_advance else None, step=(stride, ctr))
+                assert int(ctr) == 0
+            else:
+                fz.store(data, total, state, action, nxt, rew, done, rng=rng, episodes=(ep, st), advance=obs if with_advance else None)
+                total += stride
+            if not with_advance:
+                state.copy_(obs)
+        torch.cuda.synchronize()
+        out[mode] = (data.clone(), int(total), state.clone(), ep.clone(), st.clone(), rng.clone())
+    a, b = out["separate"], out["fused"]
+    assert a[1] == b[1] == 7 + 4 * stride
+    for x, y in zip(a, b):
+        if torch.is_tensor(x):
+            assert torch.equal(x, y)
+    assert float(a[0].abs().sum()) > 0
