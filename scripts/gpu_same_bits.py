@@ -1,0 +1,22 @@
+"""Development: does a kernel change leave every bit alone?  40 steps x 512 envs of random actions through the in-tree library and through csrc/variants/<lib>
+(a copy of the build before the change), both arithmetics: outputs and final states compared bit for bit.   usage: python scripts/gpu_same_bits.py prev.so"""
+import os, subprocess, sys, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+code = ("import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "from plen_ml_walk_amd.vec_env import PlenVecEnv\n"
+        "out = []\n"
+        "g = torch.Generator().manual_seed(5); acts = (torch.rand(40, 512, 18, generator=g) * 2 - 1).float().cuda()\n"
+        "env = PlenVecEnv(512, dtype=getattr(torch, sys.argv[2])); env.reset()\n"
+        "for t in range(40):\n"
+        "    o, r, d, _ = env.step(acts[t]); out.append(torch.cat([o, r[:, None], d.to(o.dtype)[:, None]], 1).cpu().numpy().copy())\n"
+        "np.save(sys.argv[1], np.array(out)); np.save(sys.argv[1] + '.state.npy', env.get_state().cpu().numpy())\n" % ROOT)
+for dt in ("float32", "float64"):
+    res = {}
+    for tag in ("-", sys.argv[1]):
+        env = dict(os.environ)
+        if tag != "-": env["PLENVEC_LIB"] = os.path.join(ROOT, "plen_ml_walk_amd/csrc/variants", tag)
+        p = "/tmp/sb_%s_%s.npy" % (dt, tag.replace(".so", ""))
+        subprocess.run([sys.executable, "-c", code, p, dt], check=True, env=env)
+        res[tag] = (np.load(p), np.load(p + ".state.npy"))
+    a, b = res["-"], res[sys.argv[1]]
+    print(dt, "outputs bitwise equal:", np.array_equal(a[0], b[0], equal_nan=True), " states:", np.array_equal(a[1], b[1], equal_nan=True))
