@@ -20,17 +20,42 @@ def hipcc_path():
     raise RuntimeError("hipcc not found (ROCm 7.x expected under /opt/rocm)")
 
 
+RESOURCES = os.path.join(CSRC, "libplenvec.resources.json")
+
+
+def parse_resource_remarks(text):
+    """The compiler's -Rpass-analysis=kernel-resource-usage remarks as {kernel symbol: {"VGPRs": .., "SGPRs Spill": .., "ScratchSize": .., "Occupancy": .., "LDS Size": ..}}."""
+    import re
+    out, cur = {}, None
+    for line in text.splitlines():
+        m = re.search(r"remark:\s+Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\S+) \[-Rpass-analysis", line)
+        if m and cur is not None:
+            v = m.group(2)
+            cur[m.group(1).strip()] = int(v) if v.lstrip("-").isdigit() else v
+    return out
+
+
 def build_extension(force=False, verbose=False):
-    """Compile plenvec.hip -> csrc/libplenvec.so (gfx950 only).  Returns the output path."""
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
+    """Compile plenvec.hip -> csrc/libplenvec.so (gfx950 only).  Returns the output path.  The compiler's resource report of every kernel (registers, spilled SGPRs,
+    scratch, LDS, occupancy) is kept next to the library as libplenvec.resources.json: tests/test_cabi_cpu.py holds the env kernels to their budgets."""
+    import json
+    if not force and os.path.exists(OUT) and os.path.exists(RESOURCES) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
     # -fno-slp-vectorize: the SLP vectoriser pairs the 3x3 kinematics products into v_pk_* ops but pays for it with more
     # v_mov shuffles than it saves (measured: -200 VALU instructions per substep, -3.6 % step time, 13 -> 5 spilled VGPRs);
     # the packed Delassus build uses explicit vector types and is unaffected.
-    cmd = [hipcc_path()] + FLAGS + ["-o", OUT, SRC]
+    cmd = [hipcc_path(), "-Rpass-analysis=kernel-resource-usage"] + FLAGS + ["-o", OUT, SRC]
+    r = subprocess.run(cmd, cwd=CSRC, stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stderr[-4000:])
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    subprocess.check_call(cmd, cwd=CSRC)
+        print(r.stderr)
+    with open(RESOURCES, "w") as f:
+        json.dump(parse_resource_remarks(r.stderr), f, indent=1, sort_keys=True)
     return OUT
 
 

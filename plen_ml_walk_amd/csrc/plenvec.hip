@@ -100,6 +100,32 @@ static constexpr unsigned ANC[NV] = {
 // L[r][i] of the factor M = L^T L can be nonzero only when DoF i (< r) supports DoF r
 static constexpr bool l_nz(int r, int i) { return i < r && ((ANC[r] >> i) & 1u); }
 static constexpr bool has_desc(int i) { for (int r = i + 1; r < NV; r++) if (l_nz(r, i)) return true; return false; }
+// Packed storage of the mass matrix / its factor in LDS (round 6: 4608 -> 1536 B in f64, one of the two cuts a third f64 wave per SIMD needs): the DoFs R that DoF i
+// supports are CONTIGUOUS, i < R <= row_end(i) (every DoF for a base coordinate, the rest of its own chain for a joint), so row i is kept as the run (i, i) .. (i, row_end(i))
+// at offset row_p0(i): 183 entries instead of 576.  Entries outside a run are structural zeros -- what the dense buffer stored as +0 and every read below now supplies.
+static constexpr int row_end(int i) { return i < 6 ? NV - 1 : i < 12 ? 11 : i < 18 ? 17 : i < 21 ? 20 : 23; }
+static constexpr int row_p0(int i) { int s_ = 0; for (int j = 0; j < i; j++) s_ += row_end(j) - j + 1; return s_; }
+#define MPK 192          /* reals in the packed buffer: 183 entries, rounded up to the 24 x 8 the mass-matrix operands are staged in */
+#define ROW_P0_LIST 0, 24, 47, 69, 90, 110, 129, 135, 140, 144, 147, 149, 150, 156, 161, 165, 168, 170, 171, 174, 176, 177, 180, 182
+#define ROW_END_LIST 23, 23, 23, 23, 23, 23, 11, 11, 11, 11, 11, 11, 17, 17, 17, 17, 17, 17, 20, 20, 20, 23, 23, 23
+__device__ __constant__ int c_rowp0[NV] = {ROW_P0_LIST};
+__device__ __constant__ int c_rowend[NV] = {ROW_END_LIST};
+static constexpr bool packed_rows_are_the_support() {
+    constexpr int p0[NV] = {ROW_P0_LIST}, re[NV] = {ROW_END_LIST};
+    for (int i = 0; i < NV; i++) {
+        if (p0[i] != row_p0(i) || re[i] != row_end(i)) return false;
+        for (int r = 0; r < NV; r++) if (l_nz(r, i) != (i < r && r <= row_end(i))) return false;
+    }
+    return row_p0(NV - 1) + 1 <= MPK;
+}
+static_assert(packed_rows_are_the_support(), "the packed rows of M / L must be exactly the kinematic tree's supports");
+// entry (J, k) of the packed factor for this lane's DoF k, J a compile-time row: L[k][J] if J supports k, else the structural zero the dense buffer held there
+template <int J, typename real>
+__device__ __forceinline__ real packed_col(const real *Mp, const int k) {
+    const bool ok = k > J && k <= row_end(J);
+    const real m_ = Mp[ok ? row_p0(J) - J + k : 0];
+    return ok ? m_ : (real)0;
+}
 // plen_env.py:148-167
 __device__ __constant__ double c_range_lo[ND] = {-1.57, -0.15, -0.95, -0.9, -0.95, -0.8, -1.57, -1.5, -0.75, -0.3, -1.2, -0.4, -1.57, -0.15, -0.2, -1.57, -0.15, -0.2};
 __device__ __constant__ double c_range_hi[ND] = {1.57, 1.5, 0.75, 0.3, 1.2, 0.4, 1.57, 0.15, 0.95, 0.9, 0.95, 0.8, 1.57, 1.57, 0.35, 1.57, 1.57, 0.35};
@@ -645,7 +671,10 @@ __device__ __forceinline__ void pgs_row_signed(real (&lim)[4][NV], real &e, cons
     const real t = u + (rv - sgn * r);
     const real nu = min_(max_(t, (real)0), (real)100 * diag);     // lambda in [0, 100] (btMultiBodyConstraint default max impulse)
     const real d = nu - u;
-    if (lane == PP) lim[3][l] = nu;
+    // the row's new impulse goes back to LDS as a broadcast stored by lane 0: ONE lane mask shared by all 18 rows.  (`if (lane == PP)` made 18 loop-invariant 64-bit masks
+    // that the compiler kept -- and spilled into VGPR lanes, and reloaded in front of every row -- across the 50 limit-flavour copies of the solver loop.)
+    const real nub = bcast(nu, PP);
+    if (lane == 0) lim[3][PP] = nub;
     const real db = bcast(d, PP);
     res_i = max(res_i, absbits(db));
     e = fma_(bcast(sgn, PP) * db, acol, e);
@@ -800,7 +829,7 @@ struct Smem {
         };
         real park[4][64];       // phases F, G (frames are dead after the collision pass): per-lane values parked out of registers (port velocity, distance, restitution, friction)
     };
-    alignas(16) real M[NV][NV]; // mass matrix, later its Cholesky factor L (lower); rows read as broadcast b128
+    alignas(16) real Mp[MPK];   // mass matrix, later its factor: row i = the entries (i, i .. row_end(i)), packed (row_p0); before that the staged operands of the mass-matrix product
     real v[NV];         // generalized velocity after the unconstrained update
     real col[NV];       // broadcast buffer
     real lamP[NPORT];
@@ -1211,7 +1240,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         for (int i = 0; i < 3; i++) f[i] = cm * Sk[3 + i] + t1[i];
 #if PLENVEC_MFMA_MASS
         // M = S (I S)^T on the matrix cores (below, outside this branch): this lane's column of I S -- n | f -- goes to LDS next to S, in the M buffer (free until the results land)
-        real *nf_row = &s.M[0][0] + 8 * k;
+        real *nf_row = &s.Mp[0] + 8 * k;
 #pragma unroll
         for (int i = 0; i < 3; i++) { nf_row[i] = n[i]; nf_row[3 + i] = f[i]; }
 #else
@@ -1222,7 +1251,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
 #pragma unroll
         for (int r = 0; r < NV; r++) {
             const real val = s.S[r][0] * n[0] + s.S[r][1] * n[1] + s.S[r][2] * n[2] + s.S[r][3] * f[0] + s.S[r][4] * f[1] + s.S[r][5] * f[2];
-            s.M[r][k] = keep_if(val, keep, r);
+            if ((keep >> r) & 1u) s.Mp[row_p0(r) + k - r] = val;
         }
 #endif
         // generalized bias force (motors are constraints, so no joint torque here)
@@ -1246,7 +1275,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         // column -- where rounds 1-4 had every lane read all of S as 72 wave-wide broadcasts for 144 multiply-adds.  The matrix instruction adds i = 0..5 in order, like the old sum.
         using acc4 = real __attribute__((ext_vector_type(4)));
         const int c16 = lane & 15, g4 = lane >> 4;
-        const real *nfb = &s.M[0][0];
+        const real *nfb = &s.Mp[0];
         real oS[2][2], oN[2][2];
 #pragma unroll
         for (int t = 0; t < 2; t++)
@@ -1279,19 +1308,18 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int rl = sizeof(real) == 8 ? g4 + 4 * j : 4 * g4 + j;          // row inside the tile
-            s.M[rl][k0] = keep_if(d00[j], keep0, rl);
-            if (col1) s.M[rl][k1] = keep_if(d01[j], keep1, rl);
-            if (rl < 8) {
-                s.M[16 + rl][k0] = 0;                                              // rows 16..23, columns 0..15: below the diagonal
-                if (col1) s.M[16 + rl][k1] = keep_if(d11[j], keep1, 16 + rl);
-            }
+            const int pa = c_rowp0[rl] - rl;                                      // (row, column) of a kept entry lives at row_p0(row) + column - row
+            if ((keep0 >> rl) & 1u) s.Mp[pa + k0] = d00[j];
+            if (col1 && ((keep1 >> rl) & 1u)) s.Mp[pa + k1] = d01[j];
+            const int r2 = 16 + (rl & 7);
+            if (rl < 8 && col1 && ((keep1 >> r2) & 1u)) s.Mp[c_rowp0[r2] - r2 + k1] = d11[j];      // (rows 16..23 have no entries in columns 0..15: below the diagonal)
         }
     }
     WSYNC();
 #endif
     if (dump && lane < NV) {
 #pragma unroll
-        for (int r = 0; r < NV; r++) dump[r * NV + lane] = r <= lane ? s.M[r][lane] : s.M[lane][r];
+        for (int r = 0; r < NV; r++) { const int a_ = r <= lane ? r : lane, b_ = r <= lane ? lane : r; dump[r * NV + lane] = b_ <= c_rowend[a_] ? s.Mp[c_rowp0[a_] + b_ - a_] : (real)0; }
         dump[576 + lane] = s.tau[lane];
     }
 
@@ -1303,8 +1331,13 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     // diagonal is kept as its reciprocal (inv_diag) and stored as 0, which makes every triangular solve
     // below a plain  broadcast + fma  per column, without lane predicates.
     real Lr[NV];
+    const int row_a = c_rowp0[k] - k, row_e = lane < NV ? c_rowend[k] : -1;          // this lane's packed row: (k, j) at row_a + j for k <= j <= row_e
 #pragma unroll
-    for (int j = 0; j < NV; j++) Lr[j] = lane < NV ? s.M[k][j] : (real)0;
+    for (int j = 0; j < NV; j++) {
+        const bool ok = j >= k && j <= row_e;
+        const real m_ = s.Mp[ok ? row_a + j : 0];
+        Lr[j] = ok ? m_ : (real)0;
+    }
     static_for<NV>([&](auto kc) {
         constexpr int K = NV - 1 - decltype(kc)::value;
         const real piv = bcast(Lr[K], K);
@@ -1329,10 +1362,8 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             });
         }
     });
-    if (lane < NV) {
 #pragma unroll
-        for (int j = 0; j < NV; j++) s.M[k][j] = Lr[j];      // s.M[i][r] = L[r][i] (strictly upper part of L^T, zero diagonal)
-    }
+    for (int j = 0; j < NV; j++) if (j >= k && j <= row_e) s.Mp[row_a + j] = Lr[j];      // packed row i: L[r][i] for the DoFs r that i supports (strictly upper part of L^T), zero diagonal
     WSYNC();
     const real inv_diag = lane < NV ? s.col[k] : (real)0;    // 1 / L[lane][lane]
     STAMP();
@@ -1354,7 +1385,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             constexpr int J = decltype(jc)::value;
             if constexpr (has_desc(J)) {
                 const real xj = bcast(yv * inv_diag, J);
-                yv -= s.M[J][k] * xj;
+                yv -= packed_col<J>(s.Mp, k) * xj;
             }
         });
         const real x = yv * inv_diag;
@@ -1366,7 +1397,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     WSYNC();
     if (dump && lane < NV) {
 #pragma unroll
-        for (int r = 0; r < NV; r++) dump[640 + lane * NV + r] = r == lane ? (real)1 / inv_diag : s.M[r][lane];    // L[lane][r]
+        for (int r = 0; r < NV; r++) dump[640 + lane * NV + r] = r == lane ? (real)1 / inv_diag : (r < lane && lane <= c_rowend[r]) ? s.Mp[c_rowp0[r] + lane - r] : (real)0;    // L[lane][r]
         dump[600 + lane] = s.v[lane];
     }
 
@@ -1542,7 +1573,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             constexpr int I = decltype(ic)::value;
             static_for<NV - 1 - I>([&](auto rc) {
                 constexpr int R = I + 1 + decltype(rc)::value;
-                if constexpr (l_nz(R, I)) cr[R] = s.M[I][R];
+                if constexpr (l_nz(R, I)) cr[R] = s.Mp[row_p0(I) + R - I];
             });
             d = s.col[I];
         };
@@ -1563,7 +1594,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             real acc = Jr[I];
             static_for<NV - 1 - I>([&](auto rc) {
                 constexpr int R = I + 1 + decltype(rc)::value;
-                if constexpr (l_nz(R, I)) acc -= s.M[I][R] * Jr[R];
+                if constexpr (l_nz(R, I)) acc -= s.Mp[row_p0(I) + R - I] * Jr[R];
             });
             Jr[I] = acc * s.col[I];
         });
@@ -1884,6 +1915,22 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         // on the deferred deltas, the lane masks OR-ed on the scalar unit.
         unsigned long long exceed = 0;
 #define OVER(x_) __ballot((float)abs_(x_) > thr_f)
+        // f32, loops compiled for known point counts: the lane-masked residual tests as 32-bit scalar ANDs on the halves of the ballot a pass owns lanes in, OR-ed into ONE
+        // 32-bit flag word (asm: from every C spelling the compiler makes a 64-bit AND whose constant-zero half it carries around the loop as a register of its own -- spilled
+        // into a VGPR lane and read back every iteration in the copies with few contact points, the common ones).  Same decision: only zero / nonzero is ever tested.
+        unsigned exc32 = 0;
+        constexpr bool EXC32 = sizeof(real) == 4 && LSPEC != LOOP_GENERIC;
+        auto over_masked = [&](const unsigned long long bal, auto mask_c) {
+            constexpr unsigned long long MASK = decltype(mask_c)::value;
+            constexpr unsigned LO = (unsigned)(MASK & 0xffffffffull), HI = (unsigned)(MASK >> 32);
+            if constexpr (EXC32) {
+                if constexpr (LO != 0) { unsigned t_; asm("s_and_b32 %0, %1, %2" : "=s"(t_) : "s"((unsigned)bal), "n"(LO) : "scc"); exc32 |= t_; }
+                if constexpr (HI != 0) { unsigned t_; asm("s_and_b32 %0, %1, %2" : "=s"(t_) : "s"((unsigned)(bal >> 32)), "n"(HI) : "scc"); exc32 |= t_; }
+            } else exceed |= bal & MASK;
+        };
+        auto over_all = [&](const unsigned long long bal) {
+            if constexpr (EXC32) exc32 |= (unsigned)bal | (unsigned)(bal >> 32); else exceed |= bal;
+        };
         // -- non-contact rows: sorted order (motors, then limits) on odd iterations, reversed on even ones --
         // HOISTED (this whole loop is compiled for known point counts): the per-pass delta vectors are never zeroed inside the loop -- the lanes a copy's rows write are the
         // same in every iteration and are rewritten before each commit, every other lane was zero at loop entry and stays so -- and the residual tests mask the ballot with the
@@ -1893,26 +1940,31 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         constexpr bool HOISTED = LSPEC != LOOP_GENERIC;
         constexpr int HCNT = HOISTED ? LSPEC % 100 : 0;
         constexpr unsigned long long MOTOR_LANES = (1ull << ND) - 1ull;
+        // the violated-limit mask, laundered through a scalar register once per iteration: the 18 per-row tests are then `s_bitcmp1_b32` + a scalar branch each.  Left
+        // loop-invariant, the compiler evaluated all 18 ahead of the loop as 64-bit condition masks, held -- and spilled into VGPR lanes, and re-read with a v_readlane
+        // pair in front of every row -- across the limit flavour of every loop copy (round 5: 705 / 433 spilled SGPRs in the f64 / f32 kernel, all of them here).
+        unsigned lm_it = lim_mask;
+        if constexpr (LIM_ROWS) asm volatile("" : "+s"(lm_it));
         if (ODD < 0 ? (it & 1) != 0 : ODD == 1) {
             pgs_motor_pass<FAST, false>(e, blo, bhi, dvec, Ar, lane);
             if constexpr (!HOISTED) { blo -= dvec; bhi -= dvec; exceed |= OVER(dvec); dvec = 0; }
-            if (LIM_ROWS && __builtin_expect(lim_mask != 0, 0)) {      // rare: kept out of the hot loop's instruction stream
+            if (LIM_ROWS && __builtin_expect(lm_it != 0, 0)) {      // rare: kept out of the hot loop's instruction stream
                 static_for<ND>([&](auto ic) {
                     constexpr int PP = NC_ORDER[decltype(ic)::value];
-                    if (lim_mask & (1u << PP)) pgs_row_signed<PP>(s.lim, e, diag, Ar[PP], lane, res_i);
+                    if (lm_it & (1u << PP)) pgs_row_signed<PP>(s.lim, e, diag, Ar[PP], lane, res_i);
                 });
             }
         } else {
-            if (LIM_ROWS && __builtin_expect(lim_mask != 0, 0)) {      // rare: kept out of the hot loop's instruction stream
+            if (LIM_ROWS && __builtin_expect(lm_it != 0, 0)) {      // rare: kept out of the hot loop's instruction stream
                 static_for<ND>([&](auto ic) {
                     constexpr int PP = NC_ORDER[ND - 1 - decltype(ic)::value];
-                    if (lim_mask & (1u << PP)) pgs_row_signed<PP>(s.lim, e, diag, Ar[PP], lane, res_i);
+                    if (lm_it & (1u << PP)) pgs_row_signed<PP>(s.lim, e, diag, Ar[PP], lane, res_i);
                 });
             }
             pgs_motor_pass<FAST, true>(e, blo, bhi, dvec, Ar, lane);
             if constexpr (!HOISTED) { blo -= dvec; bhi -= dvec; exceed |= OVER(dvec); dvec = 0; }
         }
-        if constexpr (HOISTED && HCNT == 0) { blo -= dvec; bhi -= dvec; exceed |= OVER(dvec); }        // airborne copy: only the motor lanes of dvec are ever written
+        if constexpr (HOISTED && HCNT == 0) { blo -= dvec; bhi -= dvec; over_all(OVER(dvec)); }        // airborne copy: only the motor lanes of dvec are ever written
         ISTAMP(1);
         if (LSPEC == LOOP_GENERIC ? act != 0u : (LSPEC % 100) > 0) {     // airborne: one branch skips every contact row
             // One copy of the contact section per set of touching feet (right, left, both), chosen here once per iteration: inside a copy
@@ -1937,7 +1989,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             });
             if constexpr (HOISTED) {
                 // motor and normal lanes together; bhi of an occupied normal lane is 1e30 (1e30 - d = 1e30), the lateral lanes' bounds are never read
-                blo -= dvec; bhi -= dvec; exceed |= OVER(dvec) & (MOTOR_LANES | normal_lanes(NR, NL));
+                blo -= dvec; bhi -= dvec; over_masked(OVER(dvec), std::integral_constant<unsigned long long, (MOTOR_LANES | normal_lanes(NR, NL))>{});
                 pin_order(bhi);     // here, not where the next motor pass reads it: the cone rows below overwrite dvec in place, and a pending use would cost a register copy per iteration
             } else {
                 blo -= dvec; exceed |= OVER(dvec); dvec = 0;     // bhi of a normal row is 1e30 or 0: unchanged
@@ -2015,10 +2067,10 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                 if constexpr (KMAX > 1) u1 += dv1;
                 if constexpr (KMAX > 2) u2 += dv2;
                 if constexpr (KMAX > 3) u3 += dv3;
-                if constexpr (KMAX == 1) exceed |= OVER(dv0);
-                else if constexpr (KMAX == 2) exceed |= OVER(max_(abs_(dv0), abs_(dv1)));
-                else if constexpr (KMAX == 3) exceed |= OVER(max_(max_(abs_(dv0), abs_(dv1)), abs_(dv2)));
-                else exceed |= OVER(absmax4(dv0, dv1, dv2, dv3));
+                if constexpr (KMAX == 1) over_all(OVER(dv0));
+                else if constexpr (KMAX == 2) over_all(OVER(max_(abs_(dv0), abs_(dv1))));
+                else if constexpr (KMAX == 3) over_all(OVER(max_(max_(abs_(dv0), abs_(dv1)), abs_(dv2))));
+                else over_all(OVER(absmax4(dv0, dv1, dv2, dv3)));
             }
             ISTAMP(5);
             // -- lateral friction, cone-coupled pairs --
@@ -2042,7 +2094,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                 real pair_sum;
                 if constexpr (FAST && sizeof(real) == 4) asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf" : "=v"(pair_sum) : "v"(dvec));
                 else pair_sum = dvec + shift_down1(dvec);
-                exceed |= OVER(pair_sum) & lateral_a_lanes(NR, NL);     // (the first lane of every pair the copy owns; motor and normal lanes of dvec hold this iteration's deltas)
+                over_masked(OVER(pair_sum), std::integral_constant<unsigned long long, lateral_a_lanes(NR, NL)>{});     // (the first lane of every pair the copy owns; motor and normal lanes of dvec hold this iteration's deltas)
                 u0 += dvec;                                                            // u0 means something in the torsional and lateral lanes only
             } else {
                 exceed |= OVER((dvec + shift_down1(dvec)) * selA);
@@ -2071,7 +2123,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         ISTAMP(6);
         ISTAMP(7);
         // (the rare scalar rows, joint limits, keep their max in res_i)
-        const bool stop = (res_i <= thr_i && exceed == 0) || it >= n_iter - 1;
+        const bool stop = (res_i <= thr_i && (EXC32 ? exc32 == 0u : exceed == 0)) || it >= n_iter - 1;
 #ifdef PLEN_SLIDE_STATS
         slide_iters += slide_now; slide_flips += (slide_now != slide_prev && it > 0) ? 1u : 0u; slide_prev = slide_now; slide_now = 0;
 #endif
@@ -2161,7 +2213,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             constexpr int J = decltype(jc)::value;
             if constexpr (has_desc(J)) {
                 const real xj = bcast(z * inv_diag_r, J);
-                z -= s.M[J][k] * xj;
+                z -= packed_col<J>(s.Mp, k) * xj;
             }
         });
         const real x = z * inv_diag_r;

@@ -18,4 +18,4 @@ if __name__ == "__main__":
                 print(lib, "FAILED", out.stderr[-300:]); continue
             d = json.loads(line[-1])
             print("%-28s pipelined %.3f M env-steps/s (%.4f ms/step)   one launch %.4f ms   kernel %.4f ms" % (
-                lib, d["value"] / 1e6, d["ms_per_step"], d["config"]["one_launch_per_step"]["ms_per_step"], d["kernel_ms_per_launch"]), flush=True)
+                lib, d["value"] / 1e6, d["ms_per_step"], d["config_detail"]["one_launch_per_step"]["ms_per_step"], d["kernel_ms_per_launch"]), flush=True)

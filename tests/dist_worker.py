@@ -56,6 +56,9 @@ def main():
     dist.all_gather(gathered, flat)
     res = {"rank": rank, "world": world, "same_across_ranks": bool(all(torch.equal(gathered[0], g) for g in gathered)),
            "slice": sharding.rank_env_slice(4096 * world + 3, world, rank),
+           "slice_exact": sharding.rank_env_slice(4096 * world, world, rank),          # configs[3]: 32768 envs over 8 ranks = 4096 each
+           "slice_strong": sharding.rank_env_slice(4096, world, rank),                 # the metric's literal "@4096 envs" in total (strong scaling)
+           "seed": sharding.rank_seed(1000, rank),
            "max_time": sharding.max_over_ranks(1.0 + rank, "cpu"), "sum_steps": sharding.sum_over_ranks(10 * (rank + 1), "cpu")}
     if rank == 0:
         # single-process reference: same initial parameters, the concatenated batch, no process group semantics needed

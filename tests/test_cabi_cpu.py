@@ -91,3 +91,21 @@ def test_generated_motor_pass_header_is_current(tmp_path):
     assert open(g.OUT).read() == committed
     order = g.nc_order()
     assert sorted(order) == list(range(18)) and "order: " + ", ".join(map(str, order)) in committed
+
+
+def test_env_kernels_stay_inside_their_register_budgets(lib):
+    """The compiler's resource report of the shipped library (build.py keeps it next to the .so): the env kernels run at the occupancy their design states with no scratch,
+    and the scalar registers spilled into VGPR lanes stay where round 6 brought them (f64 705 -> < 100, f32 433 -> < 150; round 5's were the 18 per-row condition masks of the
+    joint-limit rows, kept across all 50 limit-flavour copies of the solver loop).  A regression guard: a change that makes the compiler hold loop-invariant lane masks again
+    shows up here before it shows up as v_readlane traffic in the solver loops."""
+    import json
+    from plen_ml_walk_amd.build import RESOURCES
+    r = json.load(open(RESOURCES))
+    k = {(("f64" if "IdLb" in n else "f32"), ("fast" if "Lb1EE" in n else "compiler_rows")): v for n, v in r.items() if "plen_env_kernel" in n}
+    assert len(k) == 4, sorted(r)
+    for (dt, path), v in k.items():
+        assert v["ScratchSize"] == 0 and v["VGPRs Spill"] == 0, (dt, path, v)
+        assert v["Occupancy"] == (2 if dt == "f64" else 4), (dt, path, v)
+        assert v["LDS Size"] == (19872 if dt == "f64" else 9936), (dt, path, v)
+    assert k[("f64", "fast")]["SGPRs Spill"] < 100, k[("f64", "fast")]
+    assert k[("f32", "fast")]["SGPRs Spill"] < 250, k[("f32", "fast")]
