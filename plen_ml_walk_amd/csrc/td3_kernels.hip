@@ -362,7 +362,7 @@ __global__ void k_uniform_actions(const uint64_t *__restrict__ rng, float *__res
 
 // ---- K14: write one vector step into the replay ring (plen_td3.py:109-113): row (total + e) % capacity = s | a | s2 | r | 1 - done_bool,
 //      done_bool = compute_done() fired AND the time limit did not (PLENVEC_DONE_TERMINAL = 1, _TIMELIMIT = 2)
-__global__ void k_store(float *__restrict__ data, const int64_t *__restrict__ total, int64_t capacity, float *__restrict__ s, const float *__restrict__ a,
+__global__ void k_store(float *__restrict__ data, const int64_t *total, int64_t capacity, float *__restrict__ s, const float *__restrict__ a,
                         const float *__restrict__ s2, const float *__restrict__ r, const uint8_t *__restrict__ done, uint64_t *rng_bump,
                         float *__restrict__ ep_ret, double *stats, int n, const float *__restrict__ advance, int64_t *total_step, int64_t step, unsigned *blocks_done) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -370,10 +370,16 @@ __global__ void k_store(float *__restrict__ data, const int64_t *__restrict__ to
     const int e = t / TD3_ROW, c = t % TD3_ROW;
     // plentd3_store_step: *total += step once every block has read it -- the last block to get here does it (each block's first thread counts itself in after the
     // block's reads; the counter is left at zero for the next launch).  Replaces the caller's one-element add kernel on its critical path.
-    const int64_t total0 = total[0];
+    // (`total` and `total_step` are the SAME word in step mode: neither is restrict-qualified, the read is an atomic load -- not a load the compiler may treat as
+    // invariant and sink past the barrier --, and the hand-off is fenced like k_critic_block's: every block's read is ordered before its count, the last block's store
+    // after the count it saw.  ADVICE r05.)
+    const int64_t total0 = __hip_atomic_load(total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (blocks_done) {
         __syncthreads();
-        if (threadIdx.x == 0 && atomicAdd(blocks_done, 1u) == gridDim.x - 1) { blocks_done[0] = 0; total_step[0] = total0 + step; }
+        if (threadIdx.x == 0) {
+            __threadfence();
+            if (atomicAdd(blocks_done, 1u) == gridDim.x - 1) { __threadfence(); blocks_done[0] = 0; total_step[0] = total0 + step; }
+        }
     }
     if (e >= n) return;
     // episode bookkeeping at full speed (the reference prints every episode's return, plen_env.py:616-636): per-env running return; when the

@@ -397,7 +397,7 @@ class TD3Agent(object):
         self._fused = None
         self.fused_select = None     # select_action(): None = one-kernel forward on a HIP device (PLEN_TD3_FUSED_SELECT=0 turns it off), False = torch layers
         self._select_state = None
-        self.last_critic_loss = None
+        self.last_critic_loss = None          # 0-d device tensor of the last train() call; on the fused small-batch path a view of a persistent word, valid until the next call (copy to keep)
         self.last_actor_loss = None
 
     def _broadcast_parameters(self):

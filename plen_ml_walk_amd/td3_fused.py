@@ -283,7 +283,6 @@ class FusedTD3(object):
         self._partials = None
         self._big = {}               # "critic" / "actor" -> (partial gradients [chunks][stride], stride) of plentd3_wgrad_big
         self._big_pending = {}       # network -> chunks whose partial gradients still wait for their optimiser step (update() takes it with plentd3_adam_big)
-        self._hold_wgrad, self._held = False, None       # update_first_half() / update_second_half()
         self._eager = {}             # batch size -> the small-batch iteration's persistent scratch tensors and argument blocks (_update_team_eager)
         self.eager_cache = os.environ.get("PLEN_TD3_EAGER_CACHE", "1") == "1"
         # one rank, small batch, flat Adam: the optimiser step is taken inside the grouped weight-gradient kernel (plentd3_wgrad_adam_group).
@@ -411,6 +410,7 @@ class FusedTD3(object):
         self._actor_adam = FlatAdam(self.lib, ag.actor_optimizer, ag.actor, ag._actor_flat, ag._actor_grads)
         ag._critic_grads.zero(); ag._actor_grads.zero()
         self._zeroed = {"critic": True, "actor": True}            # gradient buckets known to be zero (left so by the last fused Adam step)
+        self._eager.clear()          # the cached small-batch argument blocks hold the PREVIOUS FlatAdam objects' step counters and moment pointers
 
     def _zero_grads(self, which):
         """Zero a gradient bucket before a backward pass unless the last Adam step already did.
@@ -508,6 +508,8 @@ class FusedTD3(object):
         self._fused_done.add("critic")
         self._zeroed["critic"] = True
         self._saved, self._team_pass, self._block_pass = saved, True, False
+        # NOTE: a VIEW of this cache entry's persistent loss word, rewritten by the next small-batch call -- valid until then.  Callers that keep losses across
+        # train() calls must copy (float(...) / .clone()); a clone here would put one more launch on a path that is host-bound at 63 us per call.
         ag.last_critic_loss = loss[0]
         if with_policy:
             self._zero_grads("actor")
@@ -537,32 +539,6 @@ class FusedTD3(object):
         finally:
             self._fuse = None            # (consent to the in-kernel Adam step never outlives the pass it was given for)
         return self._after_critic_backward(loss, with_policy, all_reduce, flat, fuse)
-
-    def update_first_half(self, data, B, total, guard=0):
-        """The large-batch iteration cut where its ONE big kernel ends (single rank, flat Adam): sampling, packing and the critic pass kernel here; the weight
-        gradients, both optimiser steps and the delayed policy update in update_second_half().  For a schedule that runs each half in the idle window of a
-        different collector stream (train_vec.PipelinedVecTD3Trainer, inline_update): 81 us and 28 / 87 us alone.  Returns the loss (device scalar)."""
-        assert self._critic_adam is not None and self._use_block(int(B))
-        self._fused_done = set()
-        self._hold_wgrad = True
-        try:
-            loss = self.critic_backward(data, int(B), None, total, guard)
-        finally:
-            self._hold_wgrad = False
-        assert self._held is not None
-        return loss
-
-    def update_second_half(self, loss, with_policy):
-        ag = self.agent
-        # (not cleared: once the first half is a replayed hipGraph its Python does not run again, and the tensors of its capture -- static addresses in the graph's
-        #  private pool -- are what every later capture of a second half has to see)
-        B, jobs = self._held
-        self._fuse = {"critic": ag._critic_target_flat.flat if with_policy else None}
-        try:
-            self._wgrad_big("critic", B, jobs)
-        finally:
-            self._fuse = None
-        return self._after_critic_backward(loss, with_policy, False, True, True)
 
     def _after_critic_backward(self, loss, with_policy, all_reduce, flat, fuse):
         ag = self.agent
@@ -841,10 +817,7 @@ class FusedTD3(object):
                 jobs = [(dq[:, 0:1], c2[:, :H], cr.fc3.weight.grad, None), (dq[:, 1:2], c2[:, H:], cr.fc6.weight.grad, None),
                         (dh2[:, :H], c1[:, :H], cr.fc2.weight.grad, cr.fc2.bias.grad), (dh2[:, H:], c1[:, H:], cr.fc5.weight.grad, cr.fc5.bias.grad),
                         (dh1, batch[:, :SA], gv["W14"], gv["b14"])]
-                if self._hold_wgrad:          # update_first_half(): the weight gradients are launched by update_second_half()
-                    self._held = (B, jobs)
-                else:
-                    self._wgrad_big("critic", B, jobs)
+                self._wgrad_big("critic", B, jobs)
                 self._saved = (batch[:, :S], sa_pi, B)
                 self._probe(4)
                 return loss[0]

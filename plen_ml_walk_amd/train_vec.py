@@ -474,15 +474,6 @@ class PipelinedVecTD3Trainer(object):
         self.ep_ret = [torch.zeros(self.nh, 2, device=dev) for _ in range(self.H)]                    # running return / length of every env
         self.ep_stats = torch.zeros(3, dtype=torch.float64, device=dev)                                                    # finished episodes: sum of returns, count, sum of lengths
         self._critic_loss = torch.zeros((), device=dev)
-        # inline update (round 5, an experiment kept behind PLEN_TD3_INLINE_UPDATE=1): the update's two halves run IN the collector streams, each right after that
-        # collector's env launch -- when its 2048 wave slots are free and before its next launch needs them -- instead of on a third stream beside two resident
-        # launches, where every slot the update holds delays an env wave that then needs its whole lifetime.  It does what it was built for (env
-        # launches 435 -> 331 / 379 us) and gains nothing: each collector's chain now carries a second graph launch (~24 us of gap each) and its half of the
-        # update (136 / 58 us beside the other collector's launch): 8.11 against 8.22 M env-steps/s.  Single rank, two collectors, large batch.
-        self.inline_update = (not self.collectives and self.H == 2 and self.fused._use_block(batch_size) and self.fused._critic_adam is not None
-                              and os.environ.get("PLEN_TD3_INLINE_UPDATE", "0") == "1")
-        self._ev_a = {}
-        self._loss_a = None
         self.t = 0
         self.learning = True                   # False: the collectors alone, acting with the (then frozen) policy -- what the loop costs without its learner
         self.env_steps = self.grad_steps = 0
@@ -533,17 +524,6 @@ class PipelinedVecTD3Trainer(object):
         self._stamp(self.total_u, 4 * self.H + 5)
         self._finish(buf_out)
 
-    # the update as two halves for the collector streams (inline_update)
-    def _update_a(self):
-        self._stamp(self.total_u, 4 * self.H)
-        self._loss_a = self.fused.update_first_half(self.replay.data, self.batch_size, self.total_u, guard=2 * self.n)
-        self._critic_loss.copy_(self._loss_a)
-
-    def _update_b(self, with_policy, buf_out):
-        self.fused.update_second_half(self._loss_a, with_policy)
-        self._stamp(self.total_u, 4 * self.H + 5)
-        self._finish(buf_out)
-
     def _finish(self, buf_out):
         self.total_u += self.n
         self.bflat[buf_out].flat.copy_(self.agent._actor_flat.flat)
@@ -573,14 +553,13 @@ class PipelinedVecTD3Trainer(object):
         torch.cuda.synchronize()
         self._graphs.clear(); self._eager_runs.clear()
 
-    def _run(self, key, stream, fn, *args, after=None):
-        """fn(*args) on `stream`: eagerly the first two times the key is seen, then as a replay of its graph captured on that stream.  after: a key whose graph must
-        exist before this one is captured (its tensors are this one's inputs: they have to be the static ones of that capture); eager until then."""
+    def _run(self, key, stream, fn, *args):
+        """fn(*args) on `stream`: eagerly the first two times the key is seen, then as a replay of its graph captured on that stream."""
         with torch.cuda.stream(stream):
             g = self._graphs.get(key)
             if g is None:
                 runs = self._eager_runs.get(key, 0)
-                if runs < 2 or (after is not None and after not in self._graphs):
+                if runs < 2:
                     fn(*args)
                     self._eager_runs[key] = runs + 1
                     return
@@ -602,25 +581,6 @@ class PipelinedVecTD3Trainer(object):
             self._run(("collect", h, warm, (t - 1) % 3), s, self._collect, h, warm, (t - 1) % 3)
             e = torch.cuda.Event(); e.record(s); self._ev_col[(h, t)] = e
         su = self.su
-        if learn and self.inline_update:
-            with_policy = (self.grad_steps + 1) % self.agent.policy_freq == 0
-            s0, s1 = self.streams
-            # first half on collector 0's stream, behind its own collect step t: needs the rows of step t - 1 (both collectors) and the parameters of update t - 1
-            for ev in (self._ev_col.get((1, t - 1)), self._ev_upd.get(t - 1)):
-                if ev is not None:
-                    s0.wait_event(ev)
-            self._run(("update_a",), s0, self._update_a)
-            e = torch.cuda.Event(); e.record(s0); self._ev_a[t] = e
-            # second half on collector 1's stream, behind ITS collect step t
-            s1.wait_event(e)
-            self._run(("update_b", with_policy, (t + 1) % 3), s1, self._update_b, with_policy, (t + 1) % 3, after=("update_a",))
-            e = torch.cuda.Event(); e.record(s1); self._ev_upd[t] = e
-            self.grad_steps += 1
-            self.agent.total_it = self.grad_steps
-            for k in [k for k in self._ev_a if k < t - 3]:
-                del self._ev_a[k]
-            self._step_tail(t, n)
-            return
         for h in range(self.H):
             ev = self._ev_col.get((h, t - 1))
             if ev is not None:

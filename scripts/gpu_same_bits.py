@@ -10,11 +10,12 @@ code = ("import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
         "g = torch.Generator().manual_seed(5); acts = (torch.rand(40, 512, 18, generator=g) * 2 - 1).float().cuda()\n"
         "lim = sys.argv[3] == 'limits'\n"
         "if lim: acts = acts * 2.6\n"
-        "env = PlenVecEnv(512, dtype=getattr(torch, sys.argv[2]), joint_act=lim); env.reset()\n"
+        "env = PlenVecEnv(512, dtype=getattr(torch, sys.argv[2]), joint_act=lim, auto_reset=(sys.argv[3] != 'fallen')); env.reset()\n"
         "for t in range(40):\n"
         "    o, r, d, _ = env.step(acts[t]); out.append(torch.cat([o, r[:, None], d.to(o.dtype)[:, None]], 1).cpu().numpy().copy())\n"
         "np.save(sys.argv[1], np.array(out)); np.save(sys.argv[1] + '.state.npy', env.get_state().cpu().numpy())\n" % ROOT)
-for dt, mode in (("float32", "reference"), ("float64", "reference"), ("float32", "limits"), ("float64", "limits")):
+# fallen: no auto-reset, the robots fall and stay down -- links other than the feet on the ground, contact slots lent to their box corners (ports on another limb's support)
+for dt, mode in (("float32", "reference"), ("float64", "reference"), ("float32", "limits"), ("float64", "limits"), ("float32", "fallen"), ("float64", "fallen")):
     res = {}
     for tag in ("-", sys.argv[1]):
         env = dict(os.environ)
@@ -25,4 +26,4 @@ for dt, mode in (("float32", "reference"), ("float64", "reference"), ("float32",
     a, b = res["-"], res[sys.argv[1]]
     q = a[1][:, 13:31]
     print(dt, mode, "outputs bitwise equal:", np.array_equal(a[0], b[0], equal_nan=True), " states:", np.array_equal(a[1], b[1], equal_nan=True),
-          " envs with a joint beyond +-1.7 rad at the end: %d of %d" % (int((np.abs(q) > 1.7).any(1).sum()), q.shape[0]), flush=True)
+          " envs with a joint beyond +-1.7 rad at the end: %d of %d; torso below 0.08 m: %d" % (int((np.abs(q) > 1.7).any(1).sum()), q.shape[0], int((a[1][:, 2] < 0.08).sum())), flush=True)
