@@ -72,11 +72,11 @@ def build_td3_kernels(force=False):
     return TD3_OUT
 
 
-# The A/B partner of the shipped env library (csrc/variants/nospec.so; tests/test_env_gpu.py holds the two to bitwise equality): the same source with rounds 1-3's run-time
-# contact-point tests in the solver loop instead of the count-specialised loops with their hoisted commits.  (Through round 5 the twin also built the Delassus matrix as
-# vector multiply-adds from broadcast LDS reads, bit-identical to the matrix-core tiles; that build needed the dense 24-row Y buffer, which round 6's 12-slot layout
-# replaced.  Not the mass matrix either: -DPLENVEC_MFMA_MASS=0 changes how the compiler contracts the rest of that phase, so that pair is equal to rounding, not to the bit.)
-REFERENCE_FORM_FLAGS = ["-DPLENVEC_COUNT_SPECIALISED=0"]
+# The A/B partner of the shipped env library (csrc/variants/nospec.so; tests/test_env_gpu.py holds the two to bitwise equality): every round-4/5 restructuring switched off --
+# run-time point tests instead of the count-specialised solver loops (with their hoisted commits), the Delassus matrix as vector multiply-adds from broadcast LDS reads instead of
+# matrix-core tiles.  (Not the mass matrix: -DPLENVEC_MFMA_MASS=0 changes how the compiler contracts the rest of that phase -- even the bias force, which the switch does not
+# touch, moves in its last bit -- so that pair of builds is equal to rounding, not to the bit: scripts/gpu_twin_check.py.)
+REFERENCE_FORM_FLAGS = ["-DPLENVEC_COUNT_SPECIALISED=0", "-DPLENVEC_MFMA_DELASSUS=0"]
 
 
 def build_variant(name, defines=()):

@@ -50,7 +50,7 @@
 #ifndef WPE32
 #define WPE32 4        // waves per SIMD the f32 kernel is register-allocated for
 #endif
-#define YSLOTS 12       // rows of the Y buffer: a port's Jacobian / Y column has entries only in the six base coordinates and in the (<= 6) coordinates of ONE limb
+#define YTS 52          // row stride of the transposed Y buffer (48 ports + pad: conflict-free b128 row reads)
 
 // ------------------------------------------------------------------------------------------------
 // state record (real[64]):  0-2 pos | 3-6 quat xyzw | 7-9 omega | 10-12 vel | 13-30 q | 31-48 qd |
@@ -100,37 +100,6 @@ static constexpr unsigned ANC[NV] = {
 // L[r][i] of the factor M = L^T L can be nonzero only when DoF i (< r) supports DoF r
 static constexpr bool l_nz(int r, int i) { return i < r && ((ANC[r] >> i) & 1u); }
 static constexpr bool has_desc(int i) { for (int r = i + 1; r < NV; r++) if (l_nz(r, i)) return true; return false; }
-// Packed storage of the mass matrix / its factor in LDS (round 6: 4608 -> 1536 B in f64, one of the two cuts a third f64 wave per SIMD needs): the DoFs R that DoF i
-// supports are CONTIGUOUS, i < R <= row_end(i) (every DoF for a base coordinate, the rest of its own chain for a joint), so row i is kept as the run (i, i) .. (i, row_end(i))
-// at offset row_p0(i): 183 entries instead of 576.  Entries outside a run are structural zeros -- what the dense buffer stored as +0 and every read below now supplies.
-__host__ __device__ constexpr int row_end(int i) { return i < 6 ? NV - 1 : i < 12 ? 11 : i < 18 ? 17 : i < 21 ? 20 : 23; }
-static constexpr int row_p0(int i) { int s_ = 0; for (int j = 0; j < i; j++) s_ += row_end(j) - j + 1; return s_; }
-// the same in closed form, for a lane's own row (runs of lengths 24..19 | 6..1 | 6..1 | 3..1 | 3..1): a handful of integer instructions where a table in constant memory
-// is a vector load whose latency sits in front of the factorization
-__host__ __device__ constexpr int row_p0_cf(int i) {
-    const int g0 = i < 6 ? 0 : i < 12 ? 6 : i < 18 ? 12 : i < 21 ? 18 : 21, G = i < 6 ? 0 : i < 12 ? 129 : i < 18 ? 150 : i < 21 ? 171 : 177, L0 = i < 6 ? 24 : i < 18 ? 6 : 3;
-    const int j = i - g0;
-    return G + L0 * j - j * (j - 1) / 2;
-}
-// DoFs r <= k that support DoF k, k itself included (c_anc[k] without the base coordinates above a base k, computed): the base coordinates and the joints of k's chain up to k
-__host__ __device__ constexpr unsigned anc_cf(int k) { return k < 6 ? (2u << k) - 1u : 0x3fu | (((2u << k) - 1u) & ~((1u << (k < 12 ? 6 : k < 18 ? 12 : k < 21 ? 18 : 21)) - 1u)); }
-// Limbs (the four chains of the tree): 0 right leg (coordinates 6..11, joint ports 0..5, right-foot ports), 1 left leg (12..17, ports 6..11, left-foot ports), 2 right arm
-// (18..20), 3 left arm (21..23).  Y = L^-T J^T of a port is nonzero only in the base coordinates and in the coordinates of the limb its body hangs on (the port's "limb";
-// a contact slot lent to a box corner of another link takes that link's limb), so the LDS copy keeps 12 rows -- slot j < 6: coordinate j; slot 6 + i: coordinate
-// limb_base(limb of the port) + i -- instead of 24 (round 6: 9984 -> 4800 B in f64, the second cut the third f64 wave per SIMD needs).
-__host__ __device__ constexpr int limb_base(int c) { return c == 0 ? 6 : c == 1 ? 12 : c == 2 ? 18 : 21; }
-__host__ __device__ constexpr int limb_of_coord(int j) { return j < 12 ? 0 : j < 18 ? 1 : j < 21 ? 2 : 3; }      // j >= 6
-__host__ __device__ constexpr int limb_of_body(int b) { return b <= 6 ? 0 : b <= 12 ? 1 : b <= 15 ? 2 : 3; }     // b >= 1 (body b moves with coordinate 5 + b)
-#define MPK 192          /* reals in the packed buffer: 183 entries, rounded up to the 24 x 8 the mass-matrix operands are staged in */
-static constexpr bool packed_rows_are_the_support() {
-    for (int i = 0; i < NV; i++) {
-        if (row_p0_cf(i) != row_p0(i) || anc_cf(i) != (ANC[i] & ((2u << i) - 1u))) return false;
-        for (int r = 0; r < NV; r++) if ((((anc_cf(i) & ~(1u << i)) >> r) & 1u) != (l_nz(i, r) ? 1u : 0u)) return false;          // the bits below i: exactly the entries (r, i) of the factor
-        for (int r = 0; r < NV; r++) if (l_nz(r, i) != (i < r && r <= row_end(i))) return false;
-    }
-    return row_p0(NV - 1) + 1 <= MPK;
-}
-static_assert(packed_rows_are_the_support(), "the packed rows of M / L must be exactly the kinematic tree's supports");
 // plen_env.py:148-167
 __device__ __constant__ double c_range_lo[ND] = {-1.57, -0.15, -0.95, -0.9, -0.95, -0.8, -1.57, -1.5, -0.75, -0.3, -1.2, -0.4, -1.57, -0.15, -0.2, -1.57, -0.15, -0.2};
 __device__ __constant__ double c_range_hi[ND] = {1.57, 1.5, 0.75, 0.3, 1.2, 0.4, 1.57, 0.15, 0.95, 0.9, 0.95, 0.8, 1.57, 1.57, 0.35, 1.57, 1.57, 0.35};
@@ -195,7 +164,6 @@ __device__ inline float sin_(float x) { return __sinf(x); }
 // their ~20 polynomial coefficients out of the substep loop into VGPRs that then stay reserved for the whole kernel (that was the f64
 // kernel's scratch: 8 spilled VGPRs); here every coefficient is laundered through a scalar register at its use.
 __device__ __forceinline__ double kc_(double c) { asm volatile("" : "+s"(c)); return c; }
-__device__ __forceinline__ float kc_(float c) { return c; }          // (f32 literals are instruction operands: nothing to keep out of the vector registers)
 __device__ __forceinline__ void sincos_bounded(double x, double &sn, double &cs) {
     const double k = __builtin_rint(x * kc_(0.63661977236758138243));              // 2/pi
     const double r = __builtin_fma(-k, kc_(6.12323399573676603587e-17), __builtin_fma(-k, kc_(1.57079632679489655800), x));     // x - k pi/2 (hi, lo)
@@ -251,22 +219,6 @@ __device__ __forceinline__ float keep_if(float v, unsigned mask, int b) {
     return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & m);
 }
 __device__ __forceinline__ double keep_if(double v, unsigned mask, int b) { return ((mask >> b) & 1u) ? v : 0.0; }
-// the same as bit operations on both halves (v_bfe_i32 + two v_and_b32; the select above is a compare and two v_cndmask behind the bit test)
-__device__ __forceinline__ float keep_bits(float v, unsigned mask, int b) { return keep_if(v, mask, b); }
-__device__ __forceinline__ double keep_bits(double v, unsigned mask, int b) {
-    const int m = __builtin_amdgcn_sbfe((int)mask, (unsigned)b, 1u);       // 0 or -1
-    const long long x = __builtin_bit_cast(long long, v);
-    const int lo = (int)(x & 0xffffffffLL) & m, hi = (int)(x >> 32) & m;
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-}
-// entry (J, k) of the packed factor for this lane's DoF k, J a compile-time row: L[k][J] if J supports k, else the structural zero the dense buffer held there
-// (`below`: the DoFs below k that support it, anc_cf(k) & ~(1 << k), or 0 for a lane without a DoF.  The word is read whatever the lane -- every k lands inside the buffer --
-// and masked: no address arithmetic per entry)
-template <int J, typename real>
-__device__ __forceinline__ real packed_col(const real *Mp, const int k, const unsigned below) {
-    static_assert(row_p0(J) - J >= 0 && row_p0(J) - J + NV - 1 < MPK, "every lane's read stays inside the packed buffer");
-    return keep_bits(Mp[row_p0(J) - J + k], below, J);
-}
 // wave-uniform broadcast of lane `l` (l must be wave-uniform)
 __device__ inline float bcast(float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); }
 __device__ inline double bcast(double x, int l) {
@@ -760,7 +712,7 @@ __device__ __forceinline__ void pgs_cone(real &e, const real u, real &dvec, cons
             const real y0 = __builtin_amdgcn_rsq(len2);
             const real a_ = len2 * y0, ly0 = lmv * y0;
             const real r_ = __builtin_fma(-a_, y0, (real)1);
-            const real p_ = __builtin_fma(r_, kc_((real)0.375), (real)0.5), lr = ly0 * r_;
+            const real p_ = __builtin_fma(r_, (real)0.375, (real)0.5), lr = ly0 * r_;
             asm("v_fma_f64 %0, %1, %2, %3 clamp" : "=v"(scale) : "v"(lr), "v"(p_), "v"(ly0));      // clamp(., 0, 1) as the fma's output modifier (see the f32 branch above)
         }
 #else
@@ -842,9 +794,6 @@ template <typename real> __device__ inline void matvec3(real *o, const real *M, 
 // ---------------------------------------------------------------- LDS layout (one wave = one env)
 template <typename real>
 struct Smem {
-    // row stride of the Y buffer: 48 ports + pad, chosen so that the twelve rows start 4 banks apart modulo 64 (phase H: lane k reads row slot(k), b128) -- f64: 100 words
-    // per row = 36 (mod 64), f32: 52
-    static constexpr int YSS = sizeof(real) == 8 ? 50 : 52;
     real st[REC];
     real tgt[NV];
     union {
@@ -854,7 +803,7 @@ struct Smem {
         };
         real park[4][64];       // phases F, G (frames are dead after the collision pass): per-lane values parked out of registers (port velocity, distance, restitution, friction)
     };
-    alignas(16) real Mp[MPK];   // mass matrix, later its factor: row i = the entries (i, i .. row_end(i)), packed (row_p0); before that the staged operands of the mass-matrix product
+    alignas(16) real M[NV][NV]; // mass matrix, later its Cholesky factor L (lower); rows read as broadcast b128
     real v[NV];         // generalized velocity after the unconstrained update
     real col[NV];       // broadcast buffer
     real lamP[NPORT];
@@ -867,9 +816,8 @@ struct Smem {
             real S[NV][8];      // motion subspace about the base origin: [angular; linear]
             real tau[NV];
         };
-        alignas(16) real YS[YSLOTS][YSS];  // J, then Y = L^-T J^T, slot-major: YS[slot][port] (slots: see limb_base above); during phase F the staged tiles of the Delassus product
+        alignas(16) real YT[NV][YTS];  // J, then Y = L^-T J^T, coordinate-major: YT[j][port]
     };
-    int plimb[NPORT];   // limb of each port's support (static except for contact slots lent to another link's box corner)
 };
 
 
@@ -1138,7 +1086,7 @@ __device__ __forceinline__ void euler_from_quat(const real *q, real *rpy) {   //
 // joints that moves the box's body).  The rule and its tie-breaks are spelled out in DESIGN.md (contact model); the test oracle states the same.
 template <typename real>
 __device__ __forceinline__ void box_contacts(Smem<real> &s, const DevParams<real> &P, const int lane, const unsigned near, unsigned &act, unsigned &lent,
-                                             const bool is_lin, const int pf, const int pk, const int pax, const int p, int &plimb, const real (&O0)[3],
+                                             const bool is_lin, const int pf, const int pk, const int pax, const int p, const real (&O0)[3],
                                              real &dist, real (&Pw)[3], real &rest_l, real &mu_l) {
     const real BIG = (real)1e30;
     int xb = -1;
@@ -1190,19 +1138,16 @@ __device__ __forceinline__ void box_contacts(Smem<real> &s, const DevParams<real
         rest_l = d[4]; mu_l = P.mu_box;
         const real ax[3] = {pax == 2 ? (real)1 : (real)0, pax == 1 ? (real)-1 : (real)0, pax == 0 ? (real)1 : (real)0};
 #pragma unroll
-        for (int j = 0; j < YSLOTS; j++) s.YS[j][p] = 0;
+        for (int j = 0; j < NV; j++) s.YT[j][p] = 0;
         real r[3] = {Pw[0] - O0[0], Pw[1] - O0[1], Pw[2] - O0[2]}, t1[3];
         cross3(t1, r, ax);
 #pragma unroll
-        for (int i = 0; i < 3; i++) { s.YS[i][p] = t1[i]; s.YS[3 + i][p] = ax[i]; }
-        const int cb = (int)d[3];
-        if (cb > 0) plimb = limb_of_body(cb);          // the port now hangs on the box's limb (a box of the base link: base coordinates only, any limb will do)
-        const int lb = limb_base(plimb);
-        for (int bb = cb; bb > 0; bb = c_parent[bb]) {          // the joints that move the box's body
+        for (int i = 0; i < 3; i++) { s.YT[i][p] = t1[i]; s.YT[3 + i][p] = ax[i]; }
+        for (int bb = (int)d[3]; bb > 0; bb = c_parent[bb]) {          // the joints that move the box's body
             const real a[3] = {s.CA[bb][4], s.CA[bb][5], s.CA[bb][6]};
             const real rr[3] = {Pw[0] - s.RO[bb][9], Pw[1] - s.RO[bb][10], Pw[2] - s.RO[bb][11]};
             cross3(t1, rr, ax);
-            s.YS[6 + (5 + bb - lb)][p] = dot3(a, t1);
+            s.YT[5 + bb][p] = dot3(a, t1);
         }
     }
     act |= lent;
@@ -1269,7 +1214,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         for (int i = 0; i < 3; i++) f[i] = cm * Sk[3 + i] + t1[i];
 #if PLENVEC_MFMA_MASS
         // M = S (I S)^T on the matrix cores (below, outside this branch): this lane's column of I S -- n | f -- goes to LDS next to S, in the M buffer (free until the results land)
-        real *nf_row = &s.Mp[0] + 8 * k;
+        real *nf_row = &s.M[0][0] + 8 * k;
 #pragma unroll
         for (int i = 0; i < 3; i++) { nf_row[i] = n[i]; nf_row[3 + i] = f[i]; }
 #else
@@ -1280,7 +1225,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
 #pragma unroll
         for (int r = 0; r < NV; r++) {
             const real val = s.S[r][0] * n[0] + s.S[r][1] * n[1] + s.S[r][2] * n[2] + s.S[r][3] * f[0] + s.S[r][4] * f[1] + s.S[r][5] * f[2];
-            if ((keep >> r) & 1u) s.Mp[row_p0(r) + k - r] = val;
+            s.M[r][k] = keep_if(val, keep, r);
         }
 #endif
         // generalized bias force (motors are constraints, so no joint torque here)
@@ -1304,7 +1249,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         // column -- where rounds 1-4 had every lane read all of S as 72 wave-wide broadcasts for 144 multiply-adds.  The matrix instruction adds i = 0..5 in order, like the old sum.
         using acc4 = real __attribute__((ext_vector_type(4)));
         const int c16 = lane & 15, g4 = lane >> 4;
-        const real *nfb = &s.Mp[0];
+        const real *nfb = &s.M[0][0];
         real oS[2][2], oN[2][2];
 #pragma unroll
         for (int t = 0; t < 2; t++)
@@ -1332,23 +1277,24 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         }
         // column masks: M[r][k] is kept for the DoFs r <= k that support k, +0 elsewhere (phase C factors the upper triangle in place and relies on the zeros)
         const int k0 = c16, k1 = 16 + (c16 & 7);
-        const unsigned keep0 = anc_cf(k0), keep1 = anc_cf(k1);          // (no bit above the column's own)
+        const unsigned keep0 = c_anc[k0] & ((2u << k0) - 1u), keep1 = c_anc[k1] & ((2u << k1) - 1u);
         const bool col1 = c16 < 8;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int rl = sizeof(real) == 8 ? g4 + 4 * j : 4 * g4 + j;          // row inside the tile
-            const int pa = row_p0_cf(rl) - rl;                                    // (row, column) of a kept entry lives at row_p0(row) + column - row
-            if ((keep0 >> rl) & 1u) s.Mp[pa + k0] = d00[j];
-            if (col1 && ((keep1 >> rl) & 1u)) s.Mp[pa + k1] = d01[j];
-            const int r2 = 16 + (rl & 7);
-            if (rl < 8 && col1 && ((keep1 >> r2) & 1u)) s.Mp[row_p0_cf(r2) - r2 + k1] = d11[j];      // (rows 16..23 have no entries in columns 0..15: below the diagonal)
+            s.M[rl][k0] = keep_if(d00[j], keep0, rl);
+            if (col1) s.M[rl][k1] = keep_if(d01[j], keep1, rl);
+            if (rl < 8) {
+                s.M[16 + rl][k0] = 0;                                              // rows 16..23, columns 0..15: below the diagonal
+                if (col1) s.M[16 + rl][k1] = keep_if(d11[j], keep1, 16 + rl);
+            }
         }
     }
     WSYNC();
 #endif
     if (dump && lane < NV) {
 #pragma unroll
-        for (int r = 0; r < NV; r++) { const int a_ = r <= lane ? r : lane, b_ = r <= lane ? lane : r; dump[r * NV + lane] = b_ <= row_end(a_) ? s.Mp[row_p0_cf(a_) + b_ - a_] : (real)0; }
+        for (int r = 0; r < NV; r++) dump[r * NV + lane] = r <= lane ? s.M[r][lane] : s.M[lane][r];
         dump[576 + lane] = s.tau[lane];
     }
 
@@ -1360,10 +1306,8 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     // diagonal is kept as its reciprocal (inv_diag) and stored as 0, which makes every triangular solve
     // below a plain  broadcast + fma  per column, without lane predicates.
     real Lr[NV];
-    const int row_a = row_p0_cf(k) - k;                                                                        // this lane's packed row: (k, j) at row_a + j for k <= j <= row_end(k)
-    const unsigned row_m = lane < NV ? (((2u << row_end(k)) - 1u) & ~((1u << k) - 1u)) : 0u;           // ... as a mask over j
 #pragma unroll
-    for (int j = 0; j < NV; j++) Lr[j] = keep_bits(s.Mp[row_a + j], row_m, j);          // (every lane's read stays inside the buffer; what is not its row's is masked to +0)
+    for (int j = 0; j < NV; j++) Lr[j] = lane < NV ? s.M[k][j] : (real)0;
     static_for<NV>([&](auto kc) {
         constexpr int K = NV - 1 - decltype(kc)::value;
         const real piv = bcast(Lr[K], K);
@@ -1388,8 +1332,10 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             });
         }
     });
+    if (lane < NV) {
 #pragma unroll
-    for (int j = 0; j < NV; j++) if ((row_m >> j) & 1u) s.Mp[row_a + j] = Lr[j];      // packed row i: L[r][i] for the DoFs r that i supports (strictly upper part of L^T), zero diagonal
+        for (int j = 0; j < NV; j++) s.M[k][j] = Lr[j];      // s.M[i][r] = L[r][i] (strictly upper part of L^T, zero diagonal)
+    }
     WSYNC();
     const real inv_diag = lane < NV ? s.col[k] : (real)0;    // 1 / L[lane][lane]
     STAMP();
@@ -1405,14 +1351,13 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             bi -= Lr[J] * yj;
         });
         real yv = bi * inv_diag;
-        const unsigned below_k = lane < NV ? anc_cf(k) & ~(1u << k) : 0u;
         WSYNC();
         // L x = y, ascending: lane r needs column r of L^T, read from LDS
         static_for<NV>([&](auto jc) {
             constexpr int J = decltype(jc)::value;
             if constexpr (has_desc(J)) {
                 const real xj = bcast(yv * inv_diag, J);
-                yv -= packed_col<J>(s.Mp, k, below_k) * xj;
+                yv -= s.M[J][k] * xj;
             }
         });
         const real x = yv * inv_diag;
@@ -1424,7 +1369,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     WSYNC();
     if (dump && lane < NV) {
 #pragma unroll
-        for (int r = 0; r < NV; r++) dump[640 + lane * NV + r] = r == lane ? (real)1 / inv_diag : (r < lane && lane <= row_end(r)) ? s.Mp[row_p0(r) + lane - r] : (real)0;    // L[lane][r]
+        for (int r = 0; r < NV; r++) dump[640 + lane * NV + r] = r == lane ? (real)1 / inv_diag : s.M[r][lane];    // L[lane][r]
         dump[600 + lane] = s.v[lane];
     }
 
@@ -1434,7 +1379,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     // ---------------- E. collision (feet vs ground) and port Jacobians ----------------
     // port p: 0..17 joint d | 18+15f+{0,1,2} foot f torsional (n, dir1, dir2) | 18+15f+3+3k+{0,1,2} point k linear; lanes: lane_of_port()
     // (not const: re-derived from the fresh lane id after phase F, so that none of them lives through it)
-    int p, pf, pl, pk, pax, plimb;
+    int p, pf, pl, pk, pax;
     bool is_joint, is_tors, is_lin, valid_port;
 #define LANE_ROLES() do { \
         is_joint = lane < ND; \
@@ -1449,7 +1394,6 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         pl = is_tors ? pax : 3 + 3 * pk + pax;                      /* 0..14 within foot */ \
         valid_port = is_joint || is_tors || is_lin; \
         p = is_joint ? lane : (valid_port ? 18 + 15 * pf + pl : 0); \
-        plimb = is_joint ? (lane < 6 ? 0 : lane < 12 ? 1 : lane < 15 ? 2 : 3) : pf;     /* limb of the port's support (static value; lent slots: s.plimb) */ \
     } while (0)
     // Foot manifolds.  The 32 sole-plane hull vertices of each foot sit one per lane (lane = 32 f + v); candidates are the representatives
     // of the outline's 8 corner fillets (Bullet merges manifold points closer than the breaking threshold), in range while their
@@ -1511,9 +1455,9 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     // latency (2.1 k of phase E's 17.5 k cycles in f64, scripts/gpu_phase_e_stamps.py)
     if (valid_port) {
 #pragma unroll
-        for (int j = 0; j < YSLOTS; j++) s.YS[j][p] = 0;
+        for (int j = 0; j < NV; j++) s.YT[j][p] = 0;
     }
-    if (is_joint) s.YS[6 + (6 + p - limb_base(plimb))][p] = 1;
+    if (is_joint) s.YT[6 + p][p] = 1;
     if (is_tors || is_lin) {
         real ax[3] = {pax == 2 ? (real)1 : (real)0, pax == 1 ? (real)-1 : (real)0, pax == 0 ? (real)1 : (real)0};
         if (is_lin) {
@@ -1526,10 +1470,10 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             real r[3] = {Pw[0] - O0[0], Pw[1] - O0[1], Pw[2] - O0[2]}, t1[3];
             cross3(t1, r, ax);
 #pragma unroll
-            for (int i = 0; i < 3; i++) { s.YS[i][p] = t1[i]; s.YS[3 + i][p] = ax[i]; }
+            for (int i = 0; i < 3; i++) { s.YT[i][p] = t1[i]; s.YT[3 + i][p] = ax[i]; }
         } else {
 #pragma unroll
-            for (int i = 0; i < 3; i++) s.YS[i][p] = ax[i];
+            for (int i = 0; i < 3; i++) s.YT[i][p] = ax[i];
         }
         for (int i = 0; i < 6; i++) {           // the six leg joints that move this foot
             const int b = fb - 5 + i;
@@ -1540,7 +1484,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                 cross3(t1, r, ax);
                 val = dot3(a, t1);
             } else val = dot3(a, ax);
-            s.YS[6 + i][p] = val;          // coordinate 5 + b = limb_base(this foot's leg) + i
+            s.YT[5 + b][p] = val;
         }
     }
     // act: occupied-slot mask in manifold order (right foot points 0..3, left foot 4..7), so far the foot points
@@ -1573,25 +1517,17 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             // its port lanes still hold that point's Jacobian.
             const unsigned released = act == 0xffu ? 0x88u : 0u;
             act &= ~released;
-            box_contacts(s, P, lane, near, act, lent, is_lin, pf, pk, pax, p, plimb, O0, dist, Pw, rest_l, mu_l);
+            box_contacts(s, P, lane, near, act, lent, is_lin, pf, pk, pax, p, O0, dist, Pw, rest_l, mu_l);
             act |= released;
         }
     }
     ESTAMP(3);          // box near test (+ rare path)
     lent_out = lent | (act << 8);          // bits 0-7: slots lent to box corners, bits 8-15: slots holding a contact point
-    if (valid_port) s.plimb[p] = plimb;
     WSYNC();
     // own Jacobian row into registers, b = J v*, then Y = L^-T J^T by back substitution (A = J M^-1 J^T = Y^T Y)
     real Jr[NV];
 #pragma unroll
-    for (int j = 0; j < 6; j++) Jr[j] = s.YS[j][p];        // (lanes that host no port read column 0: their results are never stored)
-#pragma unroll
-    for (int i = 0; i < 6; i++) {                          // the port's limb slots go to that limb's coordinates, every other coordinate is a structural zero
-        const real v_ = s.YS[6 + i][p];
-        Jr[6 + i] = plimb == 0 ? v_ : (real)0;
-        Jr[12 + i] = plimb == 1 ? v_ : (real)0;
-        if (i < 3) { Jr[18 + i] = plimb == 2 ? v_ : (real)0; Jr[21 + i] = plimb == 3 ? v_ : (real)0; }
-    }
+    for (int j = 0; j < NV; j++) Jr[j] = s.YT[j][p];       // (lanes that host no port read column 0: their results are never stored)
     ESTAMP(4);          // Jacobian rows into registers
     real bvel = 0;
 #pragma unroll
@@ -1599,9 +1535,8 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     // (the inverse diagonal of L is in s.col since phase C)
     ESTAMP(5);          // port velocities
     // L^T y = J^T, descending; only the supported entries of L.
-    if constexpr (sizeof(real) == 8 && WPE64 <= 2) {
-        // f64 at two waves per SIMD (at three the 2 x 23 prefetched coefficients do not fit beside the row: the plain form below, and a third wave hides what the
-        // prefetch hid): the coefficients (row I of L^T, wave-uniform LDS reads) do not depend on the chain through Jr: row I - 1's are requested in the source
+    if constexpr (sizeof(real) == 8) {
+        // f64: the coefficients (row I of L^T, wave-uniform LDS reads) do not depend on the chain through Jr: row I - 1's are requested in the source
         // before row I's chain (measured +0.5 %; f32: -0.9 %, kept in the plain form below).  Forcing the order with scheduling barriers makes the
         // register allocator spill 267 VGPRs to scratch -- an artefact of the split scheduling regions, not a shortage: built for one wave per SIMD
         // (-DWPE64=1, 512 registers allowed) the kernel still takes 254.
@@ -1610,7 +1545,7 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             constexpr int I = decltype(ic)::value;
             static_for<NV - 1 - I>([&](auto rc) {
                 constexpr int R = I + 1 + decltype(rc)::value;
-                if constexpr (l_nz(R, I)) cr[R] = s.Mp[row_p0(I) + R - I];
+                if constexpr (l_nz(R, I)) cr[R] = s.M[I][R];
             });
             d = s.col[I];
         };
@@ -1631,19 +1566,14 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             real acc = Jr[I];
             static_for<NV - 1 - I>([&](auto rc) {
                 constexpr int R = I + 1 + decltype(rc)::value;
-                if constexpr (l_nz(R, I)) acc -= s.Mp[row_p0(I) + R - I] * Jr[R];
+                if constexpr (l_nz(R, I)) acc -= s.M[I][R] * Jr[R];
             });
             Jr[I] = acc * s.col[I];
         });
     }
-    if (valid_port) {          // Y keeps J's support (the back substitution only mixes a coordinate with the coordinates it supports)
+    if (valid_port) {
 #pragma unroll
-        for (int j = 0; j < 6; j++) s.YS[j][p] = Jr[j];
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            const real arm_ = i < 3 ? (plimb == 2 ? Jr[18 + (i < 3 ? i : 0)] : Jr[21 + (i < 3 ? i : 0)]) : (real)0;
-            s.YS[6 + i][p] = plimb == 0 ? Jr[6 + i] : plimb == 1 ? Jr[12 + i] : arm_;
-        }
+        for (int j = 0; j < NV; j++) s.YT[j][p] = Jr[j];
     }
     ESTAMP(6);          // back substitution + Y stored
     s.park[0][lane] = bvel; s.park[1][lane] = dist;      // needed again in phase G; phase F needs every register
@@ -1653,49 +1583,38 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     FRESH_LANE();
     LANE_ROLES();
     // ---------------- F. port Delassus matrix, one row per lane in registers ----------------
-    // A[p][q] = Y_p . Y_q on the matrix pipe, which nothing else in this kernel uses: `v_mfma_f{32,64}_16x16x4` takes A[i][k] and B[k][j] as ONE value per lane (i or j = lane % 16,
-    // k = lane / 16), and for A = Y^T Y both operands of tile (ti, tj), k-step s are columns of the same matrix: lane l holds Y[4 s + l / 16][16 t + l % 16] for t = 0..2, s = 0..5 --
-    // 18 strided LDS reads bring the whole of Y into registers in that order (rounds 1-4: ~270 wave-uniform b128 reads feeding 534 vector multiply-adds; the LDS pipe, shared by all
-    // the waves of a compute unit, is what that build waited for on a loaded chip).  Results pass through LDS -- in the Y buffer itself, whose content sits in the operand registers
-    // and is written back afterwards for phase H -- as stage[column][row], HALF a tile row (8 rows x 48 columns) at a time since round 6 (the 12-slot Y buffer holds no more), so
-    // that lane p reads eight entries A[16 ti + 8 h ..][p] = A[p][16 ti + 8 h ..] of ITS row (A is symmetric) as consecutive words.  A slot lent to a box corner needs no dense
-    // special case: the product is dense.  (Rounds 1-4's vector build, kept as the A/B twin's through round 5 -- bit-identical, tests at that commit -- went with the dense buffer.)
+    // A[p][q] = Y_p . Y_q.  Y inherits the tree sparsity: coordinate j of a port's column is nonzero only if
+    // DoF j supports the port, so the base coordinates couple all 48 ports, a leg's coordinates only that
+    // leg's 6 joint ports + 15 foot ports, an arm's coordinates its 3 joint ports (534 instead of 1152
+    // multiply-adds).  Accumulated as register pairs (v_pk_fma_f32), loops over j kept rolled so that only
+    // the accumulators are live.
     using vec2 = real __attribute__((ext_vector_type(2)));
+#ifndef PLENVEC_MFMA_DELASSUS
+#define PLENVEC_MFMA_DELASSUS 1          /* 1: A = Y^T Y as nine 16 x 16 tiles on the matrix cores; 0: rounds 1-4's tree-sparse build on the vector unit from broadcast LDS reads */
+#endif
+#if PLENVEC_MFMA_DELASSUS
+    // The dense product on the matrix pipe, which nothing else in this kernel uses: `v_mfma_f{32,64}_16x16x4` takes A[i][k] and B[k][j] as ONE value per lane (i or j = lane % 16,
+    // k = lane / 16), and for A = Y^T Y both operands of tile (ti, tj), k-step s are columns of the same matrix: lane l holds Y[4 s + l / 16][16 t + l % 16] for t = 0..2, s = 0..5 --
+    // 18 strided LDS reads bring the whole of Y into registers in that order (instead of ~270 wave-uniform b128 reads feeding 534 vector multiply-adds: the LDS pipe, shared by all
+    // the waves of a compute unit, is what the old build waited for on a loaded chip).  A tile row of results (rows 16 ti .. 16 ti + 15 of A, all 48 columns) is passed through LDS
+    // -- in the Y buffer itself, whose content sits in the operand registers and is written back afterwards for phase H -- as stage[column][row in tile], so that lane p reads the
+    // sixteen entries A[16 ti ..][p] = A[p][16 ti ..] of ITS row (A is symmetric) as consecutive words.  A slot lent to a box corner needs no dense special case: the product is dense.
     using acc4 = real __attribute__((ext_vector_type(4)));
-    constexpr int YSS = Smem<real>::YSS;
     real Ar[NPORT];
     real diag = 0;
     {
         const int c16 = lane & 15, g4 = lane >> 4;
         real op[3][6];
-        // slot of coordinate 4 s + g4 in a port's column, and the limb a port must hang on for that coordinate to move it (-1: base coordinate, every port)
-        auto slot_of = [&](const int ks, int &slot_, int &need_) {
-            const int coord = 4 * ks + g4;
-            const bool base_ = coord < 6;
-            const int lb_ = limb_of_coord(coord);
-            slot_ = base_ ? coord : 6 + coord - limb_base(lb_);
-            need_ = base_ ? -1 : lb_;
-        };
         {
-            int pl3[3];
-#pragma unroll
-            for (int t = 0; t < 3; t++) pl3[t] = s.plimb[16 * t + c16];
-            const real *src = &s.YS[0][c16];
-            static_for<6>([&](auto sc) {
-                constexpr int ks = decltype(sc)::value;
-                int slot_, need_;
-                slot_of(ks, slot_, need_);
-                static_for<3>([&](auto tc) {
-                    constexpr int t = decltype(tc)::value;
-                    const real v_ = src[slot_ * YSS + 16 * t];
-                    op[t][ks] = (need_ < 0 || need_ == pl3[t]) ? v_ : (real)0;
-                });
-            });
+            const real *src = &s.YT[g4][c16];
+            static_for<3>([&](auto tc) { static_for<6>([&](auto sc) {
+                op[decltype(tc)::value][decltype(sc)::value] = src[4 * decltype(sc)::value * YTS + 16 * decltype(tc)::value];
+            }); });
         }
         WSYNC();                                             // every operand is in registers before the buffer is reused
-        constexpr int SS = sizeof(real) == 8 ? 10 : 12;      // words per staged column: 8 + pad (bank-conflict-free b64 / b128 stores and 16-byte-aligned row reads)
-        static_assert(NPORT * SS <= YSLOTS * YSS, "the staged half tile row must fit the Y buffer");
-        real *stage = &s.YS[0][0];
+        constexpr int SS = sizeof(real) == 8 ? 18 : 20;      // words per staged column: 16 + pad (bank-conflict-free b64 / b128 stores and 16-byte-aligned row reads)
+        static_assert(NPORT * SS <= NV * YTS, "the staged tile row must fit the Y buffer");
+        real *stage = &s.YT[0][0];
         static_for<3>([&](auto tic) {
             constexpr int ti = decltype(tic)::value;
             acc4 d[3];
@@ -1718,52 +1637,122 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                 });
             };
             if (__builtin_expect(lent != 0, 0)) products(std::true_type{}); else products(std::false_type{});
-            static_for<2>([&](auto hc) {
-                constexpr int h = decltype(hc)::value;       // rows 8 h .. 8 h + 7 of the tile row
 #pragma unroll
-                for (int tj = 0; tj < 3; tj++) {
-                    real *col = stage + (16 * tj + c16) * SS;
-                    if constexpr (sizeof(real) == 8) {       // D of the f64 form: row = lane / 16 + 4 r, column = lane % 16: registers 2 h, 2 h + 1 hold rows 8 h + g4, 8 h + g4 + 4
-                        col[g4] = d[tj][2 * h]; col[g4 + 4] = d[tj][2 * h + 1];
-                    } else {                                 // f32 form: row = 4 (lane / 16) + r: the lane groups 2 h, 2 h + 1 hold rows 8 h ..
-                        if ((g4 >> 1) == h) *reinterpret_cast<acc4 *>(col + 4 * (g4 & 1)) = d[tj];
-                    }
+            for (int tj = 0; tj < 3; tj++) {
+                real *col = stage + (16 * tj + c16) * SS;
+                if constexpr (sizeof(real) == 8) {           // D of the f64 form: row = lane / 16 + 4 r, column = lane % 16
+#pragma unroll
+                    for (int r = 0; r < 4; r++) col[g4 + 4 * r] = d[tj][r];
+                } else {                                     // f32 form: row = 4 (lane / 16) + r
+                    *reinterpret_cast<acc4 *>(col + 4 * g4) = d[tj];
                 }
-                WSYNC();
-                const real *rp = stage + p * SS;
+            }
+            WSYNC();
+            const real *rp = stage + p * SS;
 #pragma unroll
-                for (int i = 0; i < 8; i++) Ar[16 * ti + 8 * h + i] = rp[i];
-                const real dsel = rp[p & 7];
-                if ((p >> 3) == 2 * ti + h) diag = dsel;     // A[p][p], the same sum as the row's own entry
-                WSYNC();
-            });
+            for (int i = 0; i < 16; i++) Ar[16 * ti + i] = rp[i];
+            const real dsel = rp[p & 15];
+            if ((p >> 4) == ti) diag = dsel;                 // A[p][p], the same sum as the row's own entry
+            WSYNC();
         });
         {
-            // Y back into its slots (only the entries a port's limb gives it: the other coordinates of a slot belong to other limbs and are structural zeros);
-            // the arm ports' three unused slots get their zeros back (phase H multiplies them by the zero impulses of another limb's view)
-            real *dst = &s.YS[0][c16];
-            int pl3[3];
-#pragma unroll
-            for (int t = 0; t < 3; t++) pl3[t] = s.plimb[16 * t + c16];
-            static_for<6>([&](auto sc) {
-                constexpr int ks = decltype(sc)::value;
-                int slot_, need_;
-                slot_of(ks, slot_, need_);                   // (recomputed: held since the loads they would be 15 registers the tile loop has no room for at three waves per SIMD)
-                static_for<3>([&](auto tc) {
-                    constexpr int t = decltype(tc)::value;
-                    if (need_ < 0 || need_ == pl3[t]) dst[slot_ * YSS + 16 * t] = op[t][ks];
-                });
-            });
-#pragma unroll
-            for (int t = 0; t < 3; t++) if (pl3[t] >= 2 && g4 < 3) dst[(9 + g4) * YSS + 16 * t] = 0;
+            real *dst = &s.YT[g4][c16];
+            static_for<3>([&](auto tc) { static_for<6>([&](auto sc) {
+                dst[4 * decltype(sc)::value * YTS + 16 * decltype(tc)::value] = op[decltype(tc)::value][decltype(sc)::value];
+            }); });
         }
     }
+#else
+    vec2 Ar2[NPORT / 2];
+#pragma unroll
+    for (int q = 0; q < NPORT / 2; q++) Ar2[q] = (vec2){0, 0};
+    real diag = 0;
+    // The rows of Y come from LDS (uniform addresses, b64 per pair).  The loops over j stay rolled (only the 48
+    // accumulators and two row buffers are live) and are software-pipelined by hand: the reads of the next
+    // (half-)row are issued before the multiply-adds of the current one, so the LDS latency of ~100 cycles per
+    // row is overlapped instead of exposed 24 times.
+    using std::integral_constant;
+    auto row_ptr = [&](const int j) { return reinterpret_cast<const vec2 *>(&s.YT[j][0]); };
+    {   // base coordinates j = 0..5: all 24 pairs, in four chunks of 6 (two 12-register buffers in flight)
+        vec2 bufA[6], bufB[6];
+        auto ld = [&](vec2 (&b)[6], const int j, auto cc) {
+            const vec2 *r = row_ptr(j) + 6 * decltype(cc)::value;
+#pragma unroll
+            for (int i = 0; i < 6; i++) b[i] = r[i];
+        };
+        auto mac = [&](const vec2 (&b)[6], const vec2 y2, auto cc) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) Ar2[6 * decltype(cc)::value + i] += y2 * b[i];
+        };
+        integral_constant<int, 0> c0; integral_constant<int, 1> c1; integral_constant<int, 2> c2; integral_constant<int, 3> c3;
+        // a lent slot's port is supported by ITS body's chain, not by the leg it sits in: then every coordinate couples every pair (dense build, rare)
+        const int jend = lent ? NV : 6;
+        ld(bufA, 0, c0);
+        real yj = s.YT[0][p];
+#pragma unroll 1
+        for (int j = 0; j < jend; j++) {
+            const int jn = j < jend - 1 ? j + 1 : jend - 1;   // (the last prefetch re-reads the last row: harmless, keeps the loop uniform)
+            const vec2 y2 = {yj, yj};
+            diag += yj * yj;
+            ld(bufB, j, c1); mac(bufA, y2, c0);
+            ld(bufA, j, c2); mac(bufB, y2, c1);
+            ld(bufB, j, c3); mac(bufA, y2, c2);
+            yj = s.YT[jn][p];
+            ld(bufA, jn, c0); mac(bufB, y2, c3);
+        }
+    }
+    if (!lent) {
+    static_for<2>([&](auto fc_) {        // leg f: DoFs 6+6f..11+6f, joint ports 6f..6f+5 (pairs 3f..3f+2), foot ports 18+15f..32+15f (pairs 9+7f..16+7f; pair 16 = ports 32|33 is shared)
+        constexpr int f = decltype(fc_)::value, J0 = 6 + 6 * f, PJ = 3 * f, PC = 9 + 7 * f;
+        vec2 bufA[6], bufB[5];           // A: the 3 joint pairs + the first 3 foot pairs, B: the other 5 foot pairs
+        auto ldA = [&](const int j) {
+            const vec2 *r = row_ptr(j);
+#pragma unroll
+            for (int i = 0; i < 3; i++) { bufA[i] = r[PJ + i]; bufA[3 + i] = r[PC + i]; }
+        };
+        ldA(J0);
+        real yj = s.YT[J0][p];
+#pragma unroll 1
+        for (int j = J0; j < J0 + 6; j++) {
+            const int jn = j < J0 + 5 ? j + 1 : J0 + 5;
+            const vec2 y2 = {yj, yj};
+            diag += yj * yj;
+            {
+                const vec2 *r = row_ptr(j);
+#pragma unroll
+                for (int i = 0; i < 5; i++) bufB[i] = r[PC + 3 + i];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++) { Ar2[PJ + i] += y2 * bufA[i]; Ar2[PC + i] += y2 * bufA[3 + i]; }
+            yj = s.YT[jn][p];
+            ldA(jn);
+#pragma unroll
+            for (int i = 0; i < 5; i++) Ar2[PC + 3 + i] += y2 * bufB[i];
+        }
+    });
+    static_for<2>([&](auto ac_) {        // arm a: DoFs 18+3a..20+3a, joint ports 12+3a..14+3a (pairs 6+a, 7+a); three rows, unrolled
+        constexpr int a = decltype(ac_)::value;
+#pragma unroll
+        for (int j = 18 + 3 * a; j < 21 + 3 * a; j++) {
+            const real yj = s.YT[j][p];
+            diag += yj * yj;
+            const vec2 y2 = {yj, yj};
+            const vec2 *r = row_ptr(j);
+            Ar2[6 + a] += y2 * r[6 + a]; Ar2[7 + a] += y2 * r[7 + a];
+        }
+    });
+    }
+#endif
     const real EPS = sizeof(real) == 8 ? (real)2.220446049250313e-16 : (real)1.1920929e-07;
     const real jdi = diag > EPS ? rcp_(diag) : (real)0;
     if (dump) {
         if (valid_port) {
 #pragma unroll
+#if PLENVEC_MFMA_DELASSUS
             for (int q = 0; q < NPORT; q++) dump[1216 + p * NPORT + q] = Ar[q];
+#else
+            for (int q = 0; q < NPORT; q++) dump[1216 + p * NPORT + q] = Ar2[q / 2][q % 2];
+#endif
             dump[3520 + p] = s.park[0][lane];
             dump[3568 + p] = s.park[1][lane];
         }
@@ -1773,11 +1762,20 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     WSYNC();
     if (valid_port) s.lamP[p] = jdi;
     WSYNC();
+#if PLENVEC_MFMA_DELASSUS
 #pragma unroll
     for (int q = 0; q < NPORT / 2; q++) {
         const vec2 a2 = (vec2){Ar[2 * q], Ar[2 * q + 1]} * *reinterpret_cast<const vec2 *>(&s.lamP[2 * q]);
         Ar[2 * q] = a2[0]; Ar[2 * q + 1] = a2[1];
     }
+#else
+    real Ar[NPORT];
+#pragma unroll
+    for (int q = 0; q < NPORT / 2; q++) {
+        const vec2 a2 = Ar2[q] * *reinterpret_cast<const vec2 *>(&s.lamP[2 * q]);
+        Ar[2 * q] = a2[0]; Ar[2 * q + 1] = a2[1];
+    }
+#endif
 
     STAMP();
     FRESH_LANE();
@@ -1858,17 +1856,6 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
 #endif
     const int npts = __builtin_amdgcn_readfirstlane(5 * __builtin_popcount(act & 0xfu) + __builtin_popcount((act >> 4) & 0xfu));      // 5 NR + NL: a foot's occupied slots are a prefix
     PLEN_ASSERT_FULL_EXEC();
-    // Three f64 waves per SIMD (168 registers): the per-lane constants of the rows -- 1 / diagonal, diagonal, the friction coefficients -- are written to the parking area
-    // (its four values were read above) and every copy of the iteration loop reads back, once at its entry, the ones ITS rows use; what follows the loops reads its two again.
-    // Held in registers from here to phase H their live ranges span all 50 loop copies, and the register allocator -- which splits a range per loop only up to a size these
-    // exceed -- reloaded them from scratch memory INSIDE the iterations (first 3-wave build: one to four exposed scratch loads per iteration, -7 % against two waves).
-    // volatile: the compiler must not forward the stored registers to the loads.
-    constexpr bool PARK = sizeof(real) == 8 && WPE64 >= 3 && PLENVEC_COUNT_SPECIALISED == 2;
-    volatile real *const pk_ = &s.park[0][0];
-    if constexpr (PARK) {
-        pk_[lane] = jdi; pk_[64 + lane] = diag; pk_[128 + lane] = nfcn;
-        if (is_tors) { const int t_ = 256 + 4 * (lane - 52); pk_[t_] = fc0; pk_[t_ + 1] = fc1; pk_[t_ + 2] = fc2; pk_[t_ + 3] = fc3; }
-    }
     // LSPEC >= 0: this copy of the WHOLE iteration loop is compiled for these point counts (5 NR + NL; 0 = airborne: motor rows only), so that the choice is made
     // once per substep; LOOP_GENERIC: one loop, the contact section chosen inside every iteration (PLENVEC_COUNT_SPECIALISED 0 / 1)
     constexpr int LOOP_GENERIC = -1000;
@@ -1891,21 +1878,6 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
 #endif
     // one solver iteration; ODD: compile-time parity (PLENVEC_UNROLL_PARITY) or -1 = tested at run time.  Returns Bullet's exit condition; advances `it`.
     real dv0 = 0, dv1 = 0, dv2 = 0, dv3 = 0;          // the torsional rows' deltas of a foot's point k (deferred commit, like dvec)
-    // this copy's row constants (PARK: read back from the parking area, only what the copy's rows use)
-    constexpr int CNT_ = LSPEC == LOOP_GENERIC ? 24 : LSPEC % 100, KMAX_ = LSPEC == LOOP_GENERIC ? 4 : ((CNT_ / 5) > (CNT_ % 5) ? (CNT_ / 5) : (CNT_ % 5));
-    real jdi_c = 0, diag_c = 0, nfcn_c = 0, fc0_c = 0, fc1_c = 0, fc2_c = 0, fc3_c = 0;
-    if constexpr (PARK) {
-        if constexpr (CNT_ > 0) { jdi_c = pk_[lane]; nfcn_c = pk_[128 + lane]; }
-        if constexpr (LIM_ROWS) diag_c = pk_[64 + lane];
-        if constexpr (KMAX_ > 0) {
-            const int t_ = 256 + 4 * ((lane >= 52 && lane < 58) ? lane - 52 : 0);
-            const bool tl_ = lane >= 52 && lane < 58;
-            const real a0_ = pk_[t_]; fc0_c = tl_ ? a0_ : (real)0;
-            if constexpr (KMAX_ > 1) { const real a1_ = pk_[t_ + 1]; fc1_c = tl_ ? a1_ : (real)0; }
-            if constexpr (KMAX_ > 2) { const real a2_ = pk_[t_ + 2]; fc2_c = tl_ ? a2_ : (real)0; }
-            if constexpr (KMAX_ > 3) { const real a3_ = pk_[t_ + 3]; fc3_c = tl_ ? a3_ : (real)0; }
-        }
-    } else { jdi_c = jdi; diag_c = diag; nfcn_c = nfcn; fc0_c = fc0; fc1_c = fc1; fc2_c = fc2; fc3_c = fc3; }
     auto iteration = [&](auto odd_c) -> bool {
         constexpr int ODD = decltype(odd_c)::value;
         res_i = 0;
@@ -1942,7 +1914,8 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
         constexpr unsigned long long MOTOR_LANES = (1ull << ND) - 1ull;
         // the violated-limit mask, laundered through a scalar register once per iteration: the 18 per-row tests are then `s_bitcmp1_b32` + a scalar branch each.  Left
         // loop-invariant, the compiler evaluated all 18 ahead of the loop as 64-bit condition masks, held -- and spilled into VGPR lanes, and re-read with a v_readlane
-        // pair in front of every row -- across the limit flavour of every loop copy (round 5: 705 / 433 spilled SGPRs in the f64 / f32 kernel, all of them here).
+        // pair in front of every row -- across the limit flavour of every loop copy (round 5: 705 / 433 spilled SGPRs in the f64 / f32 kernel, all of them here; the
+        // copies WITHOUT limit rows, the ones a rollout runs, never carried any: DESIGN.md section 4).
         unsigned lm_it = lim_mask;
         if constexpr (LIM_ROWS) asm volatile("" : "+s"(lm_it));
         if (ODD < 0 ? (it & 1) != 0 : ODD == 1) {
@@ -1951,14 +1924,14 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
             if (LIM_ROWS && __builtin_expect(lm_it != 0, 0)) {      // rare: kept out of the hot loop's instruction stream
                 static_for<ND>([&](auto ic) {
                     constexpr int PP = NC_ORDER[decltype(ic)::value];
-                    if (lm_it & (1u << PP)) pgs_row_signed<PP>(s.lim, e, diag_c, Ar[PP], lane, res_i);
+                    if (lm_it & (1u << PP)) pgs_row_signed<PP>(s.lim, e, diag, Ar[PP], lane, res_i);
                 });
             }
         } else {
             if (LIM_ROWS && __builtin_expect(lm_it != 0, 0)) {      // rare: kept out of the hot loop's instruction stream
                 static_for<ND>([&](auto ic) {
                     constexpr int PP = NC_ORDER[ND - 1 - decltype(ic)::value];
-                    if (lm_it & (1u << PP)) pgs_row_signed<PP>(s.lim, e, diag_c, Ar[PP], lane, res_i);
+                    if (lm_it & (1u << PP)) pgs_row_signed<PP>(s.lim, e, diag, Ar[PP], lane, res_i);
                 });
             }
             pgs_motor_pass<FAST, true>(e, blo, bhi, dvec, Ar, lane);
@@ -2018,17 +1991,14 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                     // operations on a 0/1 factor m instead of an add, a subtract, a negation and two selects each: u * m is exact, so fma(u, m, lim) rounds
                     // exactly like lim + u; with m = 0 it leaves lim = fc * 0 = +-0, the empty interval.  pt1 is the NEGATED lower bound (the rows negate it
                     // with a source modifier).  f64: 32 -> 16 vector instructions per iteration.
-                    // (f64: 1.0 through a scalar register at its use -- as a vector-register constant the compiler hoists it out of all 50 loop copies, and at three waves per
-                    // SIMD spills it and reloads it from scratch memory once per iteration)
-                    const real one_ = kc_((real)1);
                     const real nbv0 = TRACKED ? blo : gather_addr(blo, tors_addr);
-                    const real lim0 = mul_rn_(fc0_c, nbv0);
-                    const real m0 = nbv0 < 0 ? one_ : (real)0;
+                    const real lim0 = mul_rn_(fc0, nbv0);
+                    const real m0 = nbv0 < 0 ? (real)1 : (real)0;
                     nt10 = fma_(u0, m0, lim0); t20 = fma_(-u0, m0, lim0);
                     if constexpr (KMAX > 1) {
                         const real nbv1 = TRACKED ? bhi : gather_addr(blo, tors_addr + 16);
-                        const real lim1 = mul_rn_(fc1_c, nbv1);
-                        const real m1 = nbv1 < 0 ? one_ : (real)0;
+                        const real lim1 = mul_rn_(fc1, nbv1);
+                        const real m1 = nbv1 < 0 ? (real)1 : (real)0;
                         nt11 = fma_(u1, m1, lim1); t21 = fma_(-u1, m1, lim1);
                     }
                 }
@@ -2036,13 +2006,13 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                 // has one or two, scripts/gpu_slot_distribution_actor.py): +0.65 % (f32: -0.3 ... -0.7 %, the branch costs more than two gathers: eager there)
                 if ((SPEC >= 0 && KMAX > 2) || (SPEC < 0 && (sizeof(real) == 4 || (act & 0xccu)))) {
                     const real nbv2 = gather_addr(blo, tors_addr + 32);
-                    const real lim2 = mul_rn_(fc2_c, nbv2);
-                    const real m2 = nbv2 < 0 ? kc_((real)1) : (real)0;
+                    const real lim2 = mul_rn_(fc2, nbv2);
+                    const real m2 = nbv2 < 0 ? (real)1 : (real)0;
                     nt12 = fma_(u2, m2, lim2); t22 = fma_(-u2, m2, lim2);
                     if constexpr (KMAX > 3) {
                         const real nbv3 = gather_addr(blo, tors_addr + 48);
-                        const real lim3 = mul_rn_(fc3_c, nbv3);
-                        const real m3 = nbv3 < 0 ? kc_((real)1) : (real)0;
+                        const real lim3 = mul_rn_(fc3, nbv3);
+                        const real m3 = nbv3 < 0 ? (real)1 : (real)0;
                         nt13 = fma_(u3, m3, lim3); t23 = fma_(-u3, m3, lim3);
                     }
                 }
@@ -2081,13 +2051,13 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
                 // mu * lambda_n of each point: from its normal lane (lane 0 of the point's quad) to the whole quad
                 real lmv;
                 if constexpr (FAST && sizeof(real) == 4) asm("s_nop 1\n\tv_mul_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "=v"(lmv) : "v"(blo), "v"(nfcnq));
-                else lmv = quad_bcast0(mul_rn_(nfcn_c, blo));
+                else lmv = quad_bcast0(mul_rn_(nfcn, blo));
                 each_point([&](auto fc_, auto kc) {
                     constexpr int PN = port_normal(4 * decltype(fc_)::value + decltype(kc)::value);
 #ifdef PLEN_SLIDE_STATS
-                    pgs_cone<FAST, PN>(e, u0, dvec, lmv, jdi_c, Ar[PN + 1], Ar[PN + 2], lane, &slide_now);
+                    pgs_cone<FAST, PN>(e, u0, dvec, lmv, jdi, Ar[PN + 1], Ar[PN + 2], lane, &slide_now);
 #else
-                    pgs_cone<FAST, PN>(e, u0, dvec, lmv, jdi_c, Ar[PN + 1], Ar[PN + 2], lane);
+                    pgs_cone<FAST, PN>(e, u0, dvec, lmv, jdi, Ar[PN + 1], Ar[PN + 2], lane);
 #endif
                 });
             }
@@ -2193,50 +2163,30 @@ __device__ __forceinline__ void substep(Smem<real> &s, const DevParams<real> &P,
     // of the env in the NEXT launch (plen_balance_kernel)
     load += P.cost_setup + it * (P.cost_it0 + P.cost_pt * __builtin_popcount(act) + (act ? P.cost_act : 0));
     // back to impulses: joint lanes u = -(mh + blo) (+ the limit row), normal lanes u = -blo, the rest explicit
-    FRESH_LANE();
-    LANE_ROLES();          // (re-derived: none of the role flags lives through the loops)
     real lam_sum;
-    {
-        real jdi_a = jdi, diag_a = diag;
-        if constexpr (PARK) { jdi_a = pk_[lane]; diag_a = pk_[64 + lane]; }
-        if (is_joint) lam_sum = (-(P.max_imp * diag_a) - blo + s.lim[2][p] * s.lim[3][p]) * jdi_a;
-        else if (is_lin && pax == 0) lam_sum = -blo * jdi_a;
-        else lam_sum = (u0 + u1 + u2 + u3) * jdi_a;
-    }
+    if (is_joint) lam_sum = (-(P.max_imp * diag) - blo + s.lim[2][p] * s.lim[3][p]) * jdi;
+    else if (is_lin && pax == 0) lam_sum = -blo * jdi;
+    else lam_sum = (u0 + u1 + u2 + u3) * jdi;
 
+    FRESH_LANE();
     // ---------------- H. apply impulses:  dv = L^-1 (Y Lambda),  v = clamp(v* + dv) ----------------
     {
         const int k = lane < NV ? lane : 0;                         // (re-derived: the phase-B copy would have to survive the solver)
         const real inv_diag_r = lane < NV ? s.col[k] : (real)0;    // 1/L[k][k], parked in LDS since phase E
-        const unsigned below_k = lane < NV ? anc_cf(k) & ~(1u << k) : 0u;
         const real vstar_r = lane < NV ? s.v[k] : (real)0;         // v* parked in LDS since phase D
         const real lamP = lam_sum;
-        // z = Y Lambda, lane k = coordinate k.  Row k of Y lives in slot row k (base) or 6 + (k - limb_base(its limb)), where the entries of ports hanging on ANOTHER limb belong
-        // to that limb's coordinates: each limb's lanes therefore read the impulses through a copy in which the other limbs' ports are zero (five rows of 48 in the parking
-        // area, dead since phase G read it: per limb, then all ports for the base lanes) -- the structural zeros of the dense Y times Lambda, now Y times a zero.
-        real *lcopy = &s.park[0][0];
-        static_assert(5 * NPORT <= 4 * 64, "the impulse copies must fit the parking area");
-        if (valid_port) {
-            s.lamP[p] = lamP;
-            const int mine = s.plimb[p];
-#pragma unroll
-            for (int c = 0; c < 4; c++) lcopy[NPORT * c + p] = mine == c ? lamP : (real)0;
-            lcopy[NPORT * 4 + p] = lamP;
-        }
+        if (valid_port) s.lamP[p] = lamP;
         WSYNC();
         real z = 0;
         if (lane < NV) {
-            const int lk = limb_of_coord(k);
-            const real *yrow = &s.YS[0][0] + (k < 6 ? k : 6 + k - limb_base(lk)) * Smem<real>::YSS;
-            const real *lrow = lcopy + NPORT * (k < 6 ? 4 : lk);
 #pragma unroll
-            for (int q = 0; q < NPORT; q++) z += yrow[q] * lrow[q];
+            for (int q = 0; q < NPORT; q++) z += s.YT[k][q] * s.lamP[q];
         }
         static_for<NV>([&](auto jc) {                 // L x = z, ascending, column k of L^T from LDS
             constexpr int J = decltype(jc)::value;
             if constexpr (has_desc(J)) {
                 const real xj = bcast(z * inv_diag_r, J);
-                z -= packed_col<J>(s.Mp, k, below_k) * xj;
+                z -= s.M[J][k] * xj;
             }
         });
         const real x = z * inv_diag_r;

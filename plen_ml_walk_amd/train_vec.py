@@ -609,6 +609,79 @@ class PipelinedVecTD3Trainer(object):
         e = torch.cuda.Event(); e.record(su); self._ev_upd[t] = e
         self._step_tail(t, n)
 
+    # ---- K vector steps of the whole pipeline as ONE hipGraph (round 6) -----------------------------------------------------------------------------------------
+    BLOCK = 6          # lcm of the behaviour-copy ring (3) and policy_freq (2): the same graph serves every block of six steps
+
+    def _block_body(self, t0, g0):
+        """Six vector steps with the event structure of step(): collect(h, t) waits for update t - 2 and acts with copy (t - 1) % 3; update t waits for both collectors' step
+        t - 1 and refreshes copy (t + 1) % 3.  Called under stream capture on the update stream: the collector streams fork from it and join it again, so every dependency
+        becomes an edge of one graph (what lies before t0 is ordered by the graph launch itself)."""
+        su, pf = self.su, self.agent.policy_freq
+        ev0 = torch.cuda.Event(); ev0.record(su)
+        for s in self.streams:
+            s.wait_event(ev0)
+        col, upd = {}, {}
+        for k in range(self.BLOCK):
+            t = t0 + k
+            for h, s in enumerate(self.streams):
+                if (t - 2) in upd:
+                    s.wait_event(upd[t - 2])
+                with torch.cuda.stream(s):
+                    self._collect(h, False, (t - 1) % 3)
+                e = torch.cuda.Event(); e.record(s); col[(h, t)] = e
+            for h in range(self.H):
+                if (h, t - 1) in col:
+                    su.wait_event(col[(h, t - 1)])
+            with torch.cuda.stream(su):
+                self._update((g0 + k + 1) % pf == 0, (t + 1) % 3)
+            e = torch.cuda.Event(); e.record(su); upd[t] = e
+        for s in self.streams:
+            su.wait_stream(s)
+
+    def step_block(self):
+        """BLOCK vector steps as one graph replay (single rank, steady state: past the random-action phase, learning on); falls back to BLOCK calls of step() otherwise.
+        Why: step() launches three graphs per vector step, and every graph launch costs ~24 us of idle gap on the chain it
+        belongs to -- on each collector's chain once per step.  Same kernels on the same data in the same order per stream as BLOCK calls of step()."""
+        t, n = self.t, self.n
+        warmed = (all(("collect", h, False, b) in self._graphs for h in range(self.H) for b in range(3))
+                  and all(("update", wp, b) in self._graphs for wp in (False, True) for b in range(3)))          # every piece has run eagerly and been captured on its own: lazy initialisations are done
+        if self.collectives or not self.learning or t * n < self.start_timesteps or t < 3 or not warmed:
+            for _ in range(self.BLOCK):
+                self.step()
+            return
+        su = self.su
+        key = ("block", t % 3, self.grad_steps % self.agent.policy_freq)
+        # everything enqueued by earlier step() calls on the collector streams is ordered before the block (its nodes run on the graph's own branches)
+        for h in range(self.H):
+            ev = self._ev_col.get((h, t - 1))
+            if ev is not None:
+                su.wait_event(ev)
+        g = self._graphs.get(key)
+        with torch.cuda.stream(su):
+            if g is None:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=su, capture_error_mode="thread_local"):
+                    self._block_body(t, self.grad_steps)
+                self._graphs[key] = g
+            g.replay()
+        # a later step() must see the whole block behind it: one event after the replay stands for every collect / update event of the block's last steps
+        e = torch.cuda.Event(); e.record(su)
+        for k in range(self.BLOCK):
+            self._ev_upd[t + k] = e
+            for h in range(self.H):
+                self._ev_col[(h, t + k)] = e
+        self.grad_steps += self.BLOCK
+        self.agent.total_it = self.grad_steps
+        for k in range(self.BLOCK):
+            self._step_tail(t + k, n)
+
+    def run(self, steps):
+        """`steps` vector steps: whole blocks through step_block(), the remainder through step()."""
+        while steps >= self.BLOCK:
+            self.step_block(); steps -= self.BLOCK
+        for _ in range(steps):
+            self.step()
+
     def _step_tail(self, t, n):
         for k in [k for k in self._ev_upd if k < t - 3]:
             del self._ev_upd[k]

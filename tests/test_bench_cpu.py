@@ -144,6 +144,27 @@ def test_bench_two_ranks_on_one_gpu(scaling):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_eight_ranks_on_one_gpu(scaling):
+    """BASELINE.json configs[3]'s process shape on the hardware there is: EIGHT ranks through the driver's command (`bench.py --gpus 8`), sharing the
+    one GPU of a box, gloo carrying the collectives.  512 envs per rank -- weak: 8 x 512, strong: the metric's literal 4096 envs in total split eight ways -- is ONE launch
+    per rank and step; the TD3 leg's gradient all-reduces pair up across all eight ranks and leave bitwise equal parameters everywhere."""
+    env = dict(os.environ, PLEN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--scaling", scaling, "--steps", "10", "--warmup", "3",
+                          "--envs-per-gpu", "512" if scaling == "weak" else "4096", "--legs", "f32,td3", "--td3-steps", "20", "--td3-batch", "256", "--no-cpu-baseline", "--no-parity"],
+                         capture_output=True, text=True, timeout=1500, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.stdout[-500:], out.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == scaling and d["value"] > 0
+    assert d["config"]["total_envs"] == 4096 and d["config"]["envs_per_gpu"] == 512
+    assert d["config_detail"]["sub_batches"].startswith("1 x 512"), d["config_detail"]["sub_batches"]          # one launch per rank and step
+    td3 = d["legs"]["td3"]
+    assert td3.get("value") and td3["parameters_equal_across_ranks"] is True and td3["collective_backend"] == "gloo" and td3["grad_steps_per_s"] > 0, td3
+    _fits_the_driver_record(d)
+
+
+@pytest.mark.gpu
 def test_bench_two_ranks_large_batch_branch_keeps_collectives_paired():
     """with --td3-batch > 512 rank 0 alone used to run the learner's roofline probe -- ~250 extra all-reduces that paired with the other ranks' NEXT
     collectives.  The default multi-rank command's branch (pipelined schedule, large-batch kernels) on two ranks: completes, parameters bitwise equal, and no roofline

@@ -108,4 +108,4 @@ def test_env_kernels_stay_inside_their_register_budgets(lib):
         assert v["Occupancy"] == (2 if dt == "f64" else 4), (dt, path, v)
         assert v["LDS Size"] == (19872 if dt == "f64" else 9936), (dt, path, v)
     assert k[("f64", "fast")]["SGPRs Spill"] < 100, k[("f64", "fast")]
-    assert k[("f32", "fast")]["SGPRs Spill"] < 250, k[("f32", "fast")]
+    assert k[("f32", "fast")]["SGPRs Spill"] < 250          # (193: prologue and limit flavours; no reload inside a hot iteration loop), k[("f32", "fast")]

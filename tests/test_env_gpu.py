@@ -345,10 +345,11 @@ def test_count_specialised_solver_loops_bitwise_equal_the_run_time_tested_loop(t
     The specialised copies run the spinning / rolling rows unconditionally and rely on (+-0, +-0) bounds being exact no-ops when a coefficient is zero, and on
     lent box slots carrying zero coefficients: `no_torsional_friction` sets both coefficients to 0, `fallen_robots` switches the auto-reset off so
     that robots fall and stay down -- links other than the feet on the ground, contact slots lent to their box corners.
-    The twin commits / zeroes its delta vectors after every pass where the shipped loops do neither: bit for bit the same trajectories says the hoisted commits touch no
-    value a row reads.  (Round 5's twin also built the Delassus matrix A = Y^T Y as vector multiply-adds from broadcast LDS reads -- bit-identical to the matrix-core
-    tiles, asserted by this test at that commit; round 6's 12-slot Y buffer, the LDS cut for a third f64 wave per SIMD, has no room for that build's dense rows, and
-    the layout change itself was held to the round-5 library bit for bit with scripts/gpu_same_bits.py: profiles/r06_*_same_bits_vs_r05.txt.)"""
+    Round 5: the same twin also builds the Delassus matrix A = Y^T Y as vector multiply-adds from broadcast LDS reads (-DPLENVEC_MFMA_DELASSUS=0) where the shipped
+    kernel uses `v_mfma_f{32,64}_16x16x4` tiles (dense when a slot is lent, the structurally zero pieces skipped otherwise), and commits / zeroes its delta vectors
+    after every pass where the shipped loops do neither: bit for bit the same trajectories says the matrix instruction adds its k terms in order, and that the hoisted
+    commits touch no value a row reads.  (The mass matrix's matrix-core build has no such twin: switching it off changes the compiler's contractions elsewhere in
+    its phase; it is held to the oracle like everything else.)"""
     from plen_ml_walk_amd.build import build_variant, REFERENCE_FORM_FLAGS
     lib0 = build_variant("nospec", REFERENCE_FORM_FLAGS)
     kw = {"reference": "", "no_torsional_friction": ", cfg_overrides={'spinning_friction': 0.0, 'rolling_friction': 0.0}", "fallen_robots": ", auto_reset=False"}[cfg]

@@ -846,6 +846,40 @@ def test_pipelined_trainer_overlaps_without_races(n, T, batch):
     assert not torch.equal(runs[0], runs[1])      # ... and the learning run did act with a learned policy
 
 
+def test_six_step_graph_equals_single_steps():
+    """PipelinedVecTD3Trainer.step_block() replays SIX vector steps of the whole loop -- both collectors and the learner, with their event
+    dependencies as graph edges -- as one hipGraph.  Same kernels on the same data in the same order per stream as six step() calls: from equal seeds, 24 warm-up
+    steps through step() and then 36 more through step() in one trainer and through run() (six-step graphs) in the other end with the SAME ring contents, counters,
+    random-stream positions and -- the large-batch kernels sum in a fixed order -- bitwise equal parameters."""
+    from plen_ml_walk_amd.td3 import ReplayBuffer, TD3Agent
+    from plen_ml_walk_amd.train_vec import PipelinedVecTD3Trainer
+    n, batch = 1024, 1024
+    out = []
+    for blocks in (False, True):
+        torch.manual_seed(0)
+        envs = [_env(n // 2), _env(n // 2)]
+        agent = TD3Agent(26, 18, 1.0); replay = ReplayBuffer(80 * n)
+        tr = PipelinedVecTD3Trainer(envs, agent, replay, start_timesteps=3 * n, batch_size=batch, seed=7)
+        for _ in range(24):
+            tr.step()
+        if blocks:
+            tr.run(36 + 2)                       # six blocks, then two single steps behind them (the hand-over back to step())
+            assert sum(1 for k in tr._graphs if k[0] == "block") >= 1
+        else:
+            for _ in range(36 + 2):
+                tr.step()
+        tr.sync(); torch.cuda.synchronize()
+        assert tr.env_steps == 62 * n and tr.grad_steps == 62 - 3 and agent.total_it == tr.grad_steps and int(tr.total_u) == 62 * n
+        assert int(tr.base[0]) == 62 * n and int(tr.base[1]) == 62 * n + n // 2
+        out.append((replay.data[:62 * n].clone(), agent._critic_flat.flat.clone(), agent._actor_flat.flat.clone(), [r.clone() for r in tr.rngs], float(agent.last_critic_loss)))
+        for e in envs:
+            e.close()
+    a, b = out
+    assert torch.equal(a[0], b[0])                                       # every stored transition, in order
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])           # critic and actor parameters, bit for bit
+    assert all(torch.equal(x, y) for x, y in zip(a[3], b[3])) and a[4] == b[4]
+
+
 def test_in_kernel_philox_draws():
     """The kernels' own random numbers (Philox4x32-10 + Box-Muller; no library RNG call inside the captured graphs): uniform actions and
     exploration noise have the right moments, differ between calls (the following store() bumps the call counter) and between seeds, and
