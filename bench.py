@@ -561,10 +561,16 @@ def _td3_run(a, dev, rank, world, dist, steps, warmup, batch):
         tr.step()
     while tr.env_steps < 10000 + 8 * n:      # few envs per rank (tests, strong scaling): the random-action phase is start_timesteps / n vector steps long
         tr.step()
+    blocks = bool(pipelined and a.td3_block_graph and world == 1)
+    if blocks:
+        tr.run(2 * tr.BLOCK)                 # the six-step graph is captured (and has run once) before the clock starts
     barrier()
     e0, g0, t0 = tr.env_steps, tr.grad_steps, time.perf_counter()
-    for _ in range(steps):
-        tr.step()
+    if blocks:
+        tr.run(steps)          # six vector steps of the whole loop per graph replay (train_vec.PipelinedVecTD3Trainer.step_block)
+    else:
+        for _ in range(steps):
+            tr.step()
     barrier()
     dt = sharding.max_over_ranks(time.perf_counter() - t0, dev)
     out = {"value": world * (tr.env_steps - e0) / dt, "unit": "env-steps/s", "grad_steps_per_s": (tr.grad_steps - g0) / dt,
@@ -572,7 +578,7 @@ def _td3_run(a, dev, rank, world, dist, steps, warmup, batch):
            "batch_per_rank": batch, "updates_per_vector_step": a.td3_updates, "replay_capacity": 1000000, "start_timesteps": 10000,
            "update_to_data": "%d gradient step(s) of batch %d per vector step of %d env-steps per rank (samples drawn per env-step: %.3f; the reference "
                              "does 1 step of batch 100 per single env-step, plen_td3.py:119-120)" % (a.td3_updates, batch, n, a.td3_updates * batch / n),
-           "hip_graphs": True,
+           "hip_graphs": True, "graph_replays_per_vector_step": (round(1.0 / tr.BLOCK, 3) if blocks else (len(envs) + 1 if pipelined else None)),
            "schedule": ("actor/learner overlap: %d sub-batches of %d envs and the update on %d HIP streams, acting policy two updates old (train_vec.PipelinedVecTD3Trainer); "
                         "update: %s; actor forward of the collect phase as 16 envs per four-wave workgroup on packed weights (k_actor_block)" % (
                             H, n // H, H + 1, "large-batch kernels (csrc/td3_block.hip: 16 batch rows per four-wave workgroup, activations in LDS, packed weights, one weight-gradient "
@@ -615,8 +621,7 @@ def _td3_roofline(tr, batch, dev):
     import torch
     tr.recapture()
     tl = tr.enable_timeline(64)
-    for _ in range(64 * 2 + 40):
-        tr.step()
+    tr.run(64 * 2 + 40 + 2)          # (whole six-step blocks once every piece has been re-captured: the schedule the leg was timed in)
     tr.sync()
     torch.cuda.synchronize()
     t = tl.cpu().numpy().astype("int64")
@@ -764,6 +769,7 @@ def main():
     ap.add_argument("--td3-steps", type=int, default=2000, help="timed vector steps of the td3 and policy legs (2000 x ~0.5 ms: about a second each)")
     ap.add_argument("--td3-parts", type=int, default=2, help="sub-batches of the pipelined TD3 loop (collector streams)")
     ap.add_argument("--td3-schedule", default="pipelined", choices=["pipelined", "sync"], help="actor/learner overlap on three streams per rank, or the synchronous graph loop")
+    ap.add_argument("--td3-block-graph", type=int, default=1, help="1: six vector steps of the pipelined TD3 loop per hipGraph replay (one rank); 0: three graph replays per vector step")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

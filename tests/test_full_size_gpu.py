@@ -15,8 +15,8 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 N = 4096
 # fraction of the 4096 envs within 1e-4 of the oracle after the first control step in the reference configuration (measured r06: see the asserts' messages in GPUTEST), minus a margin
-FIRST_STEP_FRAC = {False: 0.75, True: 0.75}
-QUIET_FRAC, QUIET_TOL = 0.3, 1e-6
+FIRST_STEP_FRAC = {False: 0.79, True: 0.79}          # measured r06: 0.8206 / 0.8271 (round 5 asserted 0.75)
+QUIET_FRAC, QUIET_TOL = 0.33, 1e-9                    # measured r06: 0.379 of the envs are quiet, kernel error there max 4.4e-11 (elsewhere: median 1.2e-7, 71 % within 1e-4)
 
 
 def _run(dtype, T, rolling=None, dr=False, seed=0):
