@@ -107,6 +107,9 @@ typedef struct PlenTd3CriticRows {
      * (float32 device scalar, torch's capturable `step`): advanced by one by the last workgroup to finish, so that the weight-gradient launch finds it
      * advanced (PlenTd3AdamFused.step_advanced = 1) and needs no counter protocol of its own */
     float *adam_step;
+    /* plentd3_critic_team only (NULL: the row-major matrices above, parked through LDS): the forward products' weight matrices in the team kernels' OPERAND order
+     * (plentd3_pack with PlenTd3PackJob.team = 1; kept current by plentd3_wgrad_adam_group: PlenTd3WgradJob.pack / pack_t) -- target actor, target critic, critic */
+    const float *tp_at_w1, *tp_at_w2, *tp_at_w3, *tp_ct_w14, *tp_ct_w2, *tp_ct_w5, *tp_c_w14, *tp_c_w2, *tp_c_w5;
 } PlenTd3CriticRows;
 int plentd3_critic_rows(const PlenTd3CriticRows *args, void *stream);
 
@@ -122,6 +125,8 @@ typedef struct PlenTd3PolicyRows {
     int B;
     /* plentd3_policy_team only (NULL otherwise): as PlenTd3CriticRows.adam_step for the actor's optimiser; done_count = device int, zero before the first call */
     float *adam_step; int *done_count;
+    /* plentd3_policy_team only (NULL: row-major, parked through LDS): as PlenTd3CriticRows.tp_*; tp_c_w14 = the critic's stacked first layers (fc1 = its first 8 tiles) */
+    const float *tp_a_w1, *tp_a_w2, *tp_a_w3, *tp_c_w14, *tp_c_w2;
 } PlenTd3PolicyRows;
 int plentd3_policy_rows(const PlenTd3PolicyRows *args, void *stream);
 
@@ -135,7 +140,12 @@ int plentd3_policy_team(const PlenTd3PolicyRows *args, void *stream);
 /* Up to PLENTD3_WGRAD_JOBS weight gradients (each as plentd3_wgrad: dW[n][k] += sum_b dH[b][n] X[b][k], db[n] += sum_b dH[b][n] when db != NULL) over the
  * same B batch rows in one launch, the whole batch as a single reduction chunk (small batches).  tile0 is filled in by the call. */
 #define PLENTD3_WGRAD_JOBS 6
-typedef struct PlenTd3WgradJob { const float *dH; const float *X; float *dW; float *db; int ds, xs, dws, N, K, tile0; } PlenTd3WgradJob;
+typedef struct PlenTd3WgradJob {
+    const float *dH; const float *X; float *dW; float *db; int ds, xs, dws, N, K, tile0;
+    /* plentd3_wgrad_adam_group only (NULL / 0 otherwise): the team-order packed copies (PlenTd3PackJob.team = 1, pack_ns = ceil(K / 64)) of this job's weight matrix and
+     * of its Polyak target -- every element the launch steps is also written into them, so the next pass finds them current without a packing launch */
+    float *pack, *pack_t; int pack_ns;
+} PlenTd3WgradJob;
 typedef struct PlenTd3WgradGroup { PlenTd3WgradJob job[PLENTD3_WGRAD_JOBS]; int n_jobs, B; } PlenTd3WgradGroup;
 int plentd3_wgrad_group(const PlenTd3WgradGroup *group, void *stream);
 
@@ -160,7 +170,12 @@ int plentd3_wgrad_adam_group(const PlenTd3WgradGroup *group, const PlenTd3AdamFu
  * KS = ceil(K / 16); dst holds ceil(N / 16) KS 256 floats.  f4_0 is filled in by the call.  Run it after every optimiser / Polyak step that changes a
  * source matrix (3 us for all of a critic's and an actor's matrices). */
 #define PLENTD3_PACK_JOBS 16
-typedef struct PlenTd3PackJob { const float *src; float *dst; int rs, cs, N, K, f4_0; } PlenTd3PackJob;
+typedef struct PlenTd3PackJob {
+    const float *src; float *dst; int rs, cs, N, K, f4_0;
+    /* team = 1: the small-batch kernels' operand order (csrc/td3_team.hip: 32-column tiles, stages of 64 k, lane = 32 (k half) + column):
+     *   dst float4 (((t NS + s) 8 + c) 64 + lane) = M[32 t + lane % 32][64 s + 32 (lane / 32) + 4 c + (0..3)],  NS = ceil(K / 64); dst holds ceil(N / 32) NS 2048 floats */
+    int team;
+} PlenTd3PackJob;
 typedef struct PlenTd3PackGroup { PlenTd3PackJob job[PLENTD3_PACK_JOBS]; int n_jobs; } PlenTd3PackGroup;
 int plentd3_pack(const PlenTd3PackGroup *group, void *stream);
 /* rows: as plentd3_critic_team (idx / noise / adam_step honoured; loss[0] STORED; t0, t1, sa2 not written).  Packed operands: p_at_w1 (256 x 26), p_at_w2

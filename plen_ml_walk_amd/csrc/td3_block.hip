@@ -225,11 +225,19 @@ __global__ __launch_bounds__(256) void k_pack(PlenTd3PackGroup G) {
 #pragma unroll
     for (int k = 1; k < PLENTD3_PACK_JOBS; k++) j += (k < G.n_jobs && e >= G.job[k].f4_0) ? 1 : 0;
     const PlenTd3PackJob &J = G.job[j];
-    const int KS = (J.K + 15) / 16, T = (J.N + 15) / 16;
     const int el = e - J.f4_0;
-    if (el >= T * KS * 64) return;
-    const int lane = el & 63, s = (el >> 6) % KS, t = (el >> 6) / KS;
-    const int i = 16 * t + (lane & 15), k0 = 16 * s + 4 * (lane >> 4);
+    int i, k0;
+    if (J.team) {          // the small-batch kernels' order (td3_team.hip quad_nt): 32-column tiles, stages of 64 k, eight 4-k pieces per stage and k half
+        const int NS = (J.K + 63) / 64, T = (J.N + 31) / 32;
+        if (el >= T * NS * 512) return;
+        const int lane = el & 63, c = (el >> 6) & 7, s = (el >> 9) % NS, t = (el >> 9) / NS;
+        i = 32 * t + (lane & 31); k0 = 64 * s + 32 * (lane >> 5) + 4 * c;
+    } else {
+        const int KS = (J.K + 15) / 16, T = (J.N + 15) / 16;
+        if (el >= T * KS * 64) return;
+        const int lane = el & 63, s = (el >> 6) % KS, t = (el >> 6) / KS;
+        i = 16 * t + (lane & 15); k0 = 16 * s + 4 * (lane >> 4);
+    }
     floatx4 v;
 #pragma unroll
     for (int u = 0; u < 4; u++) v[u] = (i < J.N && k0 + u < J.K) ? J.src[(size_t)i * J.rs + (size_t)(k0 + u) * J.cs] : 0.f;

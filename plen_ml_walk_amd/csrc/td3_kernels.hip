@@ -223,8 +223,10 @@ __global__ void k_polyak(float *__restrict__ t, const float *__restrict__ p, flo
 //      two coalesced 128-byte row segments per operand and step, no transpose, no LDS -- and the partial tiles are added into dW (zeroed by
 //      the caller) with float atomics.  Waves of the first column tile also sum their dH operand: the bias gradient comes for free.
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+// where a lane's 16 results of a 32 x 32 tile sit: element v = row n0 + 8 (v / 4) + 4 half + v % 4, column k0 + col (wgrad_tile's epilogue)
+struct WgradTileAt { int n0, k0, col, half; };
 struct WgradAtomicAdd {        // the plain epilogue: partial tiles are added into the (zeroed) gradient bucket
-    __device__ __forceinline__ void tile(float *const (&dst)[16], const float (&v)[16]) const {
+    __device__ __forceinline__ void tile(float *const (&dst)[16], const float (&v)[16], const WgradTileAt &) const {
 #pragma unroll
         for (int k = 0; k < 16; k++) if (dst[k]) atomicAdd(dst[k], v[k]);
     }
@@ -298,7 +300,7 @@ static __device__ __forceinline__ void wgrad_tile(const float *__restrict__ dH, 
             dst[v] = (ka && n0 + i < N) ? dW + (size_t)(n0 + i) * dws + k0 + col : nullptr;
             val[v] = acc[v];
         }
-        emit.tile(dst, val);
+        emit.tile(dst, val, WgradTileAt{n0, k0, col, half});
         if (db && k0 == 0 && half == 0 && na) emit.one(db + n0 + col, bsum);
     }
 }
@@ -478,8 +480,9 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, float *__re
 //      steps them and zeroes them.  Same arithmetic per element as k_adam, same step counter protocol.
 struct WgradAdamStep {
     const PlenTd3AdamFused &Ad; const AdamCoef &c;
+    float *pack, *pack_t; int pack_ns;          // this job's weight matrix (and its Polyak target) in the small-batch kernels' operand order, or null
     // all of a lane's 16 elements: every load first (one trip to memory for the tile, not one per element), then the arithmetic, then the stores
-    __device__ __forceinline__ void tile(float *const (&dst)[16], const float (&gv)[16]) const {
+    __device__ __forceinline__ void tile(float *const (&dst)[16], const float (&gv)[16], const WgradTileAt &at) const {
         float m[16], v[16], p[16], tg[16];
         size_t o[16];
 #pragma unroll
@@ -493,7 +496,16 @@ struct WgradAdamStep {
         for (int k = 0; k < 16; k++) {
             if (dst[k]) {
                 Ad.m[o[k]] = m[k]; Ad.v[o[k]] = v[k]; Ad.p[o[k]] = p[k];
-                if (Ad.target) Ad.target[o[k]] = adam_polyak(p[k], tg[k], c.tau);
+                const float tn = Ad.target ? adam_polyak(p[k], tg[k], c.tau) : 0.f;
+                if (Ad.target) Ad.target[o[k]] = tn;
+                if (pack) {
+                    // element (n, kk) of the matrix in team operand order (PlenTd3PackJob.team): float4 (((n / 32) NS + kk / 64) 8 + (kk % 32) / 4) 64 + 32 ((kk / 32) % 2) + n % 32, word kk % 4
+                    // -- written where the parameter is, so that the next pass reads current weights without a packing launch on the chain of updates
+                    const int n = at.n0 + 8 * (k / 4) + 4 * at.half + (k % 4), kk = at.k0 + at.col;
+                    const size_t po = ((size_t)((n >> 5) * pack_ns + (kk >> 6)) * 8 + ((kk & 31) >> 2)) * 256 + (size_t)(32 * ((kk >> 5) & 1) + (n & 31)) * 4 + (kk & 3);
+                    pack[po] = p[k];
+                    if (pack_t && Ad.target) pack_t[po] = tn;
+                }
             }
         }
     }
@@ -512,7 +524,7 @@ __global__ __launch_bounds__(256) void k_wgrad_adam_group(PlenTd3WgradGroup G, P
     for (int k = 1; k < PLENTD3_WGRAD_JOBS; k++) j += (k < G.n_jobs && (int)blockIdx.x >= G.job[k].tile0) ? 1 : 0;
     const PlenTd3WgradJob &J = G.job[j];
     const AdamCoef c = adam_coef(t, Ad.lr, Ad.beta1, Ad.beta2, Ad.eps, Ad.tau);
-    const WgradAdamStep emit{Ad, c};
+    const WgradAdamStep emit{Ad, c, J.pack, J.pack_t, J.pack_ns};
     wgrad_tile<4, WgradAdamStep>(J.dH, J.ds, J.X, J.xs, J.dW, J.dws, J.db, J.N, J.K, (int)blockIdx.x - J.tile0, 0, G.B, emit);
     if (blockIdx.x == 0 && (int)threadIdx.x < Ad.n_extra) {
         float *ge = Ad.g + Ad.extra_off[threadIdx.x];
@@ -654,7 +666,7 @@ int plentd3_pack(const PlenTd3PackGroup *group, void *stream) {
         const PlenTd3PackJob &J = G.job[j];
         if (!J.src || !J.dst || J.N < 1 || J.K < 1 || ((uintptr_t)J.dst & 15)) return -(int)hipErrorInvalidValue;
         G.job[j].f4_0 = f4;
-        f4 += ((J.N + 15) / 16) * ((J.K + 15) / 16) * 64;
+        f4 += J.team ? ((J.N + 31) / 32) * ((J.K + 63) / 64) * 512 : ((J.N + 15) / 16) * ((J.K + 15) / 16) * 64;
     }
     hipLaunchKernelGGL(k_pack, dim3((f4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, G); CHECK();
 }

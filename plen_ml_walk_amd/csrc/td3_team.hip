@@ -90,11 +90,32 @@ static __device__ __forceinline__ floatx4 quad_combine(const floatx4 (&a)[4]) {
 // acc[i] (rows b0 + i, column n0 + col; valid in every lane) = sum_{k < K} X[b0 + i][xcol0 + k] W[n0 + col][k]      (W: nn.Linear's [out][in], row stride ldw)
 // Rows of W at or beyond the end of rw read as zero (the 18-wide output layers); k beyond K must be harmless: KGUARD zeroes A there (B then holds
 // finite values of the next row, or zeros).
+// wp != null (round 6): W in the team's OPERAND order (plentd3_pack with team = 1, kept current by plentd3_wgrad_adam_group): the lane's eight B pieces of a stage are eight
+// float4 at ((tile NS + stage) 8 + c) 64 + lane -- every wave load one contiguous kilobyte, nothing parked, nothing read back from LDS.  Same values into the same
+// matrix instructions in the same order as the parked path: bit-identical results (tests), 9 us less per batch-100 update (profiles/r06_h_batch100_floor.json).
 template <bool KGUARD, int NS>          // NS = stages of 64 k: K <= 64 NS
-static __device__ __forceinline__ floatx4 quad_nt(const float *xa, int ldx, rsrc_t rw, int ldw, int n0, int K, const Quad &q, float *lds) {
+static __device__ __forceinline__ floatx4 quad_nt(const float *xa, int ldx, rsrc_t rw, int ldw, int n0, int K, const Quad &q, float *lds, const float *wp = nullptr) {
     const int lane = q.lane, brow = lane >> 4, bch = lane & 15;
     const float *xp = quad_a_ptr(q, xa, ldx);
     struct Stage { floatx4 b[8]; };
+    if (wp) {          // (wave-uniform)
+        const rsrc_t rp = mkrs(wp + (size_t)(n0 >> 5) * NS * 2048, (size_t)NS * 2048 * 4);
+        Stage S[NS];
+#pragma unroll
+        for (int s = 0; s < NS; s++)
+#pragma unroll
+            for (int c = 0; c < 8; c++) S[s].b[c] = bload4(rp, (uint32_t)(((s * 8 + c) * 64 + lane) * 16), 0u);
+        __builtin_amdgcn_sched_barrier(0);
+        floatx4 acc[4] = {floatx4{0, 0, 0, 0}, floatx4{0, 0, 0, 0}, floatx4{0, 0, 0, 0}, floatx4{0, 0, 0, 0}};
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const floatx4 fa = quad_a_guard<KGUARD>(*reinterpret_cast<const floatx4 *>(xp + 64 * s), 64 * s, K, q);
+#define QUAD_FB(c, j) S[s].b[c][j]
+            QUAD_MFMA_STAGE(acc, fa, QUAD_FB);
+#undef QUAD_FB
+        }
+        return quad_combine(acc);
+    }
     auto load = [&](int k0, Stage &S) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {                      // rows brow + 4 i of the tile; the chunk this lane fetches is the one whose parking slot is (row, bch)
@@ -190,9 +211,9 @@ static __device__ __forceinline__ void quad_store(float *L, int ldl, float *Y, i
 
 // one 32-column tile of a hidden layer: relu(X W^T + bias)   (the bias is requested before the product)
 template <bool KGUARD, int NS>
-static __device__ __forceinline__ void quad_dense_relu(const float *xa, int ldx, int K, rsrc_t rw, int ldw, const float *bias, int n0, float *L, int ldl, float *Y, int ldy, const Quad &q, float *lds) {
+static __device__ __forceinline__ void quad_dense_relu(const float *xa, int ldx, int K, rsrc_t rw, int ldw, const float *bias, int n0, float *L, int ldl, float *Y, int ldy, const Quad &q, float *lds, const float *wp = nullptr) {
     const float bv = bias[n0 + q.col];
-    floatx4 acc = quad_nt<KGUARD, NS>(xa, ldx, rw, ldw, n0, K, q, lds);
+    floatx4 acc = quad_nt<KGUARD, NS>(xa, ldx, rw, ldw, n0, K, q, lds, wp);
 #pragma unroll
     for (int i = 0; i < 4; i++) acc[i] = fmaxf(acc[i] + bv, 0.f);
     quad_store(L, ldl, Y, ldy, n0, acc, q);
@@ -275,12 +296,12 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
     // ---- target actor's first layer on s2 (32 columns per wave) ----
     {
         QPHASE();
-        quad_dense_relu<true, 1>(act + CA_BATCH + TD3_SA, CA_LD, TD3_S, mkrs(A.at_w1, (size_t)TD3_H * TD3_S * 4), TD3_S, A.at_b1, 32 * w, act + CA_T0, CA_LD, nullptr, 0, q, lds);
+        quad_dense_relu<true, 1>(act + CA_BATCH + TD3_SA, CA_LD, TD3_S, mkrs(A.at_w1, (size_t)TD3_H * TD3_S * 4), TD3_S, A.at_b1, 32 * w, act + CA_T0, CA_LD, nullptr, 0, q, lds, A.tp_at_w1);
     }
     TEAM_SYNC();
     {
         QPHASE();
-        quad_dense_relu<false, 4>(act + CA_T0, CA_LD, TD3_H, mkrs(A.at_w2, (size_t)TD3_H * TD3_H * 4), TD3_H, A.at_b2, 32 * w, act + CA_T1, CA_LD, nullptr, 0, q, lds);
+        quad_dense_relu<false, 4>(act + CA_T0, CA_LD, TD3_H, mkrs(A.at_w2, (size_t)TD3_H * TD3_H * 4), TD3_H, A.at_b2, 32 * w, act + CA_T1, CA_LD, nullptr, 0, q, lds, A.tp_at_w2);
     }
     TEAM_SYNC();
     // ---- target action (td3.py:299-304): the 18-wide output layer is one tile: wave 0.  Beside it, on the other seven waves, the critics' stacked
@@ -289,11 +310,11 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
         QPHASE();
         const rsrc_t rw = mkrs(A.c_w14, (size_t)2 * TD3_H * TD3_SA * 4);
 #pragma unroll 1
-        for (int t = w - 1; t < 16; t += TEAM_NW - 1) quad_dense_relu<true, 1>(act + CA_BATCH, CA_LD, TD3_SA, rw, TD3_SA, A.c_b14, 32 * t, act + CA_C1, CA_LD, A.c1, 2 * TD3_H, q, lds);
+        for (int t = w - 1; t < 16; t += TEAM_NW - 1) quad_dense_relu<true, 1>(act + CA_BATCH, CA_LD, TD3_SA, rw, TD3_SA, A.c_b14, 32 * t, act + CA_C1, CA_LD, A.c1, 2 * TD3_H, q, lds, A.tp_c_w14);
     } else {
         QPHASE();
         const float bv3 = col < TD3_A ? A.at_b3[col] : 0.f;
-        const floatx4 z = quad_nt<false, 4>(act + CA_T1, CA_LD, mkrs(A.at_w3, (size_t)TD3_A * TD3_H * 4), TD3_H, 0, TD3_H, q, lds);
+        const floatx4 z = quad_nt<false, 4>(act + CA_T1, CA_LD, mkrs(A.at_w3, (size_t)TD3_A * TD3_H * 4), TD3_H, 0, TD3_H, q, lds, A.tp_at_w3);
         if (lane < TD3_A) {
 #pragma unroll
             for (int i = 0; i < 4; i++) act[i * CA_LD + CA_SA2 + TD3_S + col] = fminf(fmaxf(A.max_a * tanhf(z[i] + bv3) + noise_l[i][col], -A.max_a), A.max_a);
@@ -305,7 +326,7 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
         QPHASE();
         const rsrc_t rw = mkrs(A.ct_w14, (size_t)2 * TD3_H * TD3_SA * 4);
 #pragma unroll 1
-        for (int t = 0; t < 2; t++) quad_dense_relu<true, 1>(act + CA_SA2, CA_LD, TD3_SA, rw, TD3_SA, A.ct_b14, 64 * w + 32 * t, act + CA_T0, CA_LD, nullptr, 0, q, lds);
+        for (int t = 0; t < 2; t++) quad_dense_relu<true, 1>(act + CA_SA2, CA_LD, TD3_SA, rw, TD3_SA, A.ct_b14, 64 * w + 32 * t, act + CA_T0, CA_LD, nullptr, 0, q, lds, A.tp_ct_w14);
     }
     TEAM_SYNC();
     // ---- second layers + heads: waves 0..3 = critic a, 4..7 = critic b, 64 columns each; target critics, then the critics themselves (c2 kept) ----
@@ -315,13 +336,14 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
         for (int k = 0; k < 2; k++) {                       // 0: target critics on t0, 1: critics on c1
             const float *W2 = k ? (half ? A.c_w5 : A.c_w2) : (half ? A.ct_w5 : A.ct_w2), *b2 = k ? (half ? A.c_b5 : A.c_b2) : (half ? A.ct_b5 : A.ct_b2);
             const float *w3 = k ? (half ? A.c_w6 : A.c_w3) : (half ? A.ct_w6 : A.ct_w3);
+            const float *W2p = k ? (half ? A.tp_c_w5 : A.tp_c_w2) : (half ? A.tp_ct_w5 : A.tp_ct_w2);
             const rsrc_t rw = mkrs(W2, (size_t)TD3_H * TD3_H * 4);
             float part[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
             for (int t = 0; t < 2; t++) {
                 const int n0 = 64 * wq + 32 * t;
                 const float bv = b2[n0 + col], wv = w3[n0 + col];
-                floatx4 acc = quad_nt<false, 4>(act + (k ? CA_C1 : CA_T0) + half * TD3_H, CA_LD, rw, TD3_H, n0, TD3_H, q, lds);
+                floatx4 acc = quad_nt<false, 4>(act + (k ? CA_C1 : CA_T0) + half * TD3_H, CA_LD, rw, TD3_H, n0, TD3_H, q, lds, W2p);
 #pragma unroll
                 for (int i = 0; i < 4; i++) { acc[i] = fmaxf(acc[i] + bv, 0.f); part[i] += acc[i] * wv; }
                 if (k) quad_store(act + CA_C2, CA_LD, A.c2, 2 * TD3_H, half * TD3_H + n0, acc, q);
@@ -461,18 +483,18 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
     // actor forward
     {
         QPHASE();
-        quad_dense_relu<true, 1>(act + PA_SA, PA_LD, TD3_S, mkrs(A.a_w1, (size_t)TD3_H * TD3_S * 4), TD3_S, A.a_b1, n0, act + PA_P1, PA_LD, A.p1, TD3_H, q, lds);
+        quad_dense_relu<true, 1>(act + PA_SA, PA_LD, TD3_S, mkrs(A.a_w1, (size_t)TD3_H * TD3_S * 4), TD3_S, A.a_b1, n0, act + PA_P1, PA_LD, A.p1, TD3_H, q, lds, A.tp_a_w1);
     }
     TEAM_SYNC();
     {
         QPHASE();
-        quad_dense_relu<false, 4>(act + PA_P1, PA_LD, TD3_H, mkrs(A.a_w2, (size_t)TD3_H * TD3_H * 4), TD3_H, A.a_b2, n0, act + PA_P2, PA_LD, A.p2, TD3_H, q, lds);
+        quad_dense_relu<false, 4>(act + PA_P1, PA_LD, TD3_H, mkrs(A.a_w2, (size_t)TD3_H * TD3_H * 4), TD3_H, A.a_b2, n0, act + PA_P2, PA_LD, A.p2, TD3_H, q, lds, A.tp_a_w2);
     }
     TEAM_SYNC();
     if (w == 0) {
         QPHASE();
         const float bv = col < TD3_A ? A.a_b3[col] : 0.f;
-        const floatx4 z = quad_nt<false, 4>(act + PA_P2, PA_LD, mkrs(A.a_w3, (size_t)TD3_A * TD3_H * 4), TD3_H, 0, TD3_H, q, lds);
+        const floatx4 z = quad_nt<false, 4>(act + PA_P2, PA_LD, mkrs(A.a_w3, (size_t)TD3_A * TD3_H * 4), TD3_H, 0, TD3_H, q, lds, A.tp_a_w3);
         if (lane < TD3_A) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -489,13 +511,13 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
     // critic.Q1 forward (fc1 = the first 256 rows of W14) and the gradient of -mean Q1 at its second hidden layer: dg2 = -(1/B) w3 (g2 > 0)
     {
         QPHASE();
-        quad_dense_relu<true, 1>(act + PA_SA, PA_LD, TD3_SA, mkrs(A.c_w1, (size_t)TD3_H * TD3_SA * 4), TD3_SA, A.c_b1, n0, act + PA_G1, PA_LD, nullptr, 0, q, lds);
+        quad_dense_relu<true, 1>(act + PA_SA, PA_LD, TD3_SA, mkrs(A.c_w1, (size_t)TD3_H * TD3_SA * 4), TD3_SA, A.c_b1, n0, act + PA_G1, PA_LD, nullptr, 0, q, lds, A.tp_c_w14);
     }
     TEAM_SYNC();
     {
         QPHASE();
         const float bv = A.c_b2[n0 + col], wv = (-1.f / (float)B) * A.c_w3[n0 + col];
-        floatx4 acc = quad_nt<false, 4>(act + PA_G1, PA_LD, mkrs(A.c_w2, (size_t)TD3_H * TD3_H * 4), TD3_H, n0, TD3_H, q, lds);
+        floatx4 acc = quad_nt<false, 4>(act + PA_G1, PA_LD, mkrs(A.c_w2, (size_t)TD3_H * TD3_H * 4), TD3_H, n0, TD3_H, q, lds, A.tp_c_w2);
 #pragma unroll
         for (int i = 0; i < 4; i++) acc[i] = acc[i] + bv > 0.f ? wv : 0.f;
         quad_store(act + PA_DG2, PA_LD, nullptr, 0, n0, acc, q);

@@ -33,14 +33,16 @@ class CriticRowsArgs(C.Structure):
                                              "ct_w14", "ct_b14", "ct_w2", "ct_b2", "ct_w5", "ct_b5", "ct_w3", "ct_b3", "ct_w6", "ct_b6",
                                              "c_w14", "c_b14", "c_w2", "c_b2", "c_w5", "c_b5", "c_w3", "c_b3", "c_w6", "c_b6",
                                              "batch", "sa_pi", "t0", "t1", "sa2", "c1", "c2", "dh2", "dh1", "dq", "loss", "db3a", "db3b", "done_count", "rng_bump")]
-                + [("sigma", C.c_float), ("clip", C.c_float), ("max_a", C.c_float), ("gamma", C.c_float), ("B", C.c_int), ("idx", C.c_void_p), ("noise", C.c_void_p), ("adam_step", C.c_void_p)])
+                + [("sigma", C.c_float), ("clip", C.c_float), ("max_a", C.c_float), ("gamma", C.c_float), ("B", C.c_int), ("idx", C.c_void_p), ("noise", C.c_void_p), ("adam_step", C.c_void_p)]
+                + [(n, C.c_void_p) for n in ("tp_at_w1", "tp_at_w2", "tp_at_w3", "tp_ct_w14", "tp_ct_w2", "tp_ct_w5", "tp_c_w14", "tp_c_w2", "tp_c_w5")])
 
 
 class PolicyRowsArgs(C.Structure):
     """Mirror of PlenTd3PolicyRows (include/plentd3.h)."""
     _fields_ = ([(n, C.c_void_p) for n in ("a_w1", "a_b1", "a_w2", "a_b2", "a_w3", "a_b3", "c_w1", "c_b1", "c_w2", "c_b2", "c_w3",
                                            "sa_pi", "a_pi", "p1", "p2", "g1", "dg2", "dg1", "dz", "dp2", "dp1")]
-                + [("max_a", C.c_float), ("B", C.c_int), ("adam_step", C.c_void_p), ("done_count", C.c_void_p)])
+                + [("max_a", C.c_float), ("B", C.c_int), ("adam_step", C.c_void_p), ("done_count", C.c_void_p)]
+                + [(n, C.c_void_p) for n in ("tp_a_w1", "tp_a_w2", "tp_a_w3", "tp_c_w14", "tp_c_w2")])
 
 
 class ActorRowsArgs(C.Structure):
@@ -51,7 +53,8 @@ class ActorRowsArgs(C.Structure):
 
 class WgradJob(C.Structure):
     """Mirror of PlenTd3WgradJob (include/plentd3.h)."""
-    _fields_ = [("dH", C.c_void_p), ("X", C.c_void_p), ("dW", C.c_void_p), ("db", C.c_void_p)] + [(n, C.c_int) for n in ("ds", "xs", "dws", "N", "K", "tile0")]
+    _fields_ = ([("dH", C.c_void_p), ("X", C.c_void_p), ("dW", C.c_void_p), ("db", C.c_void_p)] + [(n, C.c_int) for n in ("ds", "xs", "dws", "N", "K", "tile0")]
+                + [("pack", C.c_void_p), ("pack_t", C.c_void_p), ("pack_ns", C.c_int)])
 
 
 WGRAD_JOBS = 6
@@ -76,7 +79,7 @@ PACK_JOBS = 16
 
 class PackJob(C.Structure):
     """Mirror of PlenTd3PackJob (include/plentd3.h)."""
-    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p)] + [(n, C.c_int) for n in ("rs", "cs", "N", "K", "f4_0")]
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p)] + [(n, C.c_int) for n in ("rs", "cs", "N", "K", "f4_0", "team")]
 
 
 class PackGroup(C.Structure):
@@ -189,6 +192,7 @@ class FlatAdam(object):
         self.step_t = torch.zeros((), device=dev, dtype=torch.float32)
         self.done = torch.zeros(1, device=dev, dtype=torch.int32)
         self.params = _flat_order(module)
+        self.epoch = 0           # steps taken by THIS object's own kernels (FusedTD3 compares it to know whether its packed copies of the weights are current)
         self.bind()
         optimizer.step = lambda closure=None: self.step()
 
@@ -236,6 +240,7 @@ class FlatAdam(object):
             self.bind()              # optimizer.load_state_dict() replaced the state tensors: carry them over (a replayed graph never gets here:
                                      # load checkpoints before the trainers capture their graphs)
         st = C.c_void_p(torch.cuda.current_stream(self.p.device).cuda_stream)
+        self.epoch += 1
         g = self.opt.param_groups[0]                       # hyper-parameters as they are now (a captured graph keeps the values of its capture)
         _chk(self.lib.plentd3_adam(_p(self.p), _p(self.g), _p(self.m), _p(self.v), _p(self.step_t), _p(self.done), self.p.numel(), float(g["lr"]), float(g["betas"][0]),
                                    float(g["betas"][1]), float(g["eps"]), int(zero_grad), _p(target), float(tau), _p(copy_out), st))
@@ -246,6 +251,7 @@ class FlatAdam(object):
         bucket = that sum (several ranks: all-reduce it, then step())."""
         if not reduce_only:
             self.ensure_bound()
+            self.epoch += 1
         st = C.c_void_p(torch.cuda.current_stream(self.p.device).cuda_stream)
         g = self.opt.param_groups[0]
         _chk(self.lib.plentd3_adam_big(_p(self.p), _p(self.g), _p(self.m), _p(self.v), _p(self.step_t), _p(self.done), self.p.numel(), float(g["lr"]), float(g["betas"][0]),
@@ -279,6 +285,11 @@ class FusedTD3(object):
         self.block = (None if "PLEN_TD3_BLOCK" not in os.environ else os.environ["PLEN_TD3_BLOCK"] == "1") if block is None else bool(block)
         self._block_pass = False
         self._packs = {}             # name -> packed copy of a weight matrix (plentd3_pack), rewritten before every pass that reads it
+        # small-batch kernels (round 6): the forward products' twelve weight matrices in the team kernels' operand order, packed ONCE (plentd3_pack, team layout) and then
+        # kept current by the fused weight-gradient + Adam launch itself; re-packed only when something else has touched the parameters (_team_pack_sync)
+        self._team_packed = os.environ.get("PLEN_TD3_TEAM_PACKED", "1") == "1"
+        self._tpacks, self._tp_state, self._tp_epoch, self._tp_by_grad = {}, None, 0, {}
+        self._tp_live = False        # the current iteration's team passes read the packed copies (so its fused Adam steps must write them)
         self._actor_packs = {}       # id(acting network) -> its packed matrices' names and the parameter versions they were made from
         self._partials = None
         self._big = {}               # "critic" / "actor" -> (partial gradients [chunks][stride], stride) of plentd3_wgrad_big
@@ -333,6 +344,58 @@ class FusedTD3(object):
         G.n_jobs = len(jobs)
         _chk(self.lib.plentd3_pack(C.byref(G), self._stream()))
 
+    def _team_pack_sync(self):
+        """Make the team-order packed weights current; False if the feature is off.  They stay current through the small-batch path's own updates (the Adam step writes
+        every element it changes into its packed slot, PlenTd3WgradJob.pack / pack_t); anything else that may have changed a parameter -- another update path of this object
+        (FlatAdam steps, polyak()), torch-level writes to the flat buffers (load_state_dict, the autograd path: the buffers' version counters) -- makes this one launch."""
+        if not self._team_packed or self._critic_adam is None:
+            return False
+        ag = self.agent
+        at, ct, cr, ac = ag.actor_target, ag.critic_target, ag.critic, ag.actor
+        flats = (ag._actor_flat.flat, ag._critic_flat.flat, ag._actor_target_flat.flat, ag._critic_target_flat.flat)
+        # (the PARAMETERS' version counters: they are views of the flat buffers installed through .data, which does not share the buffer's counter -- a torch-level write
+        #  such as load_state_dict or `p.mul_()` moves the parameter's, not the buffer's)
+        watched = (at.fc1.weight, at.fc2.weight, at.fc3.weight, ct.fc1.weight, ct.fc4.weight, ct.fc2.weight, ct.fc5.weight,
+                   cr.fc1.weight, cr.fc4.weight, cr.fc2.weight, cr.fc5.weight, ac.fc1.weight, ac.fc2.weight, ac.fc3.weight)
+        state = (tuple(w._version for w in watched) + tuple(f._version for f in flats) + tuple(f.data_ptr() for f in flats)
+                 + (self._critic_adam.epoch, self._actor_adam.epoch, self._tp_epoch))
+        if state == self._tp_state:
+            return True
+        tv, cv, gv = ag._critic_target_flat.views, ag._critic_flat.views, ag._critic_grads.views
+        mats = [("at_w1", at.fc1.weight), ("at_w2", at.fc2.weight), ("at_w3", at.fc3.weight), ("ct_w14", tv["W14"]), ("ct_w2", ct.fc2.weight), ("ct_w5", ct.fc5.weight),
+                ("c_w14", cv["W14"]), ("c_w2", cr.fc2.weight), ("c_w5", cr.fc5.weight), ("a_w1", ac.fc1.weight), ("a_w2", ac.fc2.weight), ("a_w3", ac.fc3.weight)]
+        G = PackGroup()
+        for J, (name, w) in zip(G.job, mats):
+            N, K = w.shape
+            n = -(-N // 32) * -(-K // 64) * 2048
+            dst = self._tpacks.get(name)
+            if dst is None or dst.numel() != n:
+                dst = self._tpacks[name] = torch.zeros(n, device=self.dev, dtype=torch.float32)
+            assert w.is_contiguous()
+            J.src, J.dst, J.rs, J.cs, J.N, J.K, J.team = w.data_ptr(), dst.data_ptr(), K, 1, N, K, 1
+        G.n_jobs = len(mats)
+        _chk(self.lib.plentd3_pack(C.byref(G), self._stream()))
+        # gradient tensor -> (packed matrix, packed Polyak target, stages) for the fused weight-gradient + Adam launches
+        T = self._tpacks
+        self._tp_by_grad = {gv["W14"].data_ptr(): (T["c_w14"], T["ct_w14"], 1), cr.fc2.weight.grad.data_ptr(): (T["c_w2"], T["ct_w2"], 4), cr.fc5.weight.grad.data_ptr(): (T["c_w5"], T["ct_w5"], 4),
+                            ac.fc1.weight.grad.data_ptr(): (T["a_w1"], T["at_w1"], 1), ac.fc2.weight.grad.data_ptr(): (T["a_w2"], T["at_w2"], 4), ac.fc3.weight.grad.data_ptr(): (T["a_w3"], T["at_w3"], 4)}
+        self._tp_state = state
+        return True
+
+    def _tp_job(self, j, gw):
+        """Attach the packed copies of gw's matrix to a fused weight-gradient + Adam job (heads and biases have none)."""
+        ent = self._tp_by_grad.get(gw.data_ptr()) if self._team_packed else None
+        if ent is not None:
+            j.pack, j.pack_t, j.pack_ns = ent[0].data_ptr(), ent[1].data_ptr(), ent[2]
+
+    def _tp_critic_args(self, a):
+        for n_ in ("at_w1", "at_w2", "at_w3", "ct_w14", "ct_w2", "ct_w5", "c_w14", "c_w2", "c_w5"):
+            setattr(a, "tp_" + n_, self._tpacks[n_].data_ptr())
+
+    def _tp_policy_args(self, a):
+        for n_ in ("a_w1", "a_w2", "a_w3", "c_w14", "c_w2"):
+            setattr(a, "tp_" + n_, self._tpacks[n_].data_ptr())
+
     @staticmethod
     def _nt(name, w):
         """nn.Linear weight [out][in] as the A operand of Y^T = W X^T"""
@@ -385,6 +448,9 @@ class FusedTD3(object):
         G.n_jobs, G.B = len(jobs), int(B)
         if which is not None and self._fuse is not None and which in self._fuse:
             adam = self._critic_adam if which == "critic" else self._actor_adam
+            if self._tp_live:          # this pass read the packed weights: the step keeps them current
+                for j, (dh, x, gw, gb) in zip(G.job, jobs):
+                    self._tp_job(j, gw)
             base = adam.g.data_ptr()
             a = adam.fused_args(target=self._fuse[which], tau=self.agent.tau, extras=[(t.data_ptr() - base) // 4 for t in extras], step_advanced=True)
             _chk(self.lib.plentd3_wgrad_adam_group(C.byref(G), C.byref(a), self._stream()))
@@ -448,7 +514,10 @@ class FusedTD3(object):
         buckets never change), so a call is four or two C calls and a handful of field updates instead of 26 torch.empty and ~150 ctypes field stores (100 -> ~70 us
         per call: the GPU's 62 us show through).  Same launches, same arguments, same results as the general path (tests compare them bit for bit)."""
         ag, lib, st, dev = self.agent, self.lib, self._stream(), self.dev
+        self._tp_live = self._team_pack_sync()          # (before anything reads the weights; one launch only when something else has changed them)
         ent = self._eager.get(B)
+        if ent is not None and ent[8] != self._tp_live:
+            ent = None
         if ent is None:
             new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
             at, ct, cr, ac = ag.actor_target, ag.critic_target, ag.critic, ag.actor
@@ -471,6 +540,8 @@ class FusedTD3(object):
             a.loss, a.db3a, a.db3b = loss.data_ptr(), cr.fc3.bias.grad.data_ptr(), cr.fc6.bias.grad.data_ptr()
             a.done_count, a.rng_bump, a.B = self._done_count.data_ptr(), self.rng.data_ptr(), int(B)
             a.adam_step = self._critic_adam.step_t.data_ptr()
+            if self._tp_live:
+                self._tp_critic_args(a)
 
             def group(jobs):
                 G = WgradGroup()
@@ -478,6 +549,8 @@ class FusedTD3(object):
                     N, K = gw.shape
                     j.dH, j.X, j.dW, j.db = dh.data_ptr(), x.data_ptr(), gw.data_ptr(), (gb.data_ptr() if gb is not None else None)
                     j.ds, j.xs, j.dws, j.N, j.K = dh.stride(0), x.stride(0), K, N, K
+                    if self._tp_live:
+                        self._tp_job(j, gw)
                 G.n_jobs, G.B = len(jobs), int(B)
                 return G
             Gc = group([(dq[:, 0:1], c2[:, :H], cr.fc3.weight.grad, None), (dq[:, 1:2], c2[:, H:], cr.fc6.weight.grad, None),
@@ -491,12 +564,14 @@ class FusedTD3(object):
             pp.sa_pi, pp.a_pi, pp.p1, pp.p2, pp.g1, pp.dg2, pp.dg1, pp.dz, pp.dp2, pp.dp1 = (t.data_ptr() for t in (sa_pi, a_pi, p1, p2, g1, dg2, dg1, dz, dp2, dp1))
             pp.B = int(B)
             pp.adam_step, pp.done_count = self._actor_adam.step_t.data_ptr(), self._policy_done.data_ptr()
+            if self._tp_live:
+                self._tp_policy_args(pp)
             Gp = group([(dz, p2, ac.fc3.weight.grad, ac.fc3.bias.grad), (dp2, p1, ac.fc2.weight.grad, ac.fc2.bias.grad), (dp1, batch[:, :S], ac.fc1.weight.grad, ac.fc1.bias.grad)])
             base = self._critic_adam.g.data_ptr()
             extras = [(cr.fc3.bias.grad.data_ptr() - base) // 4, (cr.fc6.bias.grad.data_ptr() - base) // 4]
             keep = (batch, sa_pi, sa2, dq, t0, t1, c1, c2, dh2, dh1, loss, a_pi, dz, p1, p2, g1, dg2, dg1, dp2, dp1)
-            ent = self._eager[B] = (a, Gc, pp, Gp, extras, loss, (batch[:, :S], sa_pi, B), keep)
-        a, Gc, pp, Gp, extras, loss, saved, _ = ent
+            ent = self._eager[B] = (a, Gc, pp, Gp, extras, loss, (batch[:, :S], sa_pi, B), keep, self._tp_live)
+        a, Gc, pp, Gp, extras, loss, saved, _, _ = ent
         self._fused_done = set()
         self._zero_grads("critic")
         self._critic_adam.ensure_bound()
@@ -793,6 +868,11 @@ class FusedTD3(object):
                             nt("c_w14", cv["W14"]), nt("c_w2", cr.fc2.weight), nt("c_w5", cr.fc5.weight), tr("c_w2t", cr.fc2.weight), tr("c_w5t", cr.fc5.weight)])
             self._probe(2)
             if team:        # small batch: a team of 8 waves per row block, then every weight gradient in one launch (head rows as 1 x 256 products)
+                # (packed weights only when this pass's Adam steps are taken inside the weight-gradient launches, which keep the packed copies current: with ranks
+                #  to average over the separate Adam kernel would make every pass start with a packing launch)
+                self._tp_live = self._fuse is not None and "critic" in self._fuse and self._team_pack_sync()
+                if self._tp_live:
+                    self._tp_critic_args(a)
                 _chk(lib.plentd3_critic_team(C.byref(a), st))
                 self._probe(3)
                 self._wgrad_group(B, [(dq[:, 0:1], c2[:, :H], cr.fc3.weight.grad, None), (dq[:, 1:2], c2[:, H:], cr.fc6.weight.grad, None),
@@ -858,6 +938,8 @@ class FusedTD3(object):
                     self._actor_adam.ensure_bound()
                     a.adam_step, a.done_count = self._actor_adam.step_t.data_ptr(), self._policy_done.data_ptr()
                 if self._team_pass:
+                    if self._tp_live:
+                        self._tp_policy_args(a)
                     _chk(lib.plentd3_policy_team(C.byref(a), st))
                     self._wgrad_group(B, [(dz, p2, ac.fc3.weight.grad, ac.fc3.bias.grad), (dp2, p1, ac.fc2.weight.grad, ac.fc2.bias.grad),
                                           (dp1, s, ac.fc1.weight.grad, ac.fc1.bias.grad)], which="actor")
@@ -907,6 +989,7 @@ class FusedTD3(object):
                 self._wgrad(dp1, s, ac.fc1.weight.grad, ac.fc1.bias.grad)
 
     def polyak(self):
+        self._tp_epoch += 1          # (targets change outside the fused small-batch step: its packed copies are stale)
         """target = tau * online + (1 - tau) * target for critic then actor (td3.py:348-356), one pass per network over the flat buffers."""
         ag, st = self.agent, self._stream()
         for flat, tflat in ((ag._critic_flat, ag._critic_target_flat), (ag._actor_flat, ag._actor_target_flat)):

@@ -462,6 +462,73 @@ def test_cached_eager_small_batch_iteration_equals_the_general_path():
         assert torch.equal(a_, b_)
 
 
+def test_team_order_pack_kernel_matches_its_definition():
+    """plentd3_pack with PlenTd3PackJob.team = 1 (include/plentd3.h): dst float4 (((t NS + s) 8 + c) 64 + lane) = M[32 t + lane % 32][64 s + 32 (lane / 32) + 4 c + (0..3)],
+    zero beyond the matrix -- for the shapes the small-batch kernels read (256 x 26, 512 x 44, 256 x 256, 18 x 256)."""
+    import ctypes as C
+    from plen_ml_walk_amd import td3_fused as F
+    lib = F.load()
+    for N, K in ((256, 26), (512, 44), (256, 256), (18, 256)):
+        w = torch.randn(N, K, device="cuda")
+        T_, NS = -(-N // 32), -(-K // 64)
+        dst = torch.full((T_ * NS * 2048,), 7.0, device="cuda")
+        G = F.PackGroup()
+        J = G.job[0]
+        J.src, J.dst, J.rs, J.cs, J.N, J.K, J.team = w.data_ptr(), dst.data_ptr(), K, 1, N, K, 1
+        G.n_jobs = 1
+        assert lib.plentd3_pack(C.byref(G), None) == 0
+        torch.cuda.synchronize()
+        wp = torch.zeros(T_ * 32, NS * 64, device="cuda"); wp[:N, :K] = w
+        # [t][s][c][half][col][j] <- wp[32 t + col][64 s + 32 half + 4 c + j]
+        ref = wp.view(T_, 32, NS, 2, 8, 4).permute(0, 2, 4, 3, 1, 5).contiguous().view(-1)
+        assert torch.equal(dst, ref), (N, K)
+
+
+def test_packed_small_batch_weights_stay_current_and_change_no_bit(monkeypatch):
+    """Round 6: the small-batch kernels read their forward products' weights in operand order (no LDS parking), and the fused weight-gradient + Adam launches write every
+    parameter they step -- and its Polyak target -- into the packed copies, so a chain of batch-100 updates needs no packing launch.  Same values into the same matrix
+    instructions in the same order: twelve updates (every second one with the policy update; a torch-level write to the actor and an update whose Adam steps run as
+    separate kernels in between, both of which must trigger a re-pack) leave bitwise the parameters, targets, moments and losses of PLEN_TD3_TEAM_PACKED=0; at the end every packed copy equals a fresh
+    pack of its matrix."""
+    from plen_ml_walk_amd import td3 as T
+    from plen_ml_walk_amd import td3_fused as F
+    data = torch.randn(5000, 72, device="cuda")
+    data[:, 70] = torch.rand(5000, device="cuda"); data[:, 71] = (torch.rand(5000, device="cuda") > 0.1).float()
+    tot = torch.tensor(5000, dtype=torch.long, device="cuda")
+    out = {}
+    for packed in ("0", "1"):
+        monkeypatch.setenv("PLEN_TD3_TEAM_PACKED", packed)
+        torch.manual_seed(41)
+        ag = T.TD3Agent(26, 18, 1.0, data_parallel=False)
+        fz = F.FusedTD3(ag, seed=9)
+        fz.enable_flat_adam()
+        assert fz._team_packed == (packed == "1")
+        losses = []
+        for k in range(12):
+            if k == 5:
+                with torch.no_grad():
+                    ag.actor.fc2.weight.mul_(1.001)                  # a torch-level write (as load_state_dict would be): version counters move
+            if k == 8:
+                fz.fuse_adam = False                                # one update whose Adam steps are separate kernels (they know nothing of the packed copies; deterministic,
+                fz.update(data, 100, with_policy=True, all_reduce=False, total=tot)          # unlike the layer-by-layer path's float atomics)
+                fz.fuse_adam = True
+            losses.append(fz.update(data, 100 if k % 3 else 64, with_policy=(k % 2 == 1), all_reduce=False, total=tot).clone())
+            assert fz._team_pass and fz._tp_live == (packed == "1")
+        torch.cuda.synchronize()
+        out[packed] = losses + [ag._critic_flat.flat.clone(), ag._actor_flat.flat.clone(), ag._critic_target_flat.flat.clone(), ag._actor_target_flat.flat.clone(),
+                                fz._critic_adam.m.clone(), fz._actor_adam.v.clone(), fz._critic_adam.step_t.clone()]
+        if packed == "1":
+            have = {k: v.clone() for k, v in fz._tpacks.items()}
+            fz._tp_state = None
+            assert fz._team_pack_sync()                              # a fresh pack of every matrix as it is now
+            torch.cuda.synchronize()
+            assert len(have) == 12
+            for k, v in have.items():
+                assert torch.equal(v, fz._tpacks[k]), k
+    for a_, b_ in zip(out["0"], out["1"]):
+        assert torch.equal(a_, b_)
+
+
 def test_resumed_optimizer_keeps_its_step_count_through_the_fused_small_batch_update():
     """optimizer.load_state_dict() between updates (a resumed run) replaces the state tensors FlatAdam mirrors; the re-bind has to happen before the pass
     kernel counts the step, or the fused path's counter stays one behind the separate-Adam path's for good: after a reload at step 4, four
