@@ -28,6 +28,7 @@ itself as CHILD processes (decided before anything touches the GPU) and relays r
 JSON line.
 """
 import argparse
+import gc
 import json
 import os
 import subprocess
@@ -419,7 +420,10 @@ def td3_reference_leg(a, dev, rank, world, dist, n=64, steps=400):
            "update_path": "small-batch kernels (csrc/td3_team.hip: a team of 8 waves per 4 batch rows, all weight gradients + Adam + Polyak of a pass in one launch): "
                           "3 launches per critic update, 2 more per policy update; same bits every run",
            "workload": "the reference's recipe (plen_td3.py:21-30, 83-157): %d envs, one update of batch 100 per env-step, policy_freq 2, hipGraph-captured fused update" % n}
+    tr._graphs.clear()
     env.close()
+    del tr
+    gc.collect()
     # the same iteration as the reference's caller issues it: TD3Agent.train(replay_buffer, 100), eagerly from Python, one call per iteration (plen_td3.py:119-120)
     try:
         torch.manual_seed(1)
@@ -447,6 +451,7 @@ def policy_leg(a, dev, rank, world, dist, steps, warmup):
     random flailing; its episode statistics come with it."""
     import numpy as np
     import torch
+    from plen_ml_walk_amd.train_vec import capture_graph
     from plen_ml_walk_amd import sharding
     from plen_ml_walk_amd.vec_env import PlenVecEnv, worker_stream
     from plen_ml_walk_amd.td3 import TD3Agent
@@ -485,7 +490,7 @@ def policy_leg(a, dev, rank, world, dist, steps, warmup):
                         runs[h] = runs.get(h, 0) + 1
                         continue
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=streams[h], capture_error_mode="thread_local"):
+                    with capture_graph(g, stream=streams[h], capture_error_mode="thread_local"):
                         for _ in range(UNROLL):
                             collect(h)
                     graphs[h] = g
@@ -603,8 +608,11 @@ def _td3_run(a, dev, rank, world, dist, steps, warmup, batch):
                 out["roofline"] = _td3_roofline(tr, batch, dev)
             except Exception as ex:
                 out["roofline"] = {"error": repr(ex)}
+    tr._graphs.clear()
     for e in envs:
         e.close()
+    del tr
+    gc.collect()
     return out
 
 
@@ -619,6 +627,7 @@ def _td3_roofline(tr, batch, dev):
     running loop, beside the env launches: device-clock stamps (plentd3_stamp nodes in the update graph, the timeline probes of train_vec) right before and
     after the kernel over 128 more vector steps of the same trainer, re-captured with the probes in; (b) alone on the idle GPU: HIP events around 20 launches."""
     import torch
+    from plen_ml_walk_amd.train_vec import capture_graph
     tr.recapture()
     tl = tr.enable_timeline(64)
     tr.run(64 * 2 + 40 + 2)          # (whole six-step blocks once every piece has been re-captured: the schedule the leg was timed in)
@@ -650,7 +659,7 @@ def _td3_roofline(tr, batch, dev):
             one(); one()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()                 # (a graph: eagerly the 25 host calls per pass are slower than the kernel)
-        with torch.cuda.graph(g):
+        with capture_graph(g):
             for _ in range(8):
                 one()
         g.replay(); torch.cuda.synchronize()
@@ -821,6 +830,10 @@ def main():
                                           "wave-uniform scalars of each env's wavefront, so there is no lane divergence to pay for" % a.envs_per_gpu)
         except Exception as ex:                                  # the headline stands on its own; a failed leg is reported, not hidden
             legs[name] = {"value": None, "error": repr(ex)}       # (with N > 1 ranks fail alike: same code, same shapes, same device type)
+        # a leg's trainers sit in reference cycles: their hipGraphs go NOW, not whenever the collector runs (inside a later leg's stream capture a graph's
+        # destruction is an error that aborts the process: train_vec.capture_graph)
+        torch.cuda.synchronize()
+        gc.collect()
 
     if rank == 0:
         n = a.envs_per_gpu

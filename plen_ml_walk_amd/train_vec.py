@@ -22,6 +22,26 @@ import os
 import time
 
 import torch
+import contextlib
+import gc
+
+
+@contextlib.contextmanager
+def capture_graph(g, **kw):
+    """torch.cuda.graph(g, **kw) with the cyclic garbage collector held off for the duration of the capture.  The trainers (and their optimiser / probe lambdas) sit in
+    reference cycles, so an earlier trainer's CUDAGraph objects are destroyed whenever the collector happens to run -- and hipGraphDestroy DURING a stream capture is an
+    error ("operation not permitted when stream is capturing") that surfaces in a destructor and aborts the process (seen once in round 6: the driver's bench command,
+    intermittent).  torch.cuda.graph collects garbage before it begins; nothing may be collected until it has ended."""
+    was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        with torch.cuda.graph(g, **kw):
+            yield
+    finally:
+        if was:
+            gc.enable()
+
 
 
 def setup_distributed():
@@ -370,7 +390,7 @@ class GraphedVecTD3Trainer(object):
             return
         g = torch.cuda.CUDAGraph()
         # thread_local: another thread's HIP calls (the RCCL watchdog's event queries when world_size > 1) must not invalidate the capture
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        with capture_graph(g, capture_error_mode="thread_local"):
             fn(*args)
         self._graphs[key] = g
         g.replay()                                   # the capture itself does not execute
@@ -564,7 +584,7 @@ class PipelinedVecTD3Trainer(object):
                     self._eager_runs[key] = runs + 1
                     return
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+                with capture_graph(g, stream=stream, capture_error_mode="thread_local"):
                     fn(*args)
                 self._graphs[key] = g
             g.replay()
@@ -660,7 +680,7 @@ class PipelinedVecTD3Trainer(object):
         with torch.cuda.stream(su):
             if g is None:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=su, capture_error_mode="thread_local"):
+                with capture_graph(g, stream=su, capture_error_mode="thread_local"):
                     self._block_body(t, self.grad_steps)
                 self._graphs[key] = g
             g.replay()
