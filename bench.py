@@ -778,7 +778,10 @@ def main():
     ap.add_argument("--td3-steps", type=int, default=2000, help="timed vector steps of the td3 and policy legs (2000 x ~0.5 ms: about a second each)")
     ap.add_argument("--td3-parts", type=int, default=2, help="sub-batches of the pipelined TD3 loop (collector streams)")
     ap.add_argument("--td3-schedule", default="pipelined", choices=["pipelined", "sync"], help="actor/learner overlap on three streams per rank, or the synchronous graph loop")
-    ap.add_argument("--td3-block-graph", type=int, default=0, help="1: six vector steps of the pipelined TD3 loop per hipGraph replay (one rank; measured SLOWER, 6.5 against 8.5 M env-steps/s: the runtime serialises the graph's collector branches, profiles/r06_g_td3_block_graph.json); 0 (default): three graph replays per vector step")
+    ap.add_argument("--td3-block-graph", type=int, default=0,
+                    help="1: six vector steps of the pipelined TD3 loop per hipGraph replay (one rank; measured SLOWER, 6.5 against "
+                    "8.5 M env-steps/s: the runtime serialises the graph's collector branches, profiles/r06_g_td3_block_graph.json); "
+                    "0 (default): three graph replays per vector step")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
