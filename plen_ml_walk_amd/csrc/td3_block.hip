@@ -23,7 +23,15 @@
 // per-workgroup partials in workgroup order (last workgroup to arrive).  Nothing depends on timing: same bits every run.
 
 #define BLK_R 16                                // batch rows per workgroup
-#define BLK_NW 4                                // waves per workgroup
+#define BLK_NW 4                                // waves per workgroup (policy and actor passes)
+// k_critic_block's own wave count, 8 (4: round 5's form, an A/B build): eight waves of 32 features per layer put TWO waves on every SIMD inside the register
+// footprint of one (2 x 64 against 1 x 128 registers per SIMD -- the slots one retired f32 env wave per SIMD leaves; LDS 40 960 B either way).  At batch 4096 there
+// is one workgroup per compute unit, so the second wave is the only thing that can issue while the first waits: in-phase matrix-pipe occupancy 0.79 -> 0.88 of the
+// 256 x 256 layers, the thin phases (split 18-wide layer, gather) at half the per-wave work; 132 k -> 108 k shader cycles for workgroup 0 together with the hand-off
+// below, 75.6 -> 65.5 us per launch alone (profiles/r06_w_td3_block_stamps.json, r06_w_td3_block_kernel_stats.csv)
+#ifndef BLK_CRITIC_NW
+#define BLK_CRITIC_NW 8
+#endif
 // LDS activation buffers (floats per row; every stride a multiple of 64 so that the XOR swizzle stays inside one 64-float group)
 // the gathered replay row, not swizzled, re-arranged so that both critic inputs are contiguous: s 0..25 | a 26..43 | s2 44..69 | target action 70..87 | r 88 | not_done 89 | 0 0
 #define BLK_LD_ROW 92
@@ -167,36 +175,48 @@ static __device__ __forceinline__ float blk_l2_head(const BlkPre<NT> &pre, rsrc_
     }
     return part;
 }
+// lane ^ m's value (as __shfl_xor, without its width test: the bound `lane + 64` it keeps in a register across the whole kernel cost the eight-wave build a scratch slot)
+static __device__ __forceinline__ float blk_xor(float v, int lane, int m) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ m) << 2, __builtin_bit_cast(int, v)));
+}
+static __device__ __forceinline__ float blk_wave_sum(float v, int lane) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += blk_xor(v, lane, o);
+    return v;
+}
 // the four k-groups' partials of batch row r (lanes r, r + 16, r + 32, r + 48), in group order
-static __device__ __forceinline__ float blk_rowsum(float part) {
-    const float p1 = __shfl_xor(part, 16);
+static __device__ __forceinline__ float blk_rowsum(float part, int lane) {
+    const float p1 = blk_xor(part, lane, 16);
     const float s01 = part + p1;                 // (g, g ^ 1)
-    return s01 + __shfl_xor(s01, 32);
+    return s01 + blk_xor(s01, lane, 32);
 }
 
 // copy a 256-wide swizzled LDS buffer to columns col0.. of the row-major global matrix Y [B][ldy]: whole 1-KB row segments per wave
+template <int NW = BLK_NW>
 static __device__ __forceinline__ void blk_flush(const float *x, float *Y, int ldy, int col0, int b0, int B, int wv) {
     const Blk k = blk_ids(wv);
 #pragma unroll
-    for (int j = 0; j < BLK_R * 64 / (64 * BLK_NW); j++) {
-        const int i = BLK_TID(k) + 64 * BLK_NW * j, row = i >> 6, q = i & 63;
+    for (int j = 0; j < BLK_R * 64 / (64 * NW); j++) {
+        const int i = BLK_TID(k) + 64 * NW * j, row = i >> 6, q = i & 63;
         if (b0 + row < B) *reinterpret_cast<floatx4 *>(Y + (size_t)(b0 + row) * ldy + col0 + 4 * q) = *reinterpret_cast<const floatx4 *>(x + blk_at(BLK_LD_W, row, q));
     }
 }
-// an 18-wide layer (two 16-feature tiles) on a 256-wide swizzled input: its 256 k split over the four waves (64 each), the partial sums parked in a free LDS
+// an 18-wide layer (two 16-feature tiles) on a 256-wide swizzled input: its 256 k split over the NW waves (64 each of four), the partial sums parked in a free LDS
 // buffer as [wave][tile][lane] float4 and added in wave order by blk_split_sum after a barrier
+template <int NW = BLK_NW>
 static __device__ __forceinline__ void blk_split_k(rsrc_t wp, const float *x, float *park, const Blk &k) {
+    constexpr int S = 16 / NW;                         // k steps of 16 per wave
     const uint32_t voff = (uint32_t)k.lane * 16u;
-    floatx4 acc[2], a[4][2], b[4];
+    floatx4 acc[2], a[S][2], b[S];
     blk_zero(acc);
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
+    for (int s = 0; s < S; s++) {
 #pragma unroll
-        for (int t = 0; t < 2; t++) a[s][t] = bload4(wp, voff, (uint32_t)((t * 16 + 4 * k.w + s) * 1024));
-        b[s] = *reinterpret_cast<const floatx4 *>(x + blk_at(BLK_LD_W, k.r, 16 * k.w + 4 * s + k.g));
+        for (int t = 0; t < 2; t++) a[s][t] = bload4(wp, voff, (uint32_t)((t * 16 + S * k.w + s) * 1024));
+        b[s] = *reinterpret_cast<const floatx4 *>(x + blk_at(BLK_LD_W, k.r, 4 * S * k.w + 4 * s + k.g));
     }
 #pragma unroll
-    for (int s = 0; s < 4; s++)
+    for (int s = 0; s < S; s++)
 #pragma unroll
         for (int v = 0; v < 4; v++)
 #pragma unroll
@@ -204,10 +224,11 @@ static __device__ __forceinline__ void blk_split_k(rsrc_t wp, const float *x, fl
 #pragma unroll
     for (int t = 0; t < 2; t++) *reinterpret_cast<floatx4 *>(park + 4 * ((k.w * 2 + t) * 64 + k.lane)) = acc[t];
 }
+template <int NW = BLK_NW>
 static __device__ __forceinline__ floatx4 blk_split_sum(const float *park, int t, const Blk &k) {
     floatx4 z = *reinterpret_cast<const floatx4 *>(park + 4 * ((0 * 2 + t) * 64 + k.lane));
 #pragma unroll
-    for (int w2 = 1; w2 < 4; w2++) z += *reinterpret_cast<const floatx4 *>(park + 4 * ((w2 * 2 + t) * 64 + k.lane));
+    for (int w2 = 1; w2 < NW; w2++) z += *reinterpret_cast<const floatx4 *>(park + 4 * ((w2 * 2 + t) * 64 + k.lane));
     return z;
 }
 
@@ -248,16 +269,31 @@ __global__ __launch_bounds__(256) void k_pack(PlenTd3PackGroup G) {
 //      Resources are kept to what FOUR retiring env waves leave behind on a compute unit (one wave slot of 128 registers per SIMD, 41 KB of LDS): the update runs
 //      beside env launches that hold every wave slot of the chip (train_vec.PipelinedVecTD3Trainer), and a workgroup that needs more waits for more to retire.
 //      Hence two 256-wide activation buffers only: the twin critics go through them one after the other.
-__global__ __launch_bounds__(64 * BLK_NW) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_critic_block(PlenTd3CriticBlock P) {
+// The workgroup's loss / head-bias-gradient partials (wave 0): parked, made visible, counted (td3_kernels.hip: handoff_last); nonzero in lane 0 of the LAST workgroup
+// to get here.  (Counting BEFORE the kernel's last flush, so that the counter's round trip runs beside it: measured, 1.4 k of 111 k cycles, nothing in the leg; not kept.)
+static __device__ __forceinline__ int blk_park_sums(const float (*lt)[4], float *park, int *done_count, int n_blk, int lane) {
+    const float l = blk_wave_sum(lane < BLK_R ? lt[lane][0] + lt[lane][2] : 0.f, lane), ga = blk_wave_sum(lane < BLK_R ? lt[lane][1] : 0.f, lane), gb = blk_wave_sum(lane < BLK_R ? lt[lane][3] : 0.f, lane);
+    int last = 0;
+    if (lane == 0) last = handoff_last(park, l, ga, gb, done_count, n_blk);
+    return last;
+}
+__global__ __launch_bounds__(64 * BLK_CRITIC_NW) __attribute__((amdgpu_waves_per_eu(BLK_CRITIC_NW, BLK_CRITIC_NW))) void k_critic_block(PlenTd3CriticBlock P) {
     BLK_SETPRIO();
+    constexpr int NW = BLK_CRITIC_NW, NT = 16 / NW, RW = BLK_R / NW;          // waves; 16-feature tiles per wave and 256-wide layer; gathered rows per wave
+    static_assert(NW == 4 || NW == 8, "four waves of 64 features or eight of 32");
     const PlenTd3CriticRows &A = P.rows;
     __shared__ __attribute__((aligned(16))) float Rb[BLK_R * BLK_LD_ROW];
     __shared__ __attribute__((aligned(16))) float Ub[BLK_R * BLK_LD_W];
     __shared__ __attribute__((aligned(16))) float Vb[BLK_R * BLK_LD_W];
-    __shared__ float qp[4][4][BLK_R];            // [target a, target b, critic a, critic b][wave][row]: partial heads
-    __shared__ float nz[BLK_R][TD3_A];           // the target action's clipped smoothing noise; later the rows' loss terms
-    static_assert(sizeof(float) * (BLK_R * BLK_LD_ROW + 2 * BLK_R * BLK_LD_W + 4 * 4 * BLK_R + BLK_R * TD3_A) <= 40960, "four workgroups' worth of LDS per compute unit: the register cap below binds only then");
-    BlkPre<4> pre;
+    // [target a, target b, critic a, critic b][wave][row]: partial heads.  The target action's clipped smoothing noise [row][TD3_A] lives in the same words: it is
+    // consumed (target-action phase) two barriers before the first partial head is parked
+    constexpr int QPN = 4 * NW * BLK_R > BLK_R * TD3_A ? 4 * NW * BLK_R : BLK_R * TD3_A;
+    __shared__ float qpn[QPN];
+    __shared__ float lt[BLK_R][4];               // the rows' loss terms and head-bias gradients [critic a: e^2 / B, dq | critic b: ...]
+    float (*const qp)[NW][BLK_R] = reinterpret_cast<float (*)[NW][BLK_R]>(qpn);
+    float (*const nz)[TD3_A] = reinterpret_cast<float (*)[TD3_A]>(qpn);
+    static_assert(sizeof(float) * (BLK_R * BLK_LD_ROW + 2 * BLK_R * BLK_LD_W + QPN + BLK_R * 4) <= 40960, "four workgroups' worth of LDS per compute unit: the register cap below binds only then");
+    BlkPre<NT> pre;
     const int B = A.B, b0 = blockIdx.x * BLK_R, n_blk = (B + BLK_R - 1) / BLK_R;
     BLK_WAVE();
     BLK_STAMP_INIT();
@@ -266,8 +302,8 @@ __global__ __launch_bounds__(64 * BLK_NW) __attribute__((amdgpu_waves_per_eu(4, 
     {
         const Blk k = blk_ids(wv);
         int64_t id = 0;
-        if (k.lane < 4) {
-            const int b = min(b0 + 4 * k.w + k.lane, B - 1);
+        if (k.lane < RW) {
+            const int b = min(b0 + RW * k.w + k.lane, B - 1);
             if (A.idx) id = A.idx[b];
             else {
                 const int64_t tot = A.total[0];
@@ -283,8 +319,8 @@ __global__ __launch_bounds__(64 * BLK_NW) __attribute__((amdgpu_waves_per_eu(4, 
         }
         const int lo = (int)(id & 0xffffffff), hi = (int)(id >> 32);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int row = 4 * k.w + i, b = b0 + row;
+        for (int i = 0; i < RW; i++) {
+            const int row = RW * k.w + i, b = b0 + row;
             const int64_t rid = ((int64_t)__shfl(hi, i) << 32) | (uint32_t)__shfl(lo, i);
             const float *src = A.data + (size_t)rid * TD3_ROW;
             const float v0 = src[k.lane], v1 = k.lane < TD3_ROW - 64 ? src[64 + k.lane] : 0.f;
@@ -307,33 +343,33 @@ __global__ __launch_bounds__(64 * BLK_NW) __attribute__((amdgpu_waves_per_eu(4, 
     {
         const Blk k = blk_ids(wv);
         const rsrc_t w1 = mkrs(P.p_at_w1, (size_t)16 * 2 * 1024);
-        blk_dense_relu<4, 2, false>(blk_pre<4, 2>(w1, 4 * k.w, k), w1, 4 * k.w, Rb, BLK_LD_ROW, BLK_C_S2 / 4, A.at_b1, Ub, BLK_LD_W, 4 * k.w, k);
-        pre = blk_pre<4, 16>(mkrs(P.p_at_w2, (size_t)16 * 16 * 1024), 4 * k.w, k);
+        blk_dense_relu<NT, 2, false>(blk_pre<NT, 2>(w1, NT * k.w, k), w1, NT * k.w, Rb, BLK_LD_ROW, BLK_C_S2 / 4, A.at_b1, Ub, BLK_LD_W, NT * k.w, k);
+        pre = blk_pre<NT, 16>(mkrs(P.p_at_w2, (size_t)16 * 16 * 1024), NT * k.w, k);
     }
     TEAM_LDS_BARRIER(); BLK_STAMP(P, n_blk);
     {
         const Blk k = blk_ids(wv);
-        blk_dense_relu<4, 16>(pre, mkrs(P.p_at_w2, (size_t)16 * 16 * 1024), 4 * k.w, Ub, BLK_LD_W, 0, A.at_b2, Vb, BLK_LD_W, 4 * k.w, k);
+        blk_dense_relu<NT, 16>(pre, mkrs(P.p_at_w2, (size_t)16 * 16 * 1024), NT * k.w, Ub, BLK_LD_W, 0, A.at_b2, Vb, BLK_LD_W, NT * k.w, k);
     }
     TEAM_LDS_BARRIER(); BLK_STAMP(P, n_blk);
     {
         // the target action's clipped smoothing noise (td3.py:300-301), one element per thread, beside the split product (Philox + Box-Muller: 8 k cycles when
         // two waves drew it after the sum with the other two idle)
         const Blk k = blk_ids(wv);
-        for (int e = BLK_TID(k); e < BLK_R * TD3_A; e += 64 * BLK_NW) {
+        for (int e = BLK_TID(k); e < BLK_R * TD3_A; e += 64 * NW) {
             const int row = e / TD3_A, j = e - row * TD3_A, ge = min(b0 + row, B - 1) * TD3_A + j;
             const float zn = A.noise ? A.noise[ge] : rng_normal(A.rng, 1u, (uint32_t)ge);                 // torch.randn_like(action)
             nz[row][j] = fminf(fmaxf(zn * A.sigma, -A.clip), A.clip);
         }
-        blk_split_k(mkrs(P.p_at_w3, (size_t)2 * 16 * 1024), Vb, Ub, k);
-        pre = blk_pre<4, 3>(mkrs(P.p_ct_w14, (size_t)32 * 3 * 1024), 4 * k.w, k);
+        blk_split_k<NW>(mkrs(P.p_at_w3, (size_t)2 * 16 * 1024), Vb, Ub, k);
+        pre = blk_pre<NT, 3>(mkrs(P.p_ct_w14, (size_t)32 * 3 * 1024), NT * k.w, k);
     }
     TEAM_LDS_BARRIER(); BLK_STAMP(P, n_blk);
     // ---- target action (td3.py:299-304) by waves 0, 1 (one tile each); the first target critic's first layer on (s2, a2) has to wait for it ----
     {
         const Blk k = blk_ids(wv);
         if (k.w < 2) {
-            const floatx4 z = blk_split_sum(Ub, k.w, k);
+            const floatx4 z = blk_split_sum<NW>(Ub, k.w, k);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int j = 16 * k.w + 4 * k.g + i;
@@ -346,26 +382,26 @@ __global__ __launch_bounds__(64 * BLK_NW) __attribute__((amdgpu_waves_per_eu(4, 
     //      layer -> U, then b's second layer + head from U beside the critic's own first layer (a) -> V: every phase has a full matrix load on every wave ----
     {
         const Blk k = blk_ids(wv);
-        blk_dense_relu<4, 3, false>(pre, mkrs(P.p_ct_w14, (size_t)32 * 3 * 1024), 4 * k.w, Rb, BLK_LD_ROW, BLK_C_S2 / 4, A.ct_b14, Vb, BLK_LD_W, 4 * k.w, k);
-        pre = blk_pre<4, 16>(mkrs(P.p_ct_w2, (size_t)16 * 16 * 1024), 4 * k.w, k);
+        blk_dense_relu<NT, 3, false>(pre, mkrs(P.p_ct_w14, (size_t)32 * 3 * 1024), NT * k.w, Rb, BLK_LD_ROW, BLK_C_S2 / 4, A.ct_b14, Vb, BLK_LD_W, NT * k.w, k);
+        pre = blk_pre<NT, 16>(mkrs(P.p_ct_w2, (size_t)16 * 16 * 1024), NT * k.w, k);
     }
     TEAM_LDS_BARRIER(); BLK_STAMP(P, n_blk);
     {
         const Blk k = blk_ids(wv);
         const rsrc_t w14 = mkrs(P.p_ct_w14, (size_t)32 * 3 * 1024);
-        const float part = blk_rowsum(blk_l2_head<4, false>(pre, mkrs(P.p_ct_w2, (size_t)16 * 16 * 1024), 4 * k.w, Vb, BLK_LD_W, A.ct_b2, A.ct_w3, nullptr, 0, k));
+        const float part = blk_rowsum(blk_l2_head<NT, false>(pre, mkrs(P.p_ct_w2, (size_t)16 * 16 * 1024), NT * k.w, Vb, BLK_LD_W, A.ct_b2, A.ct_w3, nullptr, 0, k), k.lane);
         if (k.lane < BLK_R) qp[0][k.w][k.lane] = part;
-        blk_dense_relu<4, 3, false>(blk_pre<4, 3>(w14, 16 + 4 * k.w, k), w14, 16 + 4 * k.w, Rb, BLK_LD_ROW, BLK_C_S2 / 4, A.ct_b14, Ub, BLK_LD_W, 4 * k.w, k);
-        pre = blk_pre<4, 16>(mkrs(P.p_ct_w5, (size_t)16 * 16 * 1024), 4 * k.w, k);
+        blk_dense_relu<NT, 3, false>(blk_pre<NT, 3>(w14, 16 + NT * k.w, k), w14, 16 + NT * k.w, Rb, BLK_LD_ROW, BLK_C_S2 / 4, A.ct_b14, Ub, BLK_LD_W, NT * k.w, k);
+        pre = blk_pre<NT, 16>(mkrs(P.p_ct_w5, (size_t)16 * 16 * 1024), NT * k.w, k);
     }
     TEAM_LDS_BARRIER(); BLK_STAMP(P, n_blk);
     {
         const Blk k = blk_ids(wv);
         const rsrc_t w14 = mkrs(P.p_c_w14, (size_t)32 * 3 * 1024);
-        const float part = blk_rowsum(blk_l2_head<4, false>(pre, mkrs(P.p_ct_w5, (size_t)16 * 16 * 1024), 4 * k.w, Ub, BLK_LD_W, A.ct_b5, A.ct_w6, nullptr, 0, k));
+        const float part = blk_rowsum(blk_l2_head<NT, false>(pre, mkrs(P.p_ct_w5, (size_t)16 * 16 * 1024), NT * k.w, Ub, BLK_LD_W, A.ct_b5, A.ct_w6, nullptr, 0, k), k.lane);
         if (k.lane < BLK_R) qp[1][k.w][k.lane] = part;
-        blk_dense_relu<4, 3, false>(blk_pre<4, 3>(w14, 4 * k.w, k), w14, 4 * k.w, Rb, BLK_LD_ROW, 0, A.c_b14, Vb, BLK_LD_W, 4 * k.w, k);
-        pre = blk_pre<4, 16>(mkrs(P.p_c_w2, (size_t)16 * 16 * 1024), 4 * k.w, k);
+        blk_dense_relu<NT, 3, false>(blk_pre<NT, 3>(w14, NT * k.w, k), w14, NT * k.w, Rb, BLK_LD_ROW, 0, A.c_b14, Vb, BLK_LD_W, NT * k.w, k);
+        pre = blk_pre<NT, 16>(mkrs(P.p_c_w2, (size_t)16 * 16 * 1024), NT * k.w, k);
     }
     TEAM_LDS_BARRIER(); BLK_STAMP(P, n_blk);
     // ---- the critics (td3.py:312-323), one after the other: c1 in X, c2 -> Y (+ head), dh2 over c2, dh1 over c1, out; X / Y = V / U for critic a, U / V for b ----
@@ -374,10 +410,10 @@ __global__ __launch_bounds__(64 * BLK_NW) __attribute__((amdgpu_waves_per_eu(4, 
         float *X = c ? Ub : Vb, *Y = c ? Vb : Ub;
         {
             const Blk k = blk_ids(wv);
-            const float part = blk_rowsum(blk_l2_head<4, true>(pre, mkrs(c ? P.p_c_w5 : P.p_c_w2, (size_t)16 * 16 * 1024), 4 * k.w, X, BLK_LD_W, c ? A.c_b5 : A.c_b2, c ? A.c_w6 : A.c_w3, Y, BLK_LD_W, k));
+            const float part = blk_rowsum(blk_l2_head<NT, true>(pre, mkrs(c ? P.p_c_w5 : P.p_c_w2, (size_t)16 * 16 * 1024), NT * k.w, X, BLK_LD_W, c ? A.c_b5 : A.c_b2, c ? A.c_w6 : A.c_w3, Y, BLK_LD_W, k), k.lane);
             if (k.lane < BLK_R) qp[2 + c][k.w][k.lane] = part;
         }
-        blk_flush(X, A.c1, 2 * TD3_H, c * TD3_H, b0, B, wv);                 // c1 for the weight gradients (asynchronous: nothing below reads it back)
+        blk_flush<NW>(X, A.c1, 2 * TD3_H, c * TD3_H, b0, B, wv);                 // c1 for the weight gradients (asynchronous: nothing below reads it back)
         TEAM_LDS_BARRIER(); BLK_STAMP(P, n_blk);
         // the loss gradient at this critic's head, per row (every thread derives the rows it needs from the parked partial heads: no phase of its own), c2 to global
         // memory, and in its place dh2 = dq (x) w3 where the hidden unit was active (also to global memory)
@@ -387,9 +423,13 @@ __global__ __launch_bounds__(64 * BLK_NW) __attribute__((amdgpu_waves_per_eu(4, 
             const Blk k = blk_ids(wv);
             const floatx4 wh = blk_vec4(w3 + 4 * k.lane);            // (a thread's chunk q = its lane: the same four head weights for its four rows)
 #pragma unroll
-            for (int j = 0; j < BLK_R * 64 / (64 * BLK_NW); j++) {
-                const int row = k.w + BLK_NW * j, q = k.lane;
-                auto head = [&](int h, float b3_) { return ((qp[h][0][row] + qp[h][1][row]) + (qp[h][2][row] + qp[h][3][row])) + b3_; };
+            for (int j = 0; j < BLK_R / NW; j++) {
+                const int row = k.w + NW * j, q = k.lane;
+                auto head = [&](int h, float b3_) {
+                    float q4 = (qp[h][0][row] + qp[h][1][row]) + (qp[h][2][row] + qp[h][3][row]);
+                    if constexpr (NW == 8) q4 += (qp[h][4][row] + qp[h][5][row]) + (qp[h][6][row] + qp[h][7][row]);
+                    return q4 + b3_;
+                };
                 const float y = Rb[blk_lin(BLK_LD_ROW, row, BLK_C_R)] + Rb[blk_lin(BLK_LD_ROW, row, BLK_C_R + 1)] * A.gamma * fminf(head(0, tb3a), head(1, tb3b));
                 const float e = head(2 + c, b3) - y;
                 const bool in = b0 + row < B;
@@ -406,56 +446,50 @@ __global__ __launch_bounds__(64 * BLK_NW) __attribute__((amdgpu_waves_per_eu(4, 
                     *reinterpret_cast<floatx4 *>(A.dh2 + o) = dv;
                     if (q == 0) A.dq[2 * (b0 + row) + c] = d;
                 }
-                // the row's loss term and head-bias gradient, parked per row for the sums at the end (the noise buffer is free: the target action exists)
-                if (q == 0) { nz[row][2 * c] = in ? e * e * inv : 0.f; nz[row][2 * c + 1] = d; }
+                // the row's loss term and head-bias gradient, parked per row for the sums at the end
+                if (q == 0) { lt[row][2 * c] = in ? e * e * inv : 0.f; lt[row][2 * c + 1] = d; }
             }
         }
         {
             const Blk k = blk_ids(wv);
-            pre = blk_pre<4, 16>(mkrs(c ? P.p_c_w5t : P.p_c_w2t, (size_t)16 * 16 * 1024), 4 * k.w, k);
+            pre = blk_pre<NT, 16>(mkrs(c ? P.p_c_w5t : P.p_c_w2t, (size_t)16 * 16 * 1024), NT * k.w, k);
         }
         TEAM_LDS_BARRIER(); BLK_STAMP(P, n_blk);
         // dh1 = (W2^T dh2) where c1 was active, written over c1
         {
             const Blk k = blk_ids(wv);
-            floatx4 acc[4];
+            floatx4 acc[NT];
             blk_zero(acc);
-            blk_mm<4, 16>(pre, mkrs(c ? P.p_c_w5t : P.p_c_w2t, (size_t)16 * 16 * 1024), 4 * k.w, Y, BLK_LD_W, 0, acc, k);
+            blk_mm<NT, 16>(pre, mkrs(c ? P.p_c_w5t : P.p_c_w2t, (size_t)16 * 16 * 1024), NT * k.w, Y, BLK_LD_W, 0, acc, k);
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                float *pu = X + blk_at(BLK_LD_W, k.r, 4 * (4 * k.w + t) + k.g);
+            for (int t = 0; t < NT; t++) {
+                float *pu = X + blk_at(BLK_LD_W, k.r, 4 * (NT * k.w + t) + k.g);
                 const floatx4 m = *reinterpret_cast<const floatx4 *>(pu);
                 floatx4 v;
 #pragma unroll
                 for (int i = 0; i < 4; i++) v[i] = m[i] > 0.f ? acc[t][i] : 0.f;
                 *reinterpret_cast<floatx4 *>(pu) = v;
             }
-            if (c == 0) pre = blk_pre<4, 3>(mkrs(P.p_c_w14, (size_t)32 * 3 * 1024), 16 + 4 * k.w, k);
+            if (c == 0) pre = blk_pre<NT, 3>(mkrs(P.p_c_w14, (size_t)32 * 3 * 1024), 16 + NT * k.w, k);
         }
         TEAM_LDS_BARRIER(); BLK_STAMP(P, n_blk);
-        blk_flush(X, A.dh1, 2 * TD3_H, c * TD3_H, b0, B, wv);
         if (c == 0) {        // critic b's first layer -> U (= Y of critic a: its dh2 is dead), beside the flush of dh1_a from V
+            blk_flush<NW>(X, A.dh1, 2 * TD3_H, c * TD3_H, b0, B, wv);
             const Blk k = blk_ids(wv);
-            blk_dense_relu<4, 3, false>(pre, mkrs(P.p_c_w14, (size_t)32 * 3 * 1024), 16 + 4 * k.w, Rb, BLK_LD_ROW, 0, A.c_b14, Ub, BLK_LD_W, 4 * k.w, k);
-            pre = blk_pre<4, 16>(mkrs(P.p_c_w5, (size_t)16 * 16 * 1024), 4 * k.w, k);
+            blk_dense_relu<NT, 3, false>(pre, mkrs(P.p_c_w14, (size_t)32 * 3 * 1024), 16 + NT * k.w, Rb, BLK_LD_ROW, 0, A.c_b14, Ub, BLK_LD_W, NT * k.w, k);
+            pre = blk_pre<NT, 16>(mkrs(P.p_c_w5, (size_t)16 * 16 * 1024), NT * k.w, k);
             TEAM_LDS_BARRIER(); BLK_STAMP(P, n_blk);
         }
     }
     // ---- loss and the head biases' gradients: per-row terms live in the threads with q == 0 (lanes 0 of ... every wave holds 4 rows' worth): workgroup sums
     //      through LDS in thread order, one partial per workgroup; the last workgroup to get here adds them in workgroup order (as k_critic_team) ----
+    //      (the per-row terms were parked before the last two barriers; critic b's dh1 leaves from U)
+    blk_flush<NW>(Ub, A.dh1, 2 * TD3_H, TD3_H, b0, B, wv);
     if (wv == 0) {
         const int lane = blk_ids(wv).lane;
-        // (the per-row terms were parked before the last two barriers)
-        const float l = wave_sum(lane < BLK_R ? nz[lane][0] + nz[lane][2] : 0.f), ga = wave_sum(lane < BLK_R ? nz[lane][1] : 0.f), gb = wave_sum(lane < BLK_R ? nz[lane][3] : 0.f);
-        int last = 0;
-        if (lane == 0) {
-            float *park = P.partials + 4 * blockIdx.x;
-            park[0] = l; park[1] = ga; park[2] = gb;
-            __threadfence();
-            last = atomicAdd(A.done_count, 1) == n_blk - 1;
-        }
+        const int last = blk_park_sums(lt, P.partials + 4 * blockIdx.x, A.done_count, n_blk, lane);
         if (__builtin_amdgcn_readfirstlane(last)) {          // one workgroup's partials per lane, then added in lane order (a single lane fetching 256 x 3 partials
-            __threadfence();                                 // one after the other was 9 k cycles at the end of the kernel)
+            handoff_acquire();                               // one after the other was 9 k cycles at the end of the kernel)
             float sl = 0.f, sa = 0.f, sb = 0.f;
             for (int c0 = 0; c0 < n_blk; c0 += 64) {
                 const int j = c0 + lane;

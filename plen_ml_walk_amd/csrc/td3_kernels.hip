@@ -60,6 +60,37 @@ static __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// A workgroup hands three partial sums to whichever workgroup gets here last (called by ONE lane): parked, made visible, counted; true for the last one.
+// TD3_LIGHT_HANDOFF (default): the partials leave as write-through (agent-scope) stores and are waited for before the count -- what the last workgroup reads (with
+// agent-scope loads, after its acquire) has reached the agent's coherence point.  The textbook form (0: plain stores, __threadfence(), atomicAdd) makes the same three
+// words visible by a RELEASE FENCE, which on this chip is `buffer_wbl2 sc1`: a write-back of every dirty line the XCD's L2 holds -- here the kernel's own activations
+// and gradients on their way to the weight-gradient kernel, megabytes at batch 4096.  Phase stamps of k_critic_block's workgroup 0: 17.2 k of 132.7 k shader cycles
+// in the closing phase with the fence, 5.5 k without (profiles/r06_t_critic_block_variants.txt).
+#ifndef TD3_LIGHT_HANDOFF
+#define TD3_LIGHT_HANDOFF 1
+#endif
+static __device__ __forceinline__ bool handoff_last(float *park, float a, float b, float c, int *done_count, int n_workgroups) {
+#if TD3_LIGHT_HANDOFF
+    __hip_atomic_store(park + 0, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(park + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(park + 2, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return __hip_atomic_fetch_add(done_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_workgroups - 1;
+#else
+    park[0] = a; park[1] = b; park[2] = c;
+    __threadfence();
+    return atomicAdd(done_count, 1) == n_workgroups - 1;
+#endif
+}
+// the last workgroup, before it reads the others' partials (agent-scope loads): an acquire -- an invalidate, not another write-back
+static __device__ __forceinline__ void handoff_acquire() {
+#if TD3_LIGHT_HANDOFF
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+    __threadfence();
+#endif
+}
+
 // ---- K1: gather sampled replay rows (td3.py:166-193 ReplayBuffer.sample): out[b][:] = data[idx[b]][:] (row = s26 | a18 | s2_26 | r | not_done),
 //      and the state part again into the policy pass's state-action matrix sa_pi[b][0:26].  Also zeroes the loss accumulator.
 __global__ void k_gather(const float *__restrict__ data, const int64_t *__restrict__ idx, float *__restrict__ out, float *__restrict__ sa_pi, float *loss, int B) {
@@ -373,15 +404,23 @@ __global__ void k_store(float *__restrict__ data, const int64_t *total, int64_t 
     // plentd3_store_step: *total += step once every block has read it -- the last block to get here does it (each block's first thread counts itself in after the
     // block's reads; the counter is left at zero for the next launch).  Replaces the caller's one-element add kernel on its critical path.
     // (`total` and `total_step` are the SAME word in step mode: neither is restrict-qualified, the read is an atomic load -- not a load the compiler may treat as
-    // invariant and sink past the barrier --, and the hand-off is fenced like k_critic_block's: every block's read is ordered before its count, the last block's store
-    // after the count it saw.  ADVICE r05.)
+    // invariant and sink past the barrier --, and every block's read is ordered before its count, the last block's store after the count it saw.  ADVICE r05.)
     const int64_t total0 = __hip_atomic_load(total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (blocks_done) {
+#if TD3_LIGHT_HANDOFF
+        // what has to be ordered is a READ before the count (every thread's load of `total` has RETURNED before its block counts itself in) and the last block's store
+        // after the count it saw (it is conditional on the atomic's result): no release fence -- here an L2 write-back per block, 576 of them per 2048-env step, beside
+        // an update whose activations sit dirty in the same L2 (handoff_last above)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0 && __hip_atomic_fetch_add(blocks_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) { blocks_done[0] = 0; total_step[0] = total0 + step; }
+#else
         __syncthreads();
         if (threadIdx.x == 0) {
             __threadfence();
             if (atomicAdd(blocks_done, 1u) == gridDim.x - 1) { __threadfence(); blocks_done[0] = 0; total_step[0] = total0 + step; }
         }
+#endif
     }
     if (e >= n) return;
     // episode bookkeeping at full speed (the reference prints every episode's return, plen_env.py:616-636): per-env running return; when the
@@ -672,7 +711,7 @@ int plentd3_pack(const PlenTd3PackGroup *group, void *stream) {
 }
 int plentd3_critic_block(const PlenTd3CriticBlock *args, void *stream) {
     if (!args || args->rows.B <= 0 || !args->partials || !args->p_at_w1 || !args->p_c_w5t) return -(int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_critic_block, dim3((args->rows.B + BLK_R - 1) / BLK_R), dim3(64 * BLK_NW), 0, (hipStream_t)stream, *args); CHECK();
+    hipLaunchKernelGGL(k_critic_block, dim3((args->rows.B + BLK_R - 1) / BLK_R), dim3(64 * BLK_CRITIC_NW), 0, (hipStream_t)stream, *args); CHECK();
 }
 int plentd3_policy_block(const PlenTd3PolicyBlock *args, void *stream) {
     if (!args || args->rows.B <= 0 || !args->p_a_w1 || !args->p_a_w2t || (args->rows.adam_step && !args->rows.done_count)) return -(int)hipErrorInvalidValue;

@@ -378,9 +378,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             }
         }
     }
-    // the last wave to finish advances the random stream's call counter: every wave has read it by then
+    // the last wave to finish advances the random stream's call counter: every wave has read it by then (its draws are long consumed: no release fence, which
+    // here would be an L2 write-back per wave -- td3_kernels.hip: handoff_last)
     if (lane == 0) {
+#if !TD3_LIGHT_HANDOFF
         __threadfence();
+#endif
         if (atomicAdd(A.done_count, 1) == (int)gridDim.x - 1) { A.done_count[0] = 0; if (A.rng_bump) A.rng_bump[1] += 1; }
     }
 }

@@ -379,14 +379,9 @@ __global__ __launch_bounds__(64 * TEAM_NW) __attribute__((amdgpu_waves_per_eu(2,
         // kernel, behind a barrier and a fence that waited for the last layer's stores, and with the partials fetched one after the other, this
         // protocol was 8 us of every update.)
         int last = 0;
-        if (lane == 0) {
-            float *park = A.t1 + (size_t)b0 * 2 * TD3_H + TD3_H;
-            park[0] = lsum; park[1] = ga; park[2] = gb;
-            __threadfence();
-            last = atomicAdd(A.done_count, 1) == n_team - 1;
-        }
+        if (lane == 0) last = handoff_last(A.t1 + (size_t)b0 * 2 * TD3_H + TD3_H, lsum, ga, gb, A.done_count, n_team);
         if (__builtin_amdgcn_readfirstlane(last)) {
-            __threadfence();
+            handoff_acquire();
             float l = 0.f, sa = 0.f, sb = 0.f;
             for (int c0 = 0; c0 < n_team; c0 += 64) {            // one workgroup's partials per lane, then added in lane order
                 const int k = c0 + lane;
