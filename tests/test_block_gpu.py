@@ -165,3 +165,30 @@ def test_collect_phase_actor_forward_block_kernel_equals_the_row_kernel(n):
     with torch.no_grad():
         ref = ag.max_action * torch.tanh(ag.actor.fc3(torch.relu(ag.actor.fc2(torch.relu(ag.actor.fc1(state))))))
     assert float((fresh - ref).abs().max()) <= 2e-5
+
+
+@pytest.mark.parametrize("shape,B", [("block", 4096), ("block", 1000), ("team", 100), ("team", 256)])
+def test_loss_partials_reach_the_last_workgroup_every_time(shape, B):
+    """The workgroups' loss / head-bias partials are handed to the last workgroup WITHOUT a release fence (csrc/td3_kernels.hip: handoff_last -- write-through
+    stores, waited for, then the count): 400 launches back to back, no host synchronisation in between, each from the same random state -- loss and both head-bias
+    gradients come out with the same bits every time and the counter is back at zero.  (A partial read before it arrived would show as a different sum.)"""
+    from plen_ml_walk_amd.td3_fused import FusedTD3
+    ag = _agent(33)
+    fz = FusedTD3(ag, seed=4, team=(shape == "team"), rows=False, block=(shape == "block"))
+    data = torch.randn(5000, 72, device="cuda")
+    data[:, 70] = torch.rand(5000, device="cuda")
+    data[:, 71] = (torch.rand(5000, device="cuda") > 0.1).float()
+    tot = torch.tensor(5000, dtype=torch.long, device="cuda")
+    rng0 = fz.rng.clone()
+    cr = ag.critic
+    out = torch.empty(400, 3, device="cuda")
+    for i in range(400):
+        fz.rng.copy_(rng0)
+        ag._critic_grads.zero(); fz._zeroed = {}
+        loss = fz.critic_backward(data, B, total=tot)
+        out[i, 0], out[i, 1], out[i, 2] = loss, cr.fc3.bias.grad[0], cr.fc6.bias.grad[0]
+    torch.cuda.synchronize()
+    assert (fz._block_pass, fz._team_pass) == (shape == "block", shape == "team")
+    assert int(fz._done_count) == 0
+    assert bool(torch.isfinite(out).all()) and float(out[0, 0]) > 0
+    assert bool((out == out[0]).all()), out[(out != out[0]).any(dim=1)][:4]
