@@ -872,50 +872,68 @@ __global__ __launch_bounds__(256) void k_adam_big(float *__restrict__ p, float *
 //      (packed weights, transposed products, activations in LDS).  It is on every vector step's critical path -- a sub-batch's env launch cannot start before it --
 //      and k_actor_rows4 (unpacked weights, activations through global memory) took 20 us per 2048 envs alone, 30-67 us beside the other collector's env launch.
 //      Same draws as k_actor_rows (noise index = element index); p1 / p2 are not written.
-__global__ __launch_bounds__(64 * BLK_NW) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_actor_block(PlenTd3ActorBlock P) {
+// (BLK_ACTOR_NW waves, 8 as in k_critic_block: two waves per SIMD in the registers of one; 4 = round 5's form.  The exploration noise -- Philox + Box-Muller, ~8 k cycles
+//  when the two waves that own the output tiles drew it after the last sum -- is drawn by ALL threads at the kernel's start, beside the state rows' trip from memory,
+//  and parked in LDS: same counters, same values.)
+#ifndef BLK_ACTOR_NW
+#define BLK_ACTOR_NW 8
+#endif
+__global__ __launch_bounds__(64 * BLK_ACTOR_NW) __attribute__((amdgpu_waves_per_eu(BLK_ACTOR_NW, BLK_ACTOR_NW))) void k_actor_block(PlenTd3ActorBlock P) {
+    constexpr int NW = BLK_ACTOR_NW, NT = 16 / NW;
+    static_assert(NW == 4 || NW == 8, "four waves of 64 features or eight of 32");
     const PlenTd3ActorRows &A = P.rows;
     __shared__ __attribute__((aligned(16))) float Sb[BLK_R * PB_LD_SA];
     __shared__ __attribute__((aligned(16))) float Xb[BLK_R * BLK_LD_W];
     __shared__ __attribute__((aligned(16))) float Yb[BLK_R * BLK_LD_W];
+    __shared__ float nz[BLK_R * TD3_A];          // noise * sigma of the block's 16 x 18 actions
+    static_assert(sizeof(float) * (BLK_R * PB_LD_SA + 2 * BLK_R * BLK_LD_W + BLK_R * TD3_A) <= 40960, "four workgroups' worth of LDS per compute unit");
     const int B = A.B, b0 = blockIdx.x * BLK_R;
     BLK_WAVE();
-    BlkPre<4> pre;
+    BlkPre<NT> pre;
     {
         const Blk k = blk_ids(wv);
-        pre = blk_pre<4, 2>(mkrs(P.p_a_w1, (size_t)16 * 2 * 1024), 4 * k.w, k);
-        for (int i = BLK_TID(k); i < BLK_R * PB_LD_SA; i += 64 * BLK_NW) {
-            const int row = i / PB_LD_SA, c = i - row * PB_LD_SA;
-            Sb[i] = c < TD3_S ? A.state[(size_t)min(b0 + row, B - 1) * TD3_S + c] : 0.f;
+        float sv[(BLK_R * PB_LD_SA + 64 * NW - 1) / (64 * NW)];
+#pragma unroll
+        for (int u = 0; u < (BLK_R * PB_LD_SA + 64 * NW - 1) / (64 * NW); u++) {
+            const int i = BLK_TID(k) + 64 * NW * u, row = i / PB_LD_SA, c = i - row * PB_LD_SA;
+            sv[u] = (i < BLK_R * PB_LD_SA && c < TD3_S) ? A.state[(size_t)min(b0 + row, B - 1) * TD3_S + c] : 0.f;
         }
+        for (int e = BLK_TID(k); e < BLK_R * TD3_A; e += 64 * NW) {          // (beside the loads above)
+            const int row = e / TD3_A, j = e - row * TD3_A;
+            nz[e] = rng_normal(A.rng, 2u, (uint32_t)(min(b0 + row, B - 1) * TD3_A + j)) * A.sigma;
+        }
+#pragma unroll
+        for (int u = 0; u < (BLK_R * PB_LD_SA + 64 * NW - 1) / (64 * NW); u++) {
+            const int i = BLK_TID(k) + 64 * NW * u;
+            if (i < BLK_R * PB_LD_SA) Sb[i] = sv[u];
+        }
+        pre = blk_pre<NT, 2>(mkrs(P.p_a_w1, (size_t)16 * 2 * 1024), NT * k.w, k);          // (after the draw: its registers would not fit beside Philox's at 64)
     }
     TEAM_LDS_BARRIER();
     {
         const Blk k = blk_ids(wv);
-        blk_dense_relu<4, 2, false>(pre, mkrs(P.p_a_w1, (size_t)16 * 2 * 1024), 4 * k.w, Sb, PB_LD_SA, 0, A.a_b1, Xb, BLK_LD_W, 4 * k.w, k);
-        pre = blk_pre<4, 16>(mkrs(P.p_a_w2, (size_t)16 * 16 * 1024), 4 * k.w, k);
+        blk_dense_relu<NT, 2, false>(pre, mkrs(P.p_a_w1, (size_t)16 * 2 * 1024), NT * k.w, Sb, PB_LD_SA, 0, A.a_b1, Xb, BLK_LD_W, NT * k.w, k);
+        pre = blk_pre<NT, 16>(mkrs(P.p_a_w2, (size_t)16 * 16 * 1024), NT * k.w, k);
     }
     TEAM_LDS_BARRIER();
     {
         const Blk k = blk_ids(wv);
-        blk_dense_relu<4, 16>(pre, mkrs(P.p_a_w2, (size_t)16 * 16 * 1024), 4 * k.w, Xb, BLK_LD_W, 0, A.a_b2, Yb, BLK_LD_W, 4 * k.w, k);
+        blk_dense_relu<NT, 16>(pre, mkrs(P.p_a_w2, (size_t)16 * 16 * 1024), NT * k.w, Xb, BLK_LD_W, 0, A.a_b2, Yb, BLK_LD_W, NT * k.w, k);
     }
     TEAM_LDS_BARRIER();
     {
         const Blk k = blk_ids(wv);
-        blk_split_k(mkrs(P.p_a_w3, (size_t)2 * 16 * 1024), Yb, Xb, k);
+        blk_split_k<NW>(mkrs(P.p_a_w3, (size_t)2 * 16 * 1024), Yb, Xb, k);
     }
     TEAM_LDS_BARRIER();
     {
         const Blk k = blk_ids(wv);
         if (k.w < 2) {
-            const floatx4 z = blk_split_sum(Xb, k.w, k);
+            const floatx4 z = blk_split_sum<NW>(Xb, k.w, k);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int j = 16 * k.w + 4 * k.g + i, b = b0 + k.r;
-                if (j < TD3_A && b < B) {
-                    const int e = b * TD3_A + j;
-                    A.action[e] = fminf(fmaxf(A.max_a * tanhf(z[i] + A.a_b3[j]) + rng_normal(A.rng, 2u, (uint32_t)e) * A.sigma, -A.max_a), A.max_a);
-                }
+                if (j < TD3_A && b < B) A.action[b * TD3_A + j] = fminf(fmaxf(A.max_a * tanhf(z[i] + A.a_b3[j]) + nz[k.r * TD3_A + j], -A.max_a), A.max_a);
             }
         }
     }

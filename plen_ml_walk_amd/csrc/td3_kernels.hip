@@ -740,7 +740,7 @@ int plentd3_adam_big(float *p, float *g, float *m, float *v, float *step, int *d
 }
 int plentd3_actor_block(const PlenTd3ActorBlock *args, void *stream) {
     if (!args || args->rows.B <= 0 || !args->p_a_w1 || !args->p_a_w2 || !args->p_a_w3 || !args->rows.state || !args->rows.action || !args->rows.rng) return -(int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_actor_block, dim3((args->rows.B + BLK_R - 1) / BLK_R), dim3(64 * BLK_NW), 0, (hipStream_t)stream, *args); CHECK();
+    hipLaunchKernelGGL(k_actor_block, dim3((args->rows.B + BLK_R - 1) / BLK_R), dim3(64 * BLK_ACTOR_NW), 0, (hipStream_t)stream, *args); CHECK();
 }
 int plentd3_dev_mfma_spin(int workgroups, int iters, float *sink, void *stream) {
     hipLaunchKernelGGL(k_dev_mfma_spin, dim3(workgroups), dim3(64), 0, (hipStream_t)stream, iters, sink); CHECK();
