@@ -163,7 +163,7 @@ typedef struct PlenTd3AdamFused {
 int plentd3_wgrad_adam_group(const PlenTd3WgradGroup *group, const PlenTd3AdamFused *adam, void *stream);
 
 /* The same two passes for LARGE batches (BASELINE.json configs[2]: batch 4096): 16 batch rows per workgroup, one workgroup per compute unit at batch 4096;
- * its waves (eight in the critic pass: two per SIMD inside 2 x 64 registers; four in the policy pass) split every layer's output features, the products are formed transposed (Y^T = W X^T) so that activations stay in LDS from
+ * its waves (eight in the critic pass and the actor forward: two per SIMD inside 2 x 64 registers; four in the policy pass) split every layer's output features, the products are formed transposed (Y^T = W X^T) so that activations stay in LDS from
  * the gathered replay rows to the last gradient, and the weights are read PRE-PACKED in matrix-core operand order (csrc/td3_block.hip).
  * plentd3_pack writes that order: job j packs the N x K matrix M (element (i, k) at src[i rs + k cs]: rs / cs express W or W^T or a column block of it)
  * into dst, zero-padded to 16-row tiles and 16-k steps: dst float4 ((t KS + s) 64 + lane) = M[16 t + lane % 16][16 s + 4 (lane / 16) + (0..3)],

@@ -279,7 +279,7 @@ class FusedTD3(object):
         # (plentd3_wgrad_group): 2 + 1 (Adam) launches per critic update instead of ~35.  None: chosen per call, batch <= TEAM_MAX_BATCH.
         self.team = (None if "PLEN_TD3_TEAM" not in os.environ else os.environ["PLEN_TD3_TEAM"] == "1") if team is None else bool(team)
         self._team_pass = False      # did the last critic pass take the team kernels (policy_backward follows it)
-        # large batches (the benchmark's 4096): 16 batch rows per workgroup -- one per compute unit at batch 4096 --, its waves (critic pass: eight, policy pass: four)
+        # large batches (the benchmark's 4096): 16 batch rows per workgroup -- one per compute unit at batch 4096 --, its waves (critic pass and actor forward: eight, policy pass: four)
         # split every layer's output features, activations stay in LDS, weights are read pre-packed in matrix-core operand order (csrc/td3_block.hip).  None: chosen per
         # call, batch > TEAM_MAX_BATCH; the weight gradients stay what `rows` says (single-wave or 4-wave workgroups).
         self.block = (None if "PLEN_TD3_BLOCK" not in os.environ else os.environ["PLEN_TD3_BLOCK"] == "1") if block is None else bool(block)
